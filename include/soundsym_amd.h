@@ -1,0 +1,184 @@
+/*
+ * soundsym_amd.h -- C ABI of the MI355X-native segment-distance matcher.
+ *
+ * This is the drop-in boundary for ONE hot path of andrewcsmith/soundsym: the all-pairs
+ * segment-distance search + per-target argmin.  The reference has no FFI of its own (pure Rust,
+ * no `extern "C"`); every entry point below names the reference interface it replaces so that a
+ * maintainer can bind it 1:1 from Rust (`INTEGRATION.md` shows the binding).  Reference citations
+ * are relative to the upstream repository root.
+ *
+ * Conventions
+ *   - plain C: opaque handles, plain pointers and sizes, no C++ types, no exceptions;
+ *   - every function returns an int32 status (0 = SSYM_OK, negative = error); the message for the
+ *     last failure on a context is ssym_last_error(ctx);
+ *   - a "segment" is what the reference calls a Sound inside a SoundDictionary / SoundSequence:
+ *     `frames x dim` feature values, frame-major, contiguous (Sound::mfccs(), src/sound.rs:189-193;
+ *     segment slicing src/sound.rs:330-343).  A set of segments is handed over as ONE flat value
+ *     buffer plus `n+1` FRAME offsets: segment i = values [off[i]*dim, off[i+1]*dim);
+ *   - the library COPIES caller memory at create time (the caller keeps ownership, like the Rust
+ *     side keeps its Vec<Arc<Sound>>); results are indices into the dictionary, the Rust side
+ *     then does `dict.sounds[idx].clone()` exactly as src/sound.rs:369 does;
+ *   - calls are synchronous on the caller's thread, like the reference (no threads there).  One
+ *     context per thread, or an external lock.  A context owns one HIP stream on one GPU;
+ *   - there is NO CPU fallback: without a usable gfx950 device ssym_ctx_create fails with
+ *     SSYM_E_NO_DEVICE.
+ *
+ * Metric modes (SURVEY.md section 0 / DESIGN.md)
+ *   SSYM_METRIC_REFCOS  the reference's own segment distance: cosine_sim (src/sound.rs:22-33,
+ *                       prefix dot / product of squared norms, f64) searched by at_distance
+ *                       (src/sound.rs:351-370): argmin_i |sim_i - distance|, first minimum wins,
+ *                       fold start (0, 2.0).  Arithmetic order follows the reference bit for bit.
+ *   SSYM_METRIC_DTW     dynamic time warping over frame-wise L2 local costs with min-of-three
+ *                       recurrence and optional Sakoe-Chiba band (not in the reference; defined
+ *                       in DESIGN.md).  argmin_i |cost_i - distance| (distance NULL = 0), first
+ *                       minimum wins, fold start (0, +inf).
+ */
+#ifndef SOUNDSYM_AMD_H
+#define SOUNDSYM_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSYM_ABI_VERSION 1
+
+#if defined(__GNUC__)
+#define SSYM_API __attribute__((visibility("default")))
+#else
+#define SSYM_API
+#endif
+
+typedef struct ssym_ctx ssym_ctx;         /* one GPU + one stream + scratch                      */
+typedef struct ssym_dict ssym_dict;       /* SoundDictionary's feature side (src/sound.rs:290)   */
+typedef struct ssym_queries ssym_queries; /* the targets of one batch (SoundSequence::sounds)    */
+
+enum {
+    SSYM_OK = 0,
+    SSYM_E_INVALID = -1,     /* bad argument (NULL, dim mismatch, non-monotonic offsets, ...)    */
+    SSYM_E_EMPTY_DICT = -2,  /* replaces the reference's panic at src/sound.rs:369               */
+    SSYM_E_NO_DEVICE = -3,   /* no usable gfx950 device / HIP runtime -- there is no CPU path    */
+    SSYM_E_HIP = -4,         /* a HIP call failed; see ssym_last_error                           */
+    SSYM_E_NOMEM = -5,
+    SSYM_E_UNSUPPORTED = -6  /* shape outside what the kernels handle (see DESIGN.md limits)     */
+};
+
+enum { SSYM_METRIC_REFCOS = 0, SSYM_METRIC_DTW = 1 };
+enum { SSYM_DTYPE_F64 = 0, SSYM_DTYPE_F32 = 1 };
+
+/* flags for ssym_match_queries */
+enum {
+    SSYM_OUT_DEVICE = 1u,      /* out_idx / out_cost are device pointers on ctx's GPU            */
+    SSYM_DTW_FORCE_EXACT = 2u  /* skip the f32 MFMA filter: exact f64 kernel on every pair       */
+};
+
+typedef struct ssym_config {
+    uint32_t struct_size;  /* = sizeof(ssym_config)                                              */
+    int32_t device;        /* HIP device ordinal                                                 */
+    int32_t metric;        /* SSYM_METRIC_*                                                      */
+    int32_t dtype;         /* SSYM_DTYPE_* of every feature buffer handed to this context        */
+    int32_t band;          /* dtw: Sakoe-Chiba radius in frames, -1 = none                       */
+    int32_t dtw_squared;   /* dtw: 0 = L2 local cost (default), 1 = squared L2                   */
+    void *stream;          /* hipStream_t to enqueue on; NULL = the library creates one          */
+} ssym_config;
+
+/* Per-phase device time of the LAST ssym_match_* call on the context, measured with HIP events
+ * recorded on the context's stream (milliseconds; 0 when a phase did not run). */
+typedef struct ssym_timings {
+    float pack_ms;      /* target packing (only when the call packed targets itself)             */
+    float main_ms;      /* dtw: MFMA filter kernel / refcos: similarity tile kernel              */
+    float select_ms;    /* dtw: column min + candidate selection                                 */
+    float refine_ms;    /* dtw: exact f64 re-scoring of candidates (or of every pair)            */
+    float reduce_ms;    /* final per-target argmin                                               */
+    float total_ms;     /* first event to last event                                             */
+    uint64_t n_pairs;   /* n_sources * n_targets of the call                                     */
+    uint64_t n_refined; /* dtw: pairs re-scored exactly                                          */
+    int32_t main_launches; /* kernel launches that made up main_ms                               */
+    int32_t used_filter;   /* dtw: 1 = MFMA filter + refine, 0 = exact kernel on every pair      */
+} ssym_timings;
+
+SSYM_API int32_t ssym_abi_version(void);
+
+/* Context ------------------------------------------------------------------------------------ */
+SSYM_API int32_t ssym_ctx_create(const ssym_config *cfg, ssym_ctx **out);
+SSYM_API int32_t ssym_ctx_destroy(ssym_ctx *ctx);
+SSYM_API const char *ssym_last_error(const ssym_ctx *ctx); /* ctx may be NULL: last create failure       */
+SSYM_API int32_t ssym_ctx_synchronize(ssym_ctx *ctx);
+SSYM_API int32_t ssym_get_timings(const ssym_ctx *ctx, ssym_timings *out);
+
+/* Dictionary: replaces SoundDictionary::{new, from_segments, add_segments}
+ * (src/sound.rs:296, 323, 330) as far as features are concerned.
+ *   feats          flat values, dtype per cfg.dtype (HOST memory)
+ *   frame_offsets  n_segments + 1 offsets in FRAMES, non-decreasing, frame_offsets[0] may be > 0
+ *   dim            values per frame (NCOEFFS = 12 in the reference, src/lib.rs:22)
+ * n_segments = 0 creates an empty dictionary (SoundDictionary::new); matching against it fails
+ * with SSYM_E_EMPTY_DICT. */
+SSYM_API int32_t ssym_dict_create(ssym_ctx *ctx, const void *feats, const uint64_t *frame_offsets,
+                         uint32_t n_segments, uint32_t dim, ssym_dict **out);
+/* Same, but `feats` is a DEVICE pointer on the context's GPU (offsets stay on the host). */
+SSYM_API int32_t ssym_dict_create_device(ssym_ctx *ctx, const void *feats_dev,
+                                const uint64_t *frame_offsets, uint32_t n_segments, uint32_t dim,
+                                ssym_dict **out);
+/* add_segments (src/sound.rs:330): appended segments get the next indices. */
+SSYM_API int32_t ssym_dict_append(ssym_ctx *ctx, ssym_dict *dict, const void *feats,
+                         const uint64_t *frame_offsets, uint32_t n_segments);
+SSYM_API int32_t ssym_dict_size(const ssym_dict *dict, uint32_t *out_n_segments);
+SSYM_API int32_t ssym_dict_destroy(ssym_ctx *ctx, ssym_dict *dict);
+
+/* Targets of one batch, made resident once (the `for sound in self.sounds` side of
+ * clone_from_dictionary, src/sound.rs:453). */
+SSYM_API int32_t ssym_queries_create(ssym_ctx *ctx, const void *feats, const uint64_t *frame_offsets,
+                            uint32_t n_targets, uint32_t dim, ssym_queries **out);
+SSYM_API int32_t ssym_queries_create_device(ssym_ctx *ctx, const void *feats_dev,
+                                   const uint64_t *frame_offsets, uint32_t n_targets,
+                                   uint32_t dim, ssym_queries **out);
+SSYM_API int32_t ssym_queries_destroy(ssym_ctx *ctx, ssym_queries *q);
+
+/* The hot path.  Replaces the loop of clone_from_dictionary (src/sound.rs:451-455: one
+ * match_sound per target) and of morph_to (src/sound.rs:440-446: one at_distance per target).
+ *   distance    NULL: 1.0 per target in refcos (match_sound, src/sound.rs:346-348), 0.0 in dtw;
+ *               else n_targets values in HOST memory (morph_to's distances)
+ *   index_base  added to every returned index (a rank holding the source shard [base, base+n)
+ *               returns global indices)
+ *   out_idx     n_targets u32: chosen dictionary index per target (+ index_base)
+ *   out_cost    nullable, n_targets f64: refcos -> the winning |sim - distance| (the reference's
+ *               discarded `min_distance`, src/sound.rs:361-368); dtw -> the winner's DTW cost.
+ *               When nothing beats the fold start the index is 0 (+ index_base) and the value is
+ *               the fold start (2.0 / +inf), as in src/sound.rs:361-367.
+ *   flags       SSYM_OUT_DEVICE, SSYM_DTW_FORCE_EXACT
+ * Returns after the results are written (the stream is synchronised). */
+SSYM_API int32_t ssym_match_queries(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queries *q,
+                           const double *distance, uint32_t index_base, uint32_t *out_idx,
+                           double *out_cost, uint32_t flags);
+
+/* Convenience: pack host targets, match, release.  Same contract as ssym_match_queries with
+ * host outputs. */
+SSYM_API int32_t ssym_match_batch(ssym_ctx *ctx, const ssym_dict *dict, const void *tgt_feats,
+                         const uint64_t *tgt_frame_offsets, uint32_t n_targets,
+                         const double *distance, uint32_t *out_idx, double *out_cost);
+
+/* One query: SoundDictionary::at_distance(distance, other) (src/sound.rs:351) /
+ * match_sound(other) (src/sound.rs:346, pass distance = 1.0 in refcos). */
+SSYM_API int32_t ssym_match_one(ssym_ctx *ctx, const ssym_dict *dict, const void *feats,
+                       uint64_t n_frames, double distance, uint32_t *out_idx, double *out_cost);
+
+/* The whole [n_sources][n_targets] matrix in HOST memory, row-major, f64:
+ *   refcos: cosine_sim(source, target) (src/sound.rs:22-33), bit for bit;
+ *   dtw:    exact = 0 -> the f32 MFMA filter's costs; exact = 1 -> the exact f64 costs. */
+SSYM_API int32_t ssym_pair_matrix(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queries *q,
+                         int32_t exact, double *out_matrix);
+
+/* Source-sharded multi-GPU: after an all-gather of every shard's (cost, global index) per target
+ * (n_shards x n_targets each, shard-major, DEVICE memory), pick per target the shard entry with
+ * the smallest cost, lowest global index on equal cost -- the same first-minimum rule as
+ * src/sound.rs:361-367 because shards are ordered by index.  Outputs are DEVICE memory. */
+SSYM_API int32_t ssym_merge_shards(ssym_ctx *ctx, uint32_t n_shards, uint32_t n_targets,
+                          const double *costs_dev, const uint32_t *idx_dev, uint32_t *out_idx_dev,
+                          double *out_cost_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOUNDSYM_AMD_H */

@@ -1,0 +1,154 @@
+"""ctypes binding of ``libsoundsym_amd.so`` (the C ABI of ``include/soundsym_amd.h``).
+
+This is plumbing: argument marshalling and error translation only.  There is no fallback of any
+kind -- if the shared library is missing or no gfx950 device is usable, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsoundsym_amd.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+SSYM_OK = 0
+SSYM_E_INVALID = -1
+SSYM_E_EMPTY_DICT = -2
+SSYM_E_NO_DEVICE = -3
+SSYM_E_HIP = -4
+SSYM_E_NOMEM = -5
+SSYM_E_UNSUPPORTED = -6
+
+METRIC_REFCOS = 0
+METRIC_DTW = 1
+DTYPE_F64 = 0
+DTYPE_F32 = 1
+
+OUT_DEVICE = 1
+DTW_FORCE_EXACT = 2
+
+# every symbol include/soundsym_amd.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = [
+    "ssym_abi_version", "ssym_ctx_create", "ssym_ctx_destroy", "ssym_last_error",
+    "ssym_ctx_synchronize", "ssym_get_timings", "ssym_dict_create", "ssym_dict_create_device",
+    "ssym_dict_append", "ssym_dict_size", "ssym_dict_destroy", "ssym_queries_create",
+    "ssym_queries_create_device", "ssym_queries_destroy", "ssym_match_queries", "ssym_match_batch",
+    "ssym_match_one", "ssym_pair_matrix", "ssym_merge_shards",
+]
+
+
+class SsymError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"soundsym_amd error {code}: {msg}")
+        self.code = code
+
+
+class EmptyDictionaryError(SsymError):
+    """The reference panics here (src/sound.rs:369); the C ABI returns SSYM_E_EMPTY_DICT."""
+
+
+class Config(ctypes.Structure):
+    _fields_ = [
+        ("struct_size", ctypes.c_uint32),
+        ("device", ctypes.c_int32),
+        ("metric", ctypes.c_int32),
+        ("dtype", ctypes.c_int32),
+        ("band", ctypes.c_int32),
+        ("dtw_squared", ctypes.c_int32),
+        ("stream", ctypes.c_void_p),
+    ]
+
+
+class Timings(ctypes.Structure):
+    _fields_ = [
+        ("pack_ms", ctypes.c_float),
+        ("main_ms", ctypes.c_float),
+        ("select_ms", ctypes.c_float),
+        ("refine_ms", ctypes.c_float),
+        ("reduce_ms", ctypes.c_float),
+        ("total_ms", ctypes.c_float),
+        ("n_pairs", ctypes.c_uint64),
+        ("n_refined", ctypes.c_uint64),
+        ("main_launches", ctypes.c_int32),
+        ("used_filter", ctypes.c_int32),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP sources for gfx950 (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", CSRC, "-j4"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def lib() -> ctypes.CDLL:
+    """Load the native library.  Raises if it has not been built -- never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C soundsym_amd/csrc` (there is no CPU fallback)")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, u32, i32, u64, f64 = (ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int32, ctypes.c_uint64,
+                              ctypes.c_double)
+    pvp = ctypes.POINTER(ctypes.c_void_p)
+    L.ssym_abi_version.restype = i32
+    L.ssym_abi_version.argtypes = []
+    L.ssym_ctx_create.restype = i32
+    L.ssym_ctx_create.argtypes = [ctypes.POINTER(Config), pvp]
+    L.ssym_ctx_destroy.restype = i32
+    L.ssym_ctx_destroy.argtypes = [vp]
+    L.ssym_last_error.restype = ctypes.c_char_p
+    L.ssym_last_error.argtypes = [vp]
+    L.ssym_ctx_synchronize.restype = i32
+    L.ssym_ctx_synchronize.argtypes = [vp]
+    L.ssym_get_timings.restype = i32
+    L.ssym_get_timings.argtypes = [vp, ctypes.POINTER(Timings)]
+    for name in ("ssym_dict_create", "ssym_dict_create_device", "ssym_queries_create",
+                 "ssym_queries_create_device"):
+        f = getattr(L, name)
+        f.restype = i32
+        f.argtypes = [vp, vp, vp, u32, u32, pvp]
+    L.ssym_dict_append.restype = i32
+    L.ssym_dict_append.argtypes = [vp, vp, vp, vp, u32]
+    L.ssym_dict_size.restype = i32
+    L.ssym_dict_size.argtypes = [vp, ctypes.POINTER(u32)]
+    L.ssym_dict_destroy.restype = i32
+    L.ssym_dict_destroy.argtypes = [vp, vp]
+    L.ssym_queries_destroy.restype = i32
+    L.ssym_queries_destroy.argtypes = [vp, vp]
+    L.ssym_match_queries.restype = i32
+    L.ssym_match_queries.argtypes = [vp, vp, vp, vp, u32, vp, vp, u32]
+    L.ssym_match_batch.restype = i32
+    L.ssym_match_batch.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp]
+    L.ssym_match_one.restype = i32
+    L.ssym_match_one.argtypes = [vp, vp, vp, u64, f64, vp, vp]
+    L.ssym_pair_matrix.restype = i32
+    L.ssym_pair_matrix.argtypes = [vp, vp, vp, i32, vp]
+    L.ssym_merge_shards.restype = i32
+    L.ssym_merge_shards.argtypes = [vp, u32, u32, vp, vp, vp, vp]
+    _lib = L
+    return L
+
+
+def check(rc: int, ctx: Optional[int] = None) -> None:
+    if rc == SSYM_OK:
+        return
+    msg = lib().ssym_last_error(ctx)
+    text = msg.decode("utf-8", "replace") if msg else ""
+    if rc == SSYM_E_EMPTY_DICT:
+        raise EmptyDictionaryError(rc, text or "empty dictionary")
+    raise SsymError(rc, text)

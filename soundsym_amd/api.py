@@ -1,0 +1,223 @@
+"""Host-side mirror of the reference's matching interface: Sound / SoundDictionary / SoundSequence.
+
+Same names, argument meaning and error behaviour as the reference for the hot path
+(upstream src/sound.rs), so callers and tests read like the reference's own:
+
+    SoundDictionary.new / from_segments / add_segments      src/sound.rs:296, 323, 330
+    SoundDictionary.match_sound / at_distance               src/sound.rs:346, 351
+    SoundSequence.new / morph_to / clone_from_dictionary    src/sound.rs:392, 440, 451
+    SoundSequence.from_distances / to_sound                 src/sound.rs:405, 475
+
+Every comparison runs on the GPU through the C ABI (`engine.Engine`); this module only keeps the
+containers, does the length fit of src/sound.rs:456-465 on the matched samples, and translates
+errors.  Feature extraction (MFCC analysis, src/sound.rs:215-242) is out of scope: a Sound is
+built from samples plus ready-made features, the `Some(mfccs)` form of Sound::from_samples
+(src/sound.rs:92-94).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from ._native import EmptyDictionaryError
+from .engine import Engine, pack_segments
+
+NCOEFFS = 12   # src/lib.rs:22
+HOP = 256      # src/lib.rs:24
+BIN = 1024     # src/lib.rs:25
+
+_default_engine: Optional[Engine] = None
+
+
+def default_engine() -> Engine:
+    """refcos / f64 on GPU 0: the reference's own metric and dtype."""
+    global _default_engine
+    if _default_engine is None:
+        _default_engine = Engine(metric="refcos", dtype="f64", device=0)
+    return _default_engine
+
+
+class Sound:
+    """Samples + flat frame-major features of one sound (src/sound.rs:73-82)."""
+
+    def __init__(self, samples, sample_rate: float, mfccs, name: Optional[str] = None,
+                 ncoeffs: int = NCOEFFS):
+        self.name = name
+        self._samples = np.ascontiguousarray(samples, dtype=np.float64).reshape(-1)
+        self._sample_rate = float(sample_rate)
+        self.ncoeffs = int(ncoeffs)
+        self._mfccs = None
+        if mfccs is not None:
+            m = np.ascontiguousarray(mfccs, dtype=np.float64).reshape(-1)
+            if m.size % self.ncoeffs:
+                raise ValueError("mfccs must hold whole frames of `ncoeffs` values")
+            self._mfccs = m
+
+    @staticmethod
+    def from_samples(samples, sample_rate: float, mfccs=None, name: Optional[str] = None,
+                     ncoeffs: int = NCOEFFS) -> "Sound":
+        """Sound::from_samples (src/sound.rs:92).  mfccs=None leaves the features unset: the
+        reference would run its MFCC analysis here, which this package does not restate."""
+        return Sound(samples, sample_rate, mfccs, name, ncoeffs)
+
+    def samples(self) -> np.ndarray:          # src/sound.rs:181
+        return self._samples
+
+    def sample_rate(self) -> float:           # src/sound.rs:185
+        return self._sample_rate
+
+    def mfccs(self) -> np.ndarray:            # src/sound.rs:191
+        if self._mfccs is None:
+            raise ValueError("this Sound carries no features (MFCC analysis is out of scope)")
+        return self._mfccs
+
+    def has_mfccs(self) -> bool:
+        return self._mfccs is not None
+
+    def num_frames(self) -> int:              # src/sound.rs:210
+        return self.mfccs().size // self.ncoeffs
+
+
+class SoundDictionary:
+    """Cache of Sounds searched by similarity (src/sound.rs:290-371)."""
+
+    def __init__(self, engine: Optional[Engine] = None):
+        self.sounds: List[Sound] = []         # `pub sounds: Vec<Arc<Sound>>`
+        self._engine = engine
+        self._resident = None
+        self._resident_n = -1
+
+    # constructors -----------------------------------------------------------------------------
+    @staticmethod
+    def new(engine: Optional[Engine] = None) -> "SoundDictionary":     # src/sound.rs:296
+        return SoundDictionary(engine)
+
+    @staticmethod
+    def from_segments(sound: Sound, segments: Sequence[int],
+                      engine: Optional[Engine] = None) -> "SoundDictionary":   # src/sound.rs:323
+        d = SoundDictionary(engine)
+        d.add_segments(sound, segments)
+        return d
+
+    def add_segments(self, sound: Sound, segments: Sequence[int]) -> None:
+        """src/sound.rs:330-343: consecutive `seg` samples and `seg / HOP * ncoeffs` feature
+        values per segment (integer division), taken in order from the parent sound; a segment
+        running past the end gets what is left, like `take` on an exhausted iterator."""
+        samples, mfccs = sound.samples(), sound.mfccs()
+        spos = mpos = 0
+        for seg in segments:
+            seg = int(seg)
+            samp = samples[spos:spos + seg]
+            spos = min(spos + seg, samples.size)
+            nm = seg // HOP * sound.ncoeffs
+            mf = mfccs[mpos:mpos + nm]
+            mpos = min(mpos + nm, mfccs.size)
+            self.sounds.append(Sound(samp.copy(), sound.sample_rate(), mf.copy(), None, sound.ncoeffs))
+
+    # device residency ---------------------------------------------------------------------------
+    @property
+    def engine(self) -> Engine:
+        if self._engine is None:
+            self._engine = default_engine()
+        return self._engine
+
+    def _dim(self) -> int:
+        return self.sounds[0].ncoeffs
+
+    def resident(self):
+        """Pack the dictionary's features once per content change, not per query."""
+        if self._resident is None or self._resident_n != len(self.sounds):
+            if self._resident is not None:
+                self._resident.close()
+            dim = self._dim() if self.sounds else NCOEFFS
+            flat, off = pack_segments([s.mfccs() for s in self.sounds], dim, self.engine.np_dtype)
+            self._resident = self.engine.dictionary(flat, off, dim)
+            self._resident_n = len(self.sounds)
+        return self._resident
+
+    # queries ------------------------------------------------------------------------------------
+    def match_sound(self, other: Sound) -> Sound:                       # src/sound.rs:346
+        if not self.sounds:
+            raise EmptyDictionaryError(-2, "empty dictionary")          # reference: panic, :369
+        default = 1.0 if self.engine.metric == "refcos" else 0.0
+        return self.at_distance(default, other)
+
+    def at_distance(self, distance: float, other: Sound) -> Sound:      # src/sound.rs:351
+        if not self.sounds:
+            # the reference indexes an empty Vec and panics (src/sound.rs:369)
+            raise EmptyDictionaryError(-2, "empty dictionary")
+        idx, _ = self.engine.match_one(self.resident(), other.mfccs(), distance)
+        return self.sounds[idx]              # Some(self.sounds[min_idx].clone())
+
+    def match_indices(self, targets: Sequence[Sound], distances=None):
+        """Batched form of the loops at src/sound.rs:442-446 and :453-454."""
+        if not self.sounds:
+            raise EmptyDictionaryError(-2, "empty dictionary")
+        flat, off = pack_segments([t.mfccs() for t in targets], self._dim(), self.engine.np_dtype)
+        return self.engine.match_batch(self.resident(), flat, off, distances)
+
+
+def length_fit(matched: np.ndarray, n_target: int) -> np.ndarray:
+    """src/sound.rs:456-465: zero-pad the matched samples up to the target's sample count, or
+    truncate them down to it."""
+    out = np.zeros(n_target, dtype=np.float64)
+    n = min(matched.size, n_target)
+    out[:n] = matched[:n]
+    return out
+
+
+class SoundSequence:
+    """Sequence of sounds (src/sound.rs:375-484); `distances` between neighbours is not kept."""
+
+    def __init__(self, sounds: Sequence[Sound]):
+        self._sounds = list(sounds)
+
+    @staticmethod
+    def new(sounds: Sequence[Sound]) -> "SoundSequence":                # src/sound.rs:392
+        return SoundSequence(sounds)
+
+    def sounds(self) -> List[Sound]:                                    # src/sound.rs:432
+        return self._sounds
+
+    @staticmethod
+    def from_distances(distances: Sequence[float], start: Sound,
+                       dict_: SoundDictionary) -> "SoundSequence":      # src/sound.rs:405-417
+        """Greedy chain: each step's query is the previous result, so it is serial by nature."""
+        sounds = [start]
+        for d in distances:
+            sounds.append(dict_.at_distance(float(d), sounds[-1]))
+        return SoundSequence(sounds)
+
+    def morph_to(self, distances: Sequence[float], dict_: SoundDictionary) -> "SoundSequence":
+        """src/sound.rs:440-449: zip(sounds, distances) -> at_distance, here as ONE batch."""
+        n = min(len(self._sounds), len(distances))
+        if n == 0:
+            return SoundSequence([])
+        idx, _ = dict_.match_indices(self._sounds[:n], np.asarray(distances[:n], dtype=np.float64))
+        return SoundSequence([dict_.sounds[int(i)] for i in idx])
+
+    def clone_from_dictionary(self, dict_: SoundDictionary) -> "SoundSequence":
+        """src/sound.rs:451-472: match every sound, then fit the match to the target's length."""
+        if not self._sounds:
+            return SoundSequence([])
+        idx, _ = dict_.match_indices(self._sounds, None)
+        out = []
+        for sound, i in zip(self._sounds, idx):
+            s = dict_.sounds[int(i)]
+            diff = sound.samples().size - s.samples().size
+            if diff == 0:
+                out.append(s)                                            # :463-464 shares the Arc
+            else:
+                # :457-462 builds a new Sound from the fitted samples and re-analyses it; the
+                # re-analysis (MFCC) is outside this package, the samples are exact
+                out.append(Sound(length_fit(s.samples(), sound.samples().size), sound.sample_rate(),
+                                 None, None, s.ncoeffs))
+        return SoundSequence(out)
+
+    def to_sound(self) -> Sound:                                        # src/sound.rs:475-483
+        parts = [s.samples() for s in self._sounds]
+        samples = np.concatenate(parts) if parts else np.zeros(0)
+        rate = self._sounds[0].sample_rate() if self._sounds else 44100.0
+        ncoeffs = self._sounds[0].ncoeffs if self._sounds else NCOEFFS
+        return Sound(samples, rate, None, None, ncoeffs)

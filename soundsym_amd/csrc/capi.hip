@@ -1,0 +1,555 @@
+// capi.hip -- the C ABI of include/soundsym_amd.h on top of the kernels.
+#include "ssym_internal.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+
+using namespace ssym;
+
+static thread_local std::string g_create_err;
+
+extern "C" {
+
+int32_t ssym_abi_version(void) { return SSYM_ABI_VERSION; }
+
+const char *ssym_last_error(const ssym_ctx *ctx)
+{
+    return ctx ? ctx->err.c_str() : g_create_err.c_str();
+}
+
+int32_t ssym_ctx_create(const ssym_config *cfg, ssym_ctx **out)
+{
+    if (!cfg || !out || cfg->struct_size != sizeof(ssym_config)) {
+        g_create_err = "ssym_ctx_create: bad config (NULL or struct_size mismatch)";
+        return SSYM_E_INVALID;
+    }
+    *out = nullptr;
+    if ((cfg->metric != SSYM_METRIC_REFCOS && cfg->metric != SSYM_METRIC_DTW) ||
+        (cfg->dtype != SSYM_DTYPE_F64 && cfg->dtype != SSYM_DTYPE_F32) || cfg->band < -1) {
+        g_create_err = "ssym_ctx_create: bad metric / dtype / band";
+        return SSYM_E_INVALID;
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_create_err = std::string("ssym_ctx_create: no HIP device (") +
+                       (e != hipSuccess ? hipGetErrorString(e) : "device count 0") +
+                       "); this library has no CPU path";
+        return SSYM_E_NO_DEVICE;
+    }
+    if (cfg->device < 0 || cfg->device >= ndev) {
+        g_create_err = "ssym_ctx_create: device ordinal out of range";
+        return SSYM_E_INVALID;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) {
+        g_create_err = "ssym_ctx_create: hipGetDeviceProperties failed";
+        return SSYM_E_HIP;
+    }
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        g_create_err = std::string("ssym_ctx_create: device is ") + prop.gcnArchName +
+                       ", kernels are built for gfx950 only";
+        return SSYM_E_NO_DEVICE;
+    }
+    if (hipSetDevice(cfg->device) != hipSuccess) {
+        g_create_err = "ssym_ctx_create: hipSetDevice failed";
+        return SSYM_E_HIP;
+    }
+    ssym_ctx *ctx = new (std::nothrow) ssym_ctx();
+    if (!ctx) {
+        g_create_err = "out of memory";
+        return SSYM_E_NOMEM;
+    }
+    ctx->device = cfg->device;
+    ctx->metric = cfg->metric;
+    ctx->dtype = cfg->dtype;
+    ctx->band = cfg->band;
+    ctx->squared = cfg->dtw_squared ? 1 : 0;
+    ctx->num_cus = prop.multiProcessorCount;
+    if (cfg->stream) {
+        ctx->stream = (hipStream_t)cfg->stream;
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+            g_create_err = "hipStreamCreate failed";
+            delete ctx;
+            return SSYM_E_HIP;
+        }
+        ctx->owns_stream = true;
+    }
+    for (auto &ev : ctx->ev) {
+        if (hipEventCreate(&ev) != hipSuccess) {
+            g_create_err = "hipEventCreate failed";
+            delete ctx;
+            return SSYM_E_HIP;
+        }
+    }
+    *out = ctx;
+    return SSYM_OK;
+}
+
+int32_t ssym_ctx_destroy(ssym_ctx *ctx)
+{
+    if (!ctx)
+        return SSYM_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    DeviceBuf *bufs[] = {&ctx->cmat, &ctx->tmin, &ctx->cand, &ctx->cand_cost, &ctx->best,
+                         &ctx->dist, &ctx->part, &ctx->out_idx, &ctx->out_cost};
+    for (DeviceBuf *b : bufs)
+        if (b->ptr)
+            (void)hipFree(b->ptr);
+    for (auto &ev : ctx->ev)
+        if (ev)
+            (void)hipEventDestroy(ev);
+    if (ctx->owns_stream)
+        (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return SSYM_OK;
+}
+
+int32_t ssym_ctx_synchronize(ssym_ctx *ctx)
+{
+    if (!ctx)
+        return SSYM_E_INVALID;
+    SSYM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return SSYM_OK;
+}
+
+int32_t ssym_get_timings(const ssym_ctx *ctx, ssym_timings *out)
+{
+    if (!ctx || !out)
+        return SSYM_E_INVALID;
+    *out = ctx->timings;
+    return SSYM_OK;
+}
+
+// ---- dictionary / queries -----------------------------------------------------------------------
+static int32_t make_set(ssym_ctx *ctx, SegmentSet &set, const void *feats, bool on_device,
+                        const uint64_t *off, uint32_t n, uint32_t dim, bool is_source)
+{
+    SSYM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    int32_t rc = pack_segments(ctx, set, feats, on_device, off, n, dim, is_source);
+    if (rc != SSYM_OK)
+        free_segments(set);
+    return rc;
+}
+
+int32_t ssym_dict_create(ssym_ctx *ctx, const void *feats, const uint64_t *frame_offsets,
+                         uint32_t n_segments, uint32_t dim, ssym_dict **out)
+{
+    if (!ctx || !out)
+        return SSYM_E_INVALID;
+    *out = nullptr;
+    ssym_dict *d = new (std::nothrow) ssym_dict();
+    if (!d)
+        return SSYM_E_NOMEM;
+    int32_t rc = make_set(ctx, d->set, feats, false, frame_offsets, n_segments, dim, true);
+    if (rc != SSYM_OK) {
+        delete d;
+        return rc;
+    }
+    *out = d;
+    return SSYM_OK;
+}
+
+int32_t ssym_dict_create_device(ssym_ctx *ctx, const void *feats_dev, const uint64_t *frame_offsets,
+                                uint32_t n_segments, uint32_t dim, ssym_dict **out)
+{
+    if (!ctx || !out)
+        return SSYM_E_INVALID;
+    *out = nullptr;
+    ssym_dict *d = new (std::nothrow) ssym_dict();
+    if (!d)
+        return SSYM_E_NOMEM;
+    int32_t rc = make_set(ctx, d->set, feats_dev, true, frame_offsets, n_segments, dim, true);
+    if (rc != SSYM_OK) {
+        delete d;
+        return rc;
+    }
+    *out = d;
+    return SSYM_OK;
+}
+
+int32_t ssym_dict_append(ssym_ctx *ctx, ssym_dict *dict, const void *feats,
+                         const uint64_t *frame_offsets, uint32_t n_segments)
+{
+    if (!ctx || !dict)
+        return SSYM_E_INVALID;
+    SSYM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    return append_segments(ctx, dict->set, feats, frame_offsets, n_segments);
+}
+
+int32_t ssym_dict_size(const ssym_dict *dict, uint32_t *out_n_segments)
+{
+    if (!dict || !out_n_segments)
+        return SSYM_E_INVALID;
+    *out_n_segments = dict->set.n;
+    return SSYM_OK;
+}
+
+int32_t ssym_dict_destroy(ssym_ctx *ctx, ssym_dict *dict)
+{
+    if (!dict)
+        return SSYM_OK;
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    free_segments(dict->set);
+    delete dict;
+    return SSYM_OK;
+}
+
+int32_t ssym_queries_create(ssym_ctx *ctx, const void *feats, const uint64_t *frame_offsets,
+                            uint32_t n_targets, uint32_t dim, ssym_queries **out)
+{
+    if (!ctx || !out)
+        return SSYM_E_INVALID;
+    *out = nullptr;
+    ssym_queries *q = new (std::nothrow) ssym_queries();
+    if (!q)
+        return SSYM_E_NOMEM;
+    int32_t rc = make_set(ctx, q->set, feats, false, frame_offsets, n_targets, dim, false);
+    if (rc != SSYM_OK) {
+        delete q;
+        return rc;
+    }
+    *out = q;
+    return SSYM_OK;
+}
+
+int32_t ssym_queries_create_device(ssym_ctx *ctx, const void *feats_dev, const uint64_t *frame_offsets,
+                                   uint32_t n_targets, uint32_t dim, ssym_queries **out)
+{
+    if (!ctx || !out)
+        return SSYM_E_INVALID;
+    *out = nullptr;
+    ssym_queries *q = new (std::nothrow) ssym_queries();
+    if (!q)
+        return SSYM_E_NOMEM;
+    int32_t rc = make_set(ctx, q->set, feats_dev, true, frame_offsets, n_targets, dim, false);
+    if (rc != SSYM_OK) {
+        delete q;
+        return rc;
+    }
+    *out = q;
+    return SSYM_OK;
+}
+
+int32_t ssym_queries_destroy(ssym_ctx *ctx, ssym_queries *q)
+{
+    if (!q)
+        return SSYM_OK;
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    free_segments(q->set);
+    delete q;
+    return SSYM_OK;
+}
+
+// ---- the hot path -----------------------------------------------------------------------------------
+static float ev_ms(hipEvent_t a, hipEvent_t b)
+{
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, a, b) != hipSuccess)
+        return 0.f;
+    return ms;
+}
+
+static int32_t check_match_args(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queries *q)
+{
+    if (!ctx)
+        return SSYM_E_INVALID;
+    if (!dict || !q) {
+        ctx->err = "dictionary or queries handle is NULL";
+        return SSYM_E_INVALID;
+    }
+    if (dict->set.n == 0) {
+        // the reference indexes sounds[0] of an empty Vec and panics (src/sound.rs:369)
+        ctx->err = "empty dictionary";
+        return SSYM_E_EMPTY_DICT;
+    }
+    if (dict->set.dim != q->set.dim) {
+        ctx->err = "dim mismatch between dictionary and targets";
+        return SSYM_E_INVALID;
+    }
+    return SSYM_OK;
+}
+
+int32_t ssym_match_queries(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queries *q,
+                           const double *distance, uint32_t index_base, uint32_t *out_idx,
+                           double *out_cost, uint32_t flags)
+{
+    int32_t rc = check_match_args(ctx, dict, q);
+    if (rc != SSYM_OK)
+        return rc;
+    const SegmentSet &src = dict->set;
+    const SegmentSet &tgt = q->set;
+    const uint32_t N = src.n, M = tgt.n;
+    ssym_timings tm{};
+    tm.n_pairs = (uint64_t)N * M;
+    if (M == 0) {
+        ctx->timings = tm;
+        return SSYM_OK;
+    }
+    if (!out_idx) {
+        ctx->err = "out_idx is NULL";
+        return SSYM_E_INVALID;
+    }
+    SSYM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const bool outDev = (flags & SSYM_OUT_DEVICE) != 0;
+
+    // per-target distance (morph_to, src/sound.rs:440-446)
+    const double *distDev = nullptr;
+    if (distance) {
+        rc = ensure(ctx, ctx->dist, sizeof(double) * M);
+        if (rc != SSYM_OK)
+            return rc;
+        SSYM_HIP_CHECK(ctx, hipMemcpyAsync(ctx->dist.ptr, distance, sizeof(double) * M,
+                                           hipMemcpyHostToDevice, st));
+        distDev = (const double *)ctx->dist.ptr;
+    }
+    uint32_t *idxDev = out_idx;
+    double *costDev = out_cost;
+    if (!outDev) {
+        rc = ensure(ctx, ctx->out_idx, sizeof(uint32_t) * M);
+        if (rc != SSYM_OK)
+            return rc;
+        rc = ensure(ctx, ctx->out_cost, sizeof(double) * M);
+        if (rc != SSYM_OK)
+            return rc;
+        idxDev = (uint32_t *)ctx->out_idx.ptr;
+        costDev = (double *)ctx->out_cost.ptr;
+    }
+
+    hipEvent_t *ev = ctx->ev;
+    if (ctx->metric == SSYM_METRIC_REFCOS) {
+        rc = ensure(ctx, ctx->cmat, sizeof(double) * (size_t)N * M);
+        if (rc != SSYM_OK)
+            return rc;
+        double *sims = (double *)ctx->cmat.ptr;
+        SSYM_HIP_CHECK(ctx, hipEventRecord(ev[0], st));
+        rc = launch_refcos_sims(ctx, src, tgt, sims);
+        if (rc != SSYM_OK)
+            return rc;
+        SSYM_HIP_CHECK(ctx, hipEventRecord(ev[1], st));
+        rc = launch_refcos_argmin(ctx, N, M, sims, distDev, index_base, idxDev, costDev);
+        if (rc != SSYM_OK)
+            return rc;
+        SSYM_HIP_CHECK(ctx, hipEventRecord(ev[2], st));
+        SSYM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        tm.main_ms = ev_ms(ev[0], ev[1]);
+        tm.reduce_ms = ev_ms(ev[1], ev[2]);
+        tm.total_ms = ev_ms(ev[0], ev[2]);
+        tm.main_launches = 1;
+    } else {
+        const bool useFilter = !(flags & SSYM_DTW_FORCE_EXACT) && filter_supported(ctx, src, tgt);
+        tm.used_filter = useFilter ? 1 : 0;
+        if (useFilter) {
+            rc = ensure(ctx, ctx->cmat, sizeof(float) * (size_t)src.n_pad * tgt.n_pad);
+            if (rc != SSYM_OK)
+                return rc;
+            float *cmat = (float *)ctx->cmat.ptr;
+            SSYM_HIP_CHECK(ctx, hipEventRecord(ev[0], st));
+            rc = launch_dtw_filter(ctx, src, tgt, cmat);
+            if (rc != SSYM_OK)
+                return rc;
+            SSYM_HIP_CHECK(ctx, hipEventRecord(ev[1], st));
+            tm.main_launches = 1;
+            // candidate capacity: a few per target is the normal case; on overflow redo the
+            // selection with room for every pair (exactness never depends on the capacity)
+            uint64_t cap = std::max<uint64_t>(4ull * M, 4096);
+            cap = std::min<uint64_t>(cap, (uint64_t)N * M);
+            float sel_ms = 0.f, ref_ms = 0.f, red_ms = 0.f;
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                SSYM_HIP_CHECK(ctx, hipEventRecord(ev[2], st));
+                rc = launch_dtw_select(ctx, src, tgt, cmat, distDev, (uint32_t)cap);
+                if (rc != SSYM_OK)
+                    return rc;
+                SSYM_HIP_CHECK(ctx, hipEventRecord(ev[3], st));
+                rc = ensure(ctx, ctx->cand_cost, sizeof(double) * cap);
+                if (rc != SSYM_OK)
+                    return rc;
+                uint32_t *hdr = (uint32_t *)ctx->cand.ptr;
+                rc = launch_dtw_exact(ctx, src, tgt, (const uint2 *)(hdr + 2), hdr, (uint32_t)cap,
+                                      (double *)ctx->cand_cost.ptr);
+                if (rc != SSYM_OK)
+                    return rc;
+                SSYM_HIP_CHECK(ctx, hipEventRecord(ev[4], st));
+                rc = launch_dtw_final(ctx, src, tgt, distDev, (uint32_t)cap, index_base, idxDev, costDev);
+                if (rc != SSYM_OK)
+                    return rc;
+                SSYM_HIP_CHECK(ctx, hipEventRecord(ev[5], st));
+                uint32_t h[2] = {0, 0};
+                SSYM_HIP_CHECK(ctx, hipMemcpyAsync(h, hdr, sizeof(h), hipMemcpyDeviceToHost, st));
+                SSYM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+                sel_ms += ev_ms(ev[2], ev[3]);
+                ref_ms += ev_ms(ev[3], ev[4]);
+                red_ms += ev_ms(ev[4], ev[5]);
+                tm.n_refined = std::min<uint64_t>(h[0], cap);
+                if (!h[1])
+                    break;
+                if (attempt == 1 || cap == (uint64_t)N * M) {
+                    ctx->err = "dtw: candidate list overflow";
+                    return SSYM_E_NOMEM;
+                }
+                cap = (uint64_t)N * M;
+                if (cap > 0xffffffffull) {
+                    ctx->err = "dtw: too many near-tied candidates for one batch";
+                    return SSYM_E_UNSUPPORTED;
+                }
+            }
+            tm.main_ms = ev_ms(ev[0], ev[1]);
+            tm.select_ms = sel_ms;
+            tm.refine_ms = ref_ms;
+            tm.reduce_ms = red_ms;
+            tm.total_ms = ev_ms(ev[0], ev[5]);
+        } else {
+            rc = ensure(ctx, ctx->cmat, sizeof(double) * (size_t)N * M);
+            if (rc != SSYM_OK)
+                return rc;
+            double *costs = (double *)ctx->cmat.ptr;
+            SSYM_HIP_CHECK(ctx, hipEventRecord(ev[0], st));
+            rc = launch_dtw_exact(ctx, src, tgt, nullptr, nullptr, 0, costs);
+            if (rc != SSYM_OK)
+                return rc;
+            SSYM_HIP_CHECK(ctx, hipEventRecord(ev[1], st));
+            rc = launch_dtw_final_allpairs(ctx, N, M, costs, distDev, index_base, idxDev, costDev);
+            if (rc != SSYM_OK)
+                return rc;
+            SSYM_HIP_CHECK(ctx, hipEventRecord(ev[2], st));
+            SSYM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+            tm.refine_ms = ev_ms(ev[0], ev[1]);
+            tm.reduce_ms = ev_ms(ev[1], ev[2]);
+            tm.total_ms = ev_ms(ev[0], ev[2]);
+            tm.n_refined = (uint64_t)N * M;
+        }
+    }
+
+    if (!outDev) {
+        SSYM_HIP_CHECK(ctx, hipMemcpyAsync(out_idx, idxDev, sizeof(uint32_t) * M, hipMemcpyDeviceToHost, st));
+        if (out_cost)
+            SSYM_HIP_CHECK(ctx, hipMemcpyAsync(out_cost, costDev, sizeof(double) * M,
+                                               hipMemcpyDeviceToHost, st));
+        SSYM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    }
+    ctx->timings = tm;
+    return SSYM_OK;
+}
+
+int32_t ssym_match_batch(ssym_ctx *ctx, const ssym_dict *dict, const void *tgt_feats,
+                         const uint64_t *tgt_frame_offsets, uint32_t n_targets, const double *distance,
+                         uint32_t *out_idx, double *out_cost)
+{
+    if (!ctx)
+        return SSYM_E_INVALID;
+    if (!dict) {
+        ctx->err = "dictionary handle is NULL";
+        return SSYM_E_INVALID;
+    }
+    if (dict->set.n == 0) {
+        ctx->err = "empty dictionary";
+        return SSYM_E_EMPTY_DICT;
+    }
+    ssym_queries *q = nullptr;
+    hipEvent_t e0 = ctx->ev[6], e1 = ctx->ev[7];
+    SSYM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    SSYM_HIP_CHECK(ctx, hipEventRecord(e0, ctx->stream));
+    int32_t rc = ssym_queries_create(ctx, tgt_feats, tgt_frame_offsets, n_targets, dict->set.dim, &q);
+    if (rc != SSYM_OK)
+        return rc;
+    SSYM_HIP_CHECK(ctx, hipEventRecord(e1, ctx->stream));
+    rc = ssym_match_queries(ctx, dict, q, distance, 0, out_idx, out_cost, 0);
+    if (rc == SSYM_OK)
+        ctx->timings.pack_ms = ev_ms(e0, e1);
+    ssym_queries_destroy(ctx, q);
+    return rc;
+}
+
+int32_t ssym_match_one(ssym_ctx *ctx, const ssym_dict *dict, const void *feats, uint64_t n_frames,
+                       double distance, uint32_t *out_idx, double *out_cost)
+{
+    const uint64_t off[2] = {0, n_frames};
+    return ssym_match_batch(ctx, dict, feats, off, 1, &distance, out_idx, out_cost);
+}
+
+__global__ void f32_to_f64_matrix_kernel(const float *__restrict__ in, uint32_t rows, uint32_t cols,
+                                         uint32_t ld, double *__restrict__ out)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t r = blockIdx.y;
+    if (c < cols && r < rows)
+        out[(size_t)r * cols + c] = (double)in[(size_t)r * ld + c];
+}
+
+int32_t ssym_pair_matrix(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queries *q, int32_t exact,
+                         double *out_matrix)
+{
+    int32_t rc = check_match_args(ctx, dict, q);
+    if (rc != SSYM_OK)
+        return rc;
+    if (!out_matrix) {
+        ctx->err = "out_matrix is NULL";
+        return SSYM_E_INVALID;
+    }
+    const SegmentSet &src = dict->set;
+    const SegmentSet &tgt = q->set;
+    const uint32_t N = src.n, M = tgt.n;
+    if (M == 0)
+        return SSYM_OK;
+    SSYM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    rc = ensure(ctx, ctx->part, sizeof(double) * (size_t)N * M);
+    if (rc != SSYM_OK)
+        return rc;
+    double *mat = (double *)ctx->part.ptr;
+    if (ctx->metric == SSYM_METRIC_REFCOS) {
+        rc = launch_refcos_sims(ctx, src, tgt, mat);
+    } else if (exact) {
+        rc = launch_dtw_exact(ctx, src, tgt, nullptr, nullptr, 0, mat);
+    } else {
+        if (!filter_supported(ctx, src, tgt)) {
+            ctx->err = "dtw filter does not cover this shape (band / frames / dim); ask for exact = 1";
+            return SSYM_E_UNSUPPORTED;
+        }
+        rc = ensure(ctx, ctx->cmat, sizeof(float) * (size_t)src.n_pad * tgt.n_pad);
+        if (rc != SSYM_OK)
+            return rc;
+        rc = launch_dtw_filter(ctx, src, tgt, (float *)ctx->cmat.ptr);
+        if (rc == SSYM_OK) {
+            dim3 grid((M + 255) / 256, N);
+            f32_to_f64_matrix_kernel<<<grid, 256, 0, st>>>((const float *)ctx->cmat.ptr, N, M, tgt.n_pad, mat);
+            SSYM_HIP_CHECK(ctx, hipGetLastError());
+        }
+    }
+    if (rc != SSYM_OK)
+        return rc;
+    SSYM_HIP_CHECK(ctx, hipMemcpyAsync(out_matrix, mat, sizeof(double) * (size_t)N * M,
+                                       hipMemcpyDeviceToHost, st));
+    SSYM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    return SSYM_OK;
+}
+
+int32_t ssym_merge_shards(ssym_ctx *ctx, uint32_t n_shards, uint32_t n_targets, const double *costs_dev,
+                          const uint32_t *idx_dev, uint32_t *out_idx_dev, double *out_cost_dev)
+{
+    if (!ctx)
+        return SSYM_E_INVALID;
+    if (n_shards == 0 || !costs_dev || !idx_dev || !out_idx_dev) {
+        ctx->err = "ssym_merge_shards: bad arguments";
+        return SSYM_E_INVALID;
+    }
+    SSYM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    int32_t rc = launch_merge_shards(ctx, n_shards, n_targets, costs_dev, idx_dev, out_idx_dev, out_cost_dev);
+    if (rc != SSYM_OK)
+        return rc;
+    SSYM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return SSYM_OK;
+}
+
+}  // extern "C"

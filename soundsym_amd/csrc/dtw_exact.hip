@@ -1,0 +1,181 @@
+// dtw_exact.hip -- exact f64 DTW for a list of (source, target) pairs, or for every pair.
+//
+// Role on the path: (1) re-scores the candidates the f32 MFMA filter leaves per target, so that
+// the returned indices and costs are those of an f64 evaluation; (2) is the whole dtw path for
+// shapes the filter does not cover (banded, > 128 source frames, dim > 13; DESIGN.md "limits").
+//
+// Arithmetic follows the definition in DESIGN.md operation by operation (the same order the CPU
+// oracle uses): c(i,j) = sqrt(sum_k (a_ik - b_jk)^2), k ascending, sub / mul / add rounded
+// separately in f64 (library is built with -ffp-contract=off); D(i,j) = c + min3.
+//
+// Mapping: one wave per pair.  Lane l owns row c0+l of a 64-row chunk and walks the
+// anti-diagonals: at step tau it evaluates column j = tau - l.  D(i-1, j) arrives from lane l-1
+// by a wave shuffle, D(i-1, j-1) is the value shuffled in one step earlier, D(i, j-1) is the
+// lane's own previous value.  The bottom row of a chunk is handed to the next chunk through LDS.
+// Both segments' frames are staged in LDS when they fit, else read through L1/L2.
+#include "ssym_internal.hpp"
+
+#include <algorithm>
+
+namespace ssym {
+
+__device__ __forceinline__ double shfl_up1(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_up(lo, 1);
+    hi = __shfl_up(hi, 1);
+    return __hiloint2double(hi, lo);
+}
+
+template <bool LDS_FRAMES>
+__global__ __launch_bounds__(64) void dtw_exact_kernel(
+    const double *__restrict__ srcRaw, const uint64_t *__restrict__ srcOff,
+    const double *__restrict__ tgtRaw, const uint64_t *__restrict__ tgtOff, uint32_t nSrc,
+    uint32_t nTgt, uint32_t dim, int band, int squared, const uint2 *__restrict__ pairs,
+    const uint32_t *__restrict__ countDev, uint32_t maxPairs, uint32_t fbCap,
+    double *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *bound0 = smem;                  // [fbCap]
+    double *bound1 = smem + fbCap;          // [fbCap]
+    double *ldsA = smem + 2 * (size_t)fbCap;        // [64][dim]      (LDS_FRAMES only)
+    double *ldsB = ldsA + 64 * (size_t)dim;          // [fbCap][dim]   (LDS_FRAMES only)
+
+    const double INF = __builtin_inf();
+    const int lane = threadIdx.x;
+
+    uint64_t total;
+    if (pairs) {
+        uint32_t c = *countDev;
+        total = c < maxPairs ? c : maxPairs;
+    } else {
+        total = (uint64_t)nSrc * nTgt;
+    }
+
+    for (uint64_t k = blockIdx.x; k < total; k += gridDim.x) {
+        uint32_t s, t;
+        if (pairs) {
+            uint2 p = pairs[k];
+            s = p.x;
+            t = p.y;
+        } else {
+            s = (uint32_t)(k / nTgt);
+            t = (uint32_t)(k % nTgt);
+        }
+        const int Fa = (int)(srcOff[s + 1] - srcOff[s]);
+        const int Fb = (int)(tgtOff[t + 1] - tgtOff[t]);
+        const double *a0 = srcRaw + srcOff[s] * dim;
+        const double *b0 = tgtRaw + tgtOff[t] * dim;
+        if (Fa == 0 || Fb == 0) {
+            if (lane == 0)
+                out[k] = INF;
+            continue;
+        }
+        __syncthreads();   // previous pair's LDS reads are done
+        const double *bsrc = b0;
+        if (LDS_FRAMES) {
+            for (int i = lane; i < Fb * (int)dim; i += 64)
+                ldsB[i] = b0[i];
+            bsrc = ldsB;
+        }
+        double result = INF;
+        int chunk = 0;
+        for (int c0 = 0; c0 < Fa; c0 += 64, ++chunk) {
+            const int r = c0 + lane;
+            const bool rowValid = r < Fa;
+            const int rowsHere = min(64, Fa - c0);
+            const double *arow = a0 + (size_t)(rowValid ? r : c0) * dim;
+            if (LDS_FRAMES) {
+                __syncthreads();   // previous chunk's A rows no longer read
+                for (int i = lane; i < rowsHere * (int)dim; i += 64)
+                    ldsA[i] = a0[(size_t)c0 * dim + i];
+                arow = ldsA + (size_t)(rowValid ? lane : 0) * dim;
+            }
+            __syncthreads();       // staged frames + previous chunk's boundary row visible
+            const double *boundPrev = (chunk & 1) ? bound0 : bound1;
+            double *boundCur = (chunk & 1) ? bound1 : bound0;
+
+            double mine = INF;      // D(r, j-1)
+            double diagReg = INF;   // D(r-1, j-1)
+            const int nSteps = rowsHere + Fb - 1;
+            for (int tau = 0; tau < nSteps; ++tau) {
+                const int j = tau - lane;
+                double fromAbove = shfl_up1(mine);        // D(r-1, j) for lanes >= 1
+                double diagv = diagReg;
+                if (lane == 0) {
+                    if (c0 == 0) {
+                        fromAbove = INF;
+                        diagv = (j == 0) ? 0.0 : INF;     // virtual D(-1,-1) = 0
+                    } else {
+                        fromAbove = (j >= 0 && j < Fb) ? boundPrev[j] : INF;
+                        diagv = (j >= 1 && j <= Fb) ? boundPrev[j - 1] : INF;
+                    }
+                }
+                const bool active = rowValid && j >= 0 && j < Fb;
+                if (active) {
+                    double cur = INF;
+                    const int dij = r - j;
+                    if (band < 0 || (dij <= band && -dij <= band)) {
+                        const double *bj = bsrc + (size_t)j * dim;
+                        double acc = 0.0;
+                        for (uint32_t e = 0; e < dim; ++e) {
+                            double df = __dsub_rn(arow[e], bj[e]);
+                            acc = __dadd_rn(acc, __dmul_rn(df, df));
+                        }
+                        const double c = squared ? acc : sqrt(acc);
+                        double best = fromAbove;              // D(i-1, j)
+                        if (mine < best) best = mine;         // D(i,   j-1)
+                        if (diagv < best) best = diagv;       // D(i-1, j-1)
+                        cur = __dadd_rn(c, best);
+                    }
+                    if (lane == 63)
+                        boundCur[j] = cur;
+                    if (r == Fa - 1 && j == Fb - 1)
+                        result = cur;
+                    mine = cur;
+                }
+                diagReg = fromAbove;
+            }
+        }
+        if ((Fa - 1) % 64 == lane)
+            out[k] = result;
+    }
+}
+
+int32_t launch_dtw_exact(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt,
+                         const uint2 *pairs, const uint32_t *count_dev, uint32_t max_pairs,
+                         double *out)
+{
+    if (src.dim != tgt.dim) {
+        ctx->err = "dim mismatch between dictionary and targets";
+        return SSYM_E_INVALID;
+    }
+    const uint32_t dim = src.dim;
+    const uint32_t fbCap = std::max<uint32_t>(tgt.max_frames, 1);
+    const size_t boundBytes = 2 * (size_t)fbCap * sizeof(double);
+    const size_t frameBytes = (64 * (size_t)dim + (size_t)fbCap * dim) * sizeof(double);
+    if (boundBytes > 120 * 1024) {
+        ctx->err = "dtw exact: target segment too long (boundary row does not fit LDS)";
+        return SSYM_E_UNSUPPORTED;
+    }
+    const bool ldsFrames = boundBytes + frameBytes <= 64 * 1024;
+    const size_t lds = boundBytes + (ldsFrames ? frameBytes : 0);
+    uint64_t total = pairs ? max_pairs : (uint64_t)src.n * tgt.n;
+    if (total == 0)
+        return SSYM_OK;
+    // enough single-wave blocks to fill the chip several times over; grid-stride covers the rest
+    unsigned grid = (unsigned)std::min<uint64_t>(total, (uint64_t)ctx->num_cus * 64);
+    hipStream_t st = ctx->stream;
+    if (ldsFrames)
+        dtw_exact_kernel<true><<<grid, 64, lds, st>>>(src.raw, src.off, tgt.raw, tgt.off, src.n, tgt.n,
+                                                     dim, ctx->band, ctx->squared, pairs, count_dev,
+                                                     max_pairs, fbCap, out);
+    else
+        dtw_exact_kernel<false><<<grid, 64, lds, st>>>(src.raw, src.off, tgt.raw, tgt.off, src.n, tgt.n,
+                                                      dim, ctx->band, ctx->squared, pairs, count_dev,
+                                                      max_pairs, fbCap, out);
+    SSYM_HIP_CHECK(ctx, hipGetLastError());
+    return SSYM_OK;
+}
+
+}  // namespace ssym

@@ -1,0 +1,315 @@
+// pack.hip -- turns the caller's array-of-segments (Sound::mfccs() per segment, frame-major,
+// reference layout src/sound.rs:189-193, 330-343) into the device-resident forms the kernels read:
+//   raw   f64 [total_frames][dim]        exact copy / exact widening of the input
+//   norm  f64 [n]                        refcos: norm(me) per segment, src/sound.rs:35-38 order
+//   rec   f32 [n_pad][frames_pad][2*KSP] dtw filter: MFMA operand records (ssym_internal.hpp)
+//   len, max_sqnorm                      per segment
+#include "ssym_internal.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+namespace ssym {
+
+int32_t ensure(ssym_ctx *ctx, DeviceBuf &b, size_t bytes)
+{
+    if (bytes <= b.bytes && b.ptr)
+        return SSYM_OK;
+    if (b.ptr) {
+        SSYM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        SSYM_HIP_CHECK(ctx, hipFree(b.ptr));
+        b.ptr = nullptr;
+        b.bytes = 0;
+    }
+    size_t want = std::max<size_t>(bytes, 256);
+    SSYM_HIP_CHECK(ctx, hipMalloc(&b.ptr, want));
+    b.bytes = want;
+    return SSYM_OK;
+}
+
+__global__ void widen_f32_kernel(const float *__restrict__ in, double *__restrict__ out, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride)
+        out[i] = (double)in[i];
+}
+
+// refcos: norm(me) = fold(0, |memo, item| item*item + memo), src/sound.rs:35-38.
+// One thread per segment, strictly sequential, product and sum rounded separately
+// (the library is compiled with -ffp-contract=off; __dmul_rn/__dadd_rn make it explicit).
+__global__ void segment_norm_kernel(const double *__restrict__ raw, const uint64_t *__restrict__ off,
+                                    uint32_t n, uint32_t dim, double *__restrict__ norm)
+{
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n)
+        return;
+    const double *p = raw + off[s] * dim;
+    size_t len = (size_t)(off[s + 1] - off[s]) * dim;
+    double memo = 0.0;
+    for (size_t i = 0; i < len; ++i) {
+        double v = p[i];
+        memo = __dadd_rn(__dmul_rn(v, v), memo);
+    }
+    norm[s] = memo;
+}
+
+// dtw filter records: one thread per (segment, record slot).
+//   targets: frame f sits in slot f.
+//   sources: END-ALIGNED -- frame f of a segment with nf frames sits in slot frames_pad - nf + f;
+//            the slots above it (and every slot of a padding segment) carry |a|^2 = +inf, which
+//            keeps their DP rows at +inf in dtw_filter.hip.
+__global__ void build_records_kernel(const double *__restrict__ raw, const uint64_t *__restrict__ off,
+                                     uint32_t n, uint32_t dim, uint32_t frames_pad, int ks, int ksp,
+                                     int is_source, float *__restrict__ rec,
+                                     int32_t *__restrict__ len, unsigned *__restrict__ max_sqnorm_bits)
+{
+    const uint32_t s = blockIdx.y;                              // < n_pad
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= frames_pad)
+        return;
+    const uint32_t nf = s < n ? (uint32_t)(off[s + 1] - off[s]) : 0u;
+    if (slot == 0)
+        len[s] = (int32_t)nf;
+    float *r = rec + ((size_t)s * frames_pad + slot) * (size_t)(2 * ksp);
+    const int nh = (int)dim / ks, nk = (int)dim % ks;           // where the norm element lives
+    uint32_t f;
+    if (is_source) {
+        if (slot < frames_pad - nf) {
+            r[nh * ksp + nk] = __builtin_inff();
+            return;
+        }
+        f = slot - (frames_pad - nf);
+    } else {
+        if (slot >= nf)
+            return;
+        f = slot;
+    }
+    const double *p = raw + (off[s] + f) * dim;
+    double sq = 0.0;
+    for (uint32_t e = 0; e < dim; ++e) {
+        float v = (float)p[e];               // f32 operand the MFMA will see
+        sq += (double)v * (double)v;          // norm of the ROUNDED frame (self-consistent expansion)
+        int h = (int)e / ks, k = (int)e % ks;
+        r[h * ksp + k] = is_source ? -2.0f * v : v;
+    }
+    float sqf = (float)sq;
+    r[nh * ksp + nk] = is_source ? sqf : 1.0f;
+    if (!is_source) {
+        r[ksp - 1] = sqf;       // pad slot of half 0
+        r[2 * ksp - 1] = sqf;   // pad slot of half 1
+    }
+    // upper bound of the true squared norm as f32 bits (non-negative floats order like uints)
+    float up = sqf * 1.000001f;
+    atomicMax(&max_sqnorm_bits[s], __float_as_uint(up));
+}
+
+void free_segments(SegmentSet &set)
+{
+    if (set.raw) (void)hipFree(set.raw);
+    if (set.off) (void)hipFree(set.off);
+    if (set.norm) (void)hipFree(set.norm);
+    if (set.rec) (void)hipFree(set.rec);
+    if (set.len) (void)hipFree(set.len);
+    if (set.max_sqnorm) (void)hipFree(set.max_sqnorm);
+    set = SegmentSet{};
+}
+
+// (Re)build everything derived from set.raw / set.h_off.
+static int32_t build_derived(ssym_ctx *ctx, SegmentSet &set)
+{
+    hipStream_t st = ctx->stream;
+    const uint32_t n = set.n, dim = set.dim;
+    if (set.off) { (void)hipFree(set.off); set.off = nullptr; }
+    if (set.norm) { (void)hipFree(set.norm); set.norm = nullptr; }
+    if (set.rec) { (void)hipFree(set.rec); set.rec = nullptr; }
+    if (set.len) { (void)hipFree(set.len); set.len = nullptr; }
+    if (set.max_sqnorm) { (void)hipFree(set.max_sqnorm); set.max_sqnorm = nullptr; }
+
+    set.max_frames = 0;
+    for (uint32_t i = 0; i < n; ++i)
+        set.max_frames = std::max<uint32_t>(set.max_frames, (uint32_t)(set.h_off[i + 1] - set.h_off[i]));
+
+    SSYM_HIP_CHECK(ctx, hipMalloc((void **)&set.off, sizeof(uint64_t) * (n + 1)));
+    SSYM_HIP_CHECK(ctx, hipMemcpyAsync(set.off, set.h_off.data(), sizeof(uint64_t) * (n + 1),
+                                       hipMemcpyHostToDevice, st));
+    if (n == 0) {
+        SSYM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        return SSYM_OK;
+    }
+
+    if (ctx->metric == SSYM_METRIC_REFCOS) {
+        SSYM_HIP_CHECK(ctx, hipMalloc((void **)&set.norm, sizeof(double) * n));
+        segment_norm_kernel<<<(n + 63) / 64, 64, 0, st>>>(set.raw, set.off, n, dim, set.norm);
+        SSYM_HIP_CHECK(ctx, hipGetLastError());
+    } else {
+        set.ks = filter_ks((int)dim);
+        set.ksp = filter_ksp(set.ks);
+        const uint32_t quantum = set.is_source ? 8u : 32u;
+        set.n_pad = (n + quantum - 1) / quantum * quantum;
+        uint32_t mf = std::max<uint32_t>(set.max_frames, 1);
+        set.frames_pad = set.is_source ? (uint32_t)filter_rows_pad((int)mf) : mf;
+        size_t rec_bytes = (size_t)set.n_pad * set.frames_pad * 2 * set.ksp * sizeof(float);
+        SSYM_HIP_CHECK(ctx, hipMalloc((void **)&set.rec, rec_bytes));
+        SSYM_HIP_CHECK(ctx, hipMemsetAsync(set.rec, 0, rec_bytes, st));
+        SSYM_HIP_CHECK(ctx, hipMalloc((void **)&set.len, sizeof(int32_t) * set.n_pad));
+        SSYM_HIP_CHECK(ctx, hipMemsetAsync(set.len, 0, sizeof(int32_t) * set.n_pad, st));
+        SSYM_HIP_CHECK(ctx, hipMalloc((void **)&set.max_sqnorm, sizeof(float) * set.n_pad));
+        SSYM_HIP_CHECK(ctx, hipMemsetAsync(set.max_sqnorm, 0, sizeof(float) * set.n_pad, st));
+        dim3 grid((set.frames_pad + 63) / 64, set.n_pad);
+        build_records_kernel<<<grid, 64, 0, st>>>(set.raw, set.off, n, dim, set.frames_pad, set.ks,
+                                                  set.ksp, set.is_source ? 1 : 0, set.rec, set.len,
+                                                  (unsigned *)set.max_sqnorm);
+        SSYM_HIP_CHECK(ctx, hipGetLastError());
+        std::vector<float> h(set.n_pad);
+        SSYM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), set.max_sqnorm, sizeof(float) * set.n_pad,
+                                           hipMemcpyDeviceToHost, st));
+        SSYM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        float m = 0.f;
+        for (float v : h)
+            m = std::max(m, v);
+        set.max_sqnorm_all = (double)m;
+    }
+    SSYM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    return SSYM_OK;
+}
+
+static int32_t validate_offsets(ssym_ctx *ctx, const uint64_t *off, uint32_t n)
+{
+    if (!off) {
+        ctx->err = "frame_offsets is NULL";
+        return SSYM_E_INVALID;
+    }
+    for (uint32_t i = 0; i < n; ++i) {
+        if (off[i + 1] < off[i]) {
+            ctx->err = "frame_offsets must be non-decreasing";
+            return SSYM_E_INVALID;
+        }
+        if (off[i + 1] - off[i] > 0x7fffffffull) {
+            ctx->err = "segment too long";
+            return SSYM_E_INVALID;
+        }
+    }
+    return SSYM_OK;
+}
+
+// Copy `count_vals` feature values (ctx dtype) starting at `feats` into set.raw + dst_val_offset.
+static int32_t upload_values(ssym_ctx *ctx, SegmentSet &set, size_t dst_val_offset, const void *feats,
+                             bool on_device, size_t count_vals)
+{
+    if (count_vals == 0)
+        return SSYM_OK;
+    hipStream_t st = ctx->stream;
+    double *dst = set.raw + dst_val_offset;
+    if (ctx->dtype == SSYM_DTYPE_F64) {
+        SSYM_HIP_CHECK(ctx, hipMemcpyAsync(dst, feats, count_vals * sizeof(double),
+                                           on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+        SSYM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        return SSYM_OK;
+    }
+    const float *src_dev = (const float *)feats;
+    float *tmp = nullptr;
+    if (!on_device) {
+        SSYM_HIP_CHECK(ctx, hipMalloc((void **)&tmp, count_vals * sizeof(float)));
+        hipError_t e = hipMemcpyAsync(tmp, feats, count_vals * sizeof(float), hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) {
+            (void)hipFree(tmp);
+            ctx->err = std::string("hipMemcpyAsync: ") + hipGetErrorString(e);
+            return SSYM_E_HIP;
+        }
+        src_dev = tmp;
+    }
+    unsigned blocks = (unsigned)std::min<size_t>((count_vals + 255) / 256, 4096);
+    widen_f32_kernel<<<blocks, 256, 0, st>>>(src_dev, dst, count_vals);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(st);
+    if (tmp)
+        (void)hipFree(tmp);
+    if (e != hipSuccess) {
+        ctx->err = std::string("widen_f32_kernel: ") + hipGetErrorString(e);
+        return SSYM_E_HIP;
+    }
+    return SSYM_OK;
+}
+
+int32_t pack_segments(ssym_ctx *ctx, SegmentSet &set, const void *feats, bool feats_on_device,
+                      const uint64_t *frame_offsets, uint32_t n, uint32_t dim, bool is_source)
+{
+    if (dim == 0 || dim > 4096) {
+        ctx->err = "dim must be in [1, 4096]";
+        return SSYM_E_INVALID;
+    }
+    if (n > 0) {
+        int32_t rc = validate_offsets(ctx, frame_offsets, n);
+        if (rc != SSYM_OK)
+            return rc;
+    }
+    set.n = n;
+    set.dim = dim;
+    set.is_source = is_source;
+    set.h_off.assign(n + 1, 0);
+    for (uint32_t i = 0; i < n; ++i)
+        set.h_off[i + 1] = frame_offsets[i + 1] - frame_offsets[0];
+    set.total_frames = set.h_off[n];
+    size_t vals = (size_t)set.total_frames * dim;
+    if (vals > 0 && !feats) {
+        ctx->err = "feats is NULL";
+        return SSYM_E_INVALID;
+    }
+    set.raw_capacity_vals = std::max<size_t>(vals, 1);
+    SSYM_HIP_CHECK(ctx, hipMalloc((void **)&set.raw, set.raw_capacity_vals * sizeof(double)));
+    if (vals > 0) {
+        size_t esz = ctx->dtype == SSYM_DTYPE_F64 ? sizeof(double) : sizeof(float);
+        const char *base = (const char *)feats + (size_t)frame_offsets[0] * dim * esz;
+        int32_t rc = upload_values(ctx, set, 0, base, feats_on_device, vals);
+        if (rc != SSYM_OK)
+            return rc;
+    }
+    return build_derived(ctx, set);
+}
+
+int32_t append_segments(ssym_ctx *ctx, SegmentSet &set, const void *feats,
+                        const uint64_t *frame_offsets, uint32_t n)
+{
+    if (n == 0)
+        return SSYM_OK;
+    int32_t rc = validate_offsets(ctx, frame_offsets, n);
+    if (rc != SSYM_OK)
+        return rc;
+    const uint32_t dim = set.dim;
+    uint64_t add_frames = frame_offsets[n] - frame_offsets[0];
+    size_t old_vals = (size_t)set.total_frames * dim;
+    size_t add_vals = (size_t)add_frames * dim;
+    if (add_vals > 0 && !feats) {
+        ctx->err = "feats is NULL";
+        return SSYM_E_INVALID;
+    }
+    if (old_vals + add_vals > set.raw_capacity_vals) {
+        size_t cap = std::max(old_vals + add_vals, set.raw_capacity_vals * 2);
+        double *nraw = nullptr;
+        SSYM_HIP_CHECK(ctx, hipMalloc((void **)&nraw, cap * sizeof(double)));
+        if (old_vals)
+            SSYM_HIP_CHECK(ctx, hipMemcpyAsync(nraw, set.raw, old_vals * sizeof(double),
+                                               hipMemcpyDeviceToDevice, ctx->stream));
+        SSYM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(set.raw);
+        set.raw = nraw;
+        set.raw_capacity_vals = cap;
+    }
+    if (add_vals > 0) {
+        size_t esz = ctx->dtype == SSYM_DTYPE_F64 ? sizeof(double) : sizeof(float);
+        const char *base = (const char *)feats + (size_t)frame_offsets[0] * dim * esz;
+        rc = upload_values(ctx, set, old_vals, base, false, add_vals);
+        if (rc != SSYM_OK)
+            return rc;
+    }
+    uint64_t base_frames = set.total_frames;
+    for (uint32_t i = 0; i < n; ++i)
+        set.h_off.push_back(base_frames + (frame_offsets[i + 1] - frame_offsets[0]));
+    set.n += n;
+    set.total_frames += add_frames;
+    return build_derived(ctx, set);
+}
+
+}  // namespace ssym

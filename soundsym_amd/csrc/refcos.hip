@@ -1,0 +1,176 @@
+// refcos.hip -- the reference's own segment similarity, all pairs, bit for bit.
+//
+// Replaces cosine_sim (src/sound.rs:22-33) as called N x M times from at_distance
+// (src/sound.rs:354):
+//     len = min(|me|, |you|)                                   :24-28
+//     nrm = norm(me) * norm(you)      (full vectors, SQUARED norms, src/sound.rs:35-38)   :30
+//     dot = rulinalg::utils::dot(&me[..len], &you[..len])      :31   (rulinalg 0.4.2)
+//     dot / nrm                                                :32
+//
+// Arithmetic order is the reference's, so results equal the CPU oracle's bit for bit:
+//   * norm: sequential fold per segment, computed once in pack.hip (recomputing it per pair, as the
+//     reference does, yields the same bits);
+//   * dot: rulinalg's eight running sums p0..p7 over blocks of eight elements, combined as
+//     ((((0+(p0+p4))+(p1+p5))+(p2+p6))+(p3+p7)), then the len%8 tail added one product at a time;
+//     every product and sum is rounded separately (no FMA: -ffp-contract=off and __dmul_rn/__dadd_rn);
+//   * the block structure depends on the PAIR's len, so each pair carries its own block count and
+//     switches from the eight sums to the tail exactly where the reference does.
+//
+// Mapping: a 256-thread workgroup owns a 32 x 32 tile of pairs; 64-element chunks of the 32 source
+// and 32 target segments are staged in LDS (element-major, so lanes read consecutive doubles);
+// each thread keeps 2 x 2 pairs x 8 running sums in registers.
+#include "ssym_internal.hpp"
+
+#include <algorithm>
+
+namespace ssym {
+
+constexpr int kTS = 32;       // sources per tile
+constexpr int kTT = 32;       // targets per tile
+constexpr int kCH = 64;       // elements per staged chunk
+constexpr int kLd = kTS + 1;  // padded leading dimension of the element-major LDS images
+
+__global__ __launch_bounds__(256) void refcos_sims_kernel(
+    const double *__restrict__ srcRaw, const uint64_t *__restrict__ srcOff,
+    const double *__restrict__ srcNorm, const double *__restrict__ tgtRaw,
+    const uint64_t *__restrict__ tgtOff, const double *__restrict__ tgtNorm, uint32_t nSrc,
+    uint32_t nTgt, uint32_t dim, uint32_t maxLenVals, double *__restrict__ sims)
+{
+    __shared__ double sS[kCH * kLd];
+    __shared__ double sT[kCH * kLd];
+    __shared__ unsigned long long sBase[kTS + kTT];   // value offset of each staged segment
+    __shared__ unsigned sLen[kTS + kTT];              // length in values
+
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
+    const uint32_t sTile = blockIdx.y * kTS, tTile = blockIdx.x * kTT;
+
+    if (tid < kTS + kTT) {
+        const bool isS = tid < kTS;
+        const uint32_t g = isS ? sTile + tid : tTile + (tid - kTS);
+        const uint32_t n = isS ? nSrc : nTgt;
+        const uint64_t *off = isS ? srcOff : tgtOff;
+        unsigned long long base = 0;
+        unsigned len = 0;
+        if (g < n) {
+            base = off[g] * dim;
+            len = (unsigned)((off[g + 1] - off[g]) * dim);
+        }
+        sBase[tid] = base;
+        sLen[tid] = len;
+    }
+    __syncthreads();
+
+    // this thread's 2 x 2 pairs: sources {ty, ty+16}, targets {tx, tx+16}
+    unsigned q[2][2], rem[2][2];
+    bool done[2][2];
+    double p[2][2][8];
+    double dot[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const unsigned la = sLen[ty + 16 * a], lb = sLen[kTS + tx + 16 * b];
+            const unsigned len = la < lb ? la : lb;            // src/sound.rs:24-28
+            q[a][b] = len / 8;
+            rem[a][b] = len % 8;
+            done[a][b] = false;
+            dot[a][b] = 0.0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                p[a][b][i] = 0.0;
+        }
+
+    const unsigned nChunks = (maxLenVals + kCH - 1) / kCH + 1;   // +1: a block index == q exists
+    for (unsigned c = 0; c < nChunks; ++c) {
+        // ---- stage chunk c of the 32 + 32 segments, element-major, zero beyond each length ----
+        __syncthreads();
+        {
+            const int row = tid >> 3;          // 0..31
+            const int e0 = (tid & 7) * 8;      // 8 consecutive elements
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+                const unsigned long long base = sBase[side * kTS + row];
+                const unsigned len = sLen[side * kTS + row];
+                const double *raw = side ? tgtRaw : srcRaw;
+                double *dst = side ? sT : sS;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const unsigned e = c * kCH + e0 + i;
+                    dst[(e0 + i) * kLd + row] = e < len ? raw[base + e] : 0.0;
+                }
+            }
+        }
+        __syncthreads();
+
+#pragma unroll 1
+        for (int m = 0; m < kCH / 8; ++m) {
+            const unsigned gm = c * (kCH / 8) + m;   // block-of-eight index within the segment
+            double xs[2][8], yt[2][8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                xs[0][i] = sS[(8 * m + i) * kLd + ty];
+                xs[1][i] = sS[(8 * m + i) * kLd + ty + 16];
+                yt[0][i] = sT[(8 * m + i) * kLd + tx];
+                yt[1][i] = sT[(8 * m + i) * kLd + tx + 16];
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    if (gm < q[a][b]) {
+                        // rulinalg dot main loop: p_i = p_i + xs[i] * ys[i]
+#pragma unroll
+                        for (int i = 0; i < 8; ++i)
+                            p[a][b][i] = __dadd_rn(p[a][b][i], __dmul_rn(xs[a][i], yt[b][i]));
+                    } else if (gm == q[a][b] && !done[a][b]) {
+                        double s = 0.0;
+                        s = __dadd_rn(s, __dadd_rn(p[a][b][0], p[a][b][4]));
+                        s = __dadd_rn(s, __dadd_rn(p[a][b][1], p[a][b][5]));
+                        s = __dadd_rn(s, __dadd_rn(p[a][b][2], p[a][b][6]));
+                        s = __dadd_rn(s, __dadd_rn(p[a][b][3], p[a][b][7]));
+#pragma unroll
+                        for (int i = 0; i < 8; ++i)
+                            if ((unsigned)i < rem[a][b])
+                                s = __dadd_rn(s, __dmul_rn(xs[a][i], yt[b][i]));
+                        dot[a][b] = s;
+                        done[a][b] = true;
+                    }
+                }
+        }
+    }
+
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const uint32_t s = sTile + ty + 16 * a, t = tTile + tx + 16 * b;
+            if (s < nSrc && t < nTgt) {
+                const double nrm = __dmul_rn(srcNorm[s], tgtNorm[t]);   // src/sound.rs:30
+                sims[(size_t)s * nTgt + t] = __ddiv_rn(dot[a][b], nrm); // src/sound.rs:32
+            }
+        }
+}
+
+int32_t launch_refcos_sims(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, double *sims)
+{
+    if (src.dim != tgt.dim) {
+        ctx->err = "dim mismatch between dictionary and targets";
+        return SSYM_E_INVALID;
+    }
+    if (src.n == 0 || tgt.n == 0)
+        return SSYM_OK;
+    const uint64_t maxLen = (uint64_t)std::min(src.max_frames, tgt.max_frames) * src.dim;
+    if (maxLen > 0xfffffff0ull) {
+        ctx->err = "segment too long";
+        return SSYM_E_UNSUPPORTED;
+    }
+    dim3 grid((tgt.n + kTT - 1) / kTT, (src.n + kTS - 1) / kTS);
+    refcos_sims_kernel<<<grid, 256, 0, ctx->stream>>>(src.raw, src.off, src.norm, tgt.raw, tgt.off,
+                                                      tgt.norm, src.n, tgt.n, src.dim, (uint32_t)maxLen,
+                                                      sims);
+    SSYM_HIP_CHECK(ctx, hipGetLastError());
+    return SSYM_OK;
+}
+
+}  // namespace ssym

@@ -1,0 +1,377 @@
+// select.hip -- per-target reductions of the matching path.
+//
+// Replaces the fold of SoundDictionary::at_distance (src/sound.rs:359-367):
+//     .map(|v| (v - distance).abs()).enumerate().fold((0usize, 2f64), |..| if d < min {..})
+// i.e. first minimum of |value - distance| with a strict '<', start value INIT, index 0 when
+// nothing beats INIT.  INIT = 2.0 for refcos (the reference's literal), +inf for dtw.
+//
+// dtw has two stages around the exact kernel:
+//   1. candidate selection on the f32 filter costs with a rigorous margin (derivation below),
+//   2. final first-minimum over the exactly re-scored candidates.
+#include "ssym_internal.hpp"
+
+#include <algorithm>
+#include <cmath>
+
+namespace ssym {
+
+// ---------------------------------------------------------------------------------------------
+// Error bound of the f32 MFMA filter (dtw_filter.hip), u = 2^-24.
+//
+//  x~ = |fl( sum of 2*KS products, then + |b|^2 )| with true value x = |a - b|^2 >= 0:
+//       the fma chain has at most 2*KS+1 <= 15 roundings (dim <= 13) over the terms |a|^2, |b|^2,
+//       -2 a_k b_k, and the two stored norms are themselves rounded once:
+//          |x~ - x| <= (gamma_15 + u(1 + gamma_15)) (|a|^2 + |b|^2 + 2 sum|a_k b_k|)
+//                   <= 33 u (|a|^2 + |b|^2)            =: E            (2 sum|a_k b_k| <= |a|^2+|b|^2)
+//  local cost c~ = sqrt~(x~), v_sqrt_f32 within 1 ulp:  |c~ - c| <= sqrt(E) + 2u c
+//       (|sqrt(y) - sqrt(x)| <= sqrt(|y - x|));  squared-L2 mode: |c~ - c| <= E.
+//  f64 inputs rounded to f32 move every frame by at most u|a|, so c moves by <= u(|a| + |b|)
+//       (squared mode: <= 2 u (|a|+|b|)^2 (1+u) <= 4.1 u (|a|^2 + |b|^2)).
+//  DP: min is exact, each of the <= Fa+Fb-1 additions along a path rounds once (relative u), and
+//       DTW is monotone and 1-Lipschitz in the cell costs along the optimal path of either side:
+//          |C~ - C| <= P * cell + rho * C,   P = Fa + Fb - 1,  rho = (P + 2) u.
+//  Selection: with s^ the filter's argmin of key = |C~ - delta| and s* the exact one,
+//          key~(s*) <= key~(s^) + 2 P cell + rho (C(s*) + C(s^)),
+//       so every target keeps all s with key~(s) <= keymin~ + margin,
+//          margin = 2.05 P cell + 3.1 rho (delta + keymin~) .
+//  The constants below add slack on top (34 instead of 33, maxima over the whole dictionary).
+// ---------------------------------------------------------------------------------------------
+struct MarginParams {
+    double na_max;    // max_f |a_f|^2 over the dictionary (rounded up)
+    int fa_max;
+    int squared;
+};
+
+__device__ __forceinline__ double dtw_margin(const MarginParams &mp, double nb_max, int fb,
+                                             double delta, double keymin)
+{
+    const double u = 5.9604644775390625e-8;   // 2^-24
+    const double nsum = mp.na_max + nb_max;
+    double cell;
+    if (mp.squared)
+        cell = (34.0 + 4.1) * u * nsum;
+    else
+        cell = sqrt(34.0 * u * nsum) + 3.0 * u * (sqrt(mp.na_max) + sqrt(nb_max));
+    const double P = (double)(mp.fa_max + fb - 1);
+    const double rho = (P + 2.0) * u;
+    return 2.05 * P * cell + 3.1 * rho * (delta + keymin) + 1e-300;
+}
+
+__global__ void fill_u64_kernel(unsigned long long *p, unsigned long long v, uint32_t n)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        p[i] = v;
+}
+
+__global__ void fill_u32_kernel(uint32_t *p, uint32_t v, uint32_t n)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        p[i] = v;
+}
+
+constexpr int kSelChunk = 64;   // sources scanned per thread
+
+// key~(s,t) = |C~(s,t) - delta_t|; keymin[t] = min_s key~ as order-preserving u64 bits.
+__global__ __launch_bounds__(256) void dtw_colmin_kernel(const float *__restrict__ cmat, uint32_t nSrc,
+                                                         uint32_t nTgt, uint32_t mPad,
+                                                         const double *__restrict__ dist,
+                                                         unsigned long long *__restrict__ keymin)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nTgt)
+        return;
+    const double delta = dist ? dist[t] : 0.0;
+    const uint32_t s0 = blockIdx.y * kSelChunk;
+    const uint32_t s1 = min(s0 + kSelChunk, nSrc);
+    double best = __builtin_inf();
+    for (uint32_t s = s0; s < s1; ++s) {
+        const double key = fabs((double)cmat[(size_t)s * mPad + t] - delta);
+        if (key < best)
+            best = key;
+    }
+    if (best < __builtin_inf())
+        atomicMin(&keymin[t], (unsigned long long)__double_as_longlong(best));
+}
+
+// cand layout: [0] = count, [1] = overflow flag, pairs start at cand + 2 (as uint2)
+__global__ __launch_bounds__(256) void dtw_select_kernel(
+    const float *__restrict__ cmat, uint32_t nSrc, uint32_t nTgt, uint32_t mPad,
+    const double *__restrict__ dist, const unsigned long long *__restrict__ keymin,
+    const int *__restrict__ tgtLen, const float *__restrict__ tgtMaxSq, MarginParams mp,
+    uint32_t cap, uint32_t *__restrict__ candHdr, uint2 *__restrict__ candPairs)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nTgt)
+        return;
+    const double km = __longlong_as_double((long long)keymin[t]);
+    if (!(km < __builtin_inf()))
+        return;   // no finite cost for this target: the fold keeps (0, +inf)
+    const double delta = dist ? dist[t] : 0.0;
+    const double thr = km + dtw_margin(mp, (double)tgtMaxSq[t], tgtLen[t], delta, km);
+    const uint32_t s0 = blockIdx.y * kSelChunk;
+    const uint32_t s1 = min(s0 + kSelChunk, nSrc);
+    for (uint32_t s = s0; s < s1; ++s) {
+        const double key = fabs((double)cmat[(size_t)s * mPad + t] - delta);
+        if (key <= thr) {
+            const uint32_t slot = atomicAdd(&candHdr[0], 1u);
+            if (slot < cap)
+                candPairs[slot] = make_uint2(s, t);
+            else
+                candHdr[1] = 1u;
+        }
+    }
+}
+
+// final first-minimum over exactly re-scored candidates, three order-independent passes:
+//   A: bestKey[t] = min key      B: bestIdx[t] = min s among key == bestKey      C: outputs
+__global__ void dtw_final_key_kernel(const uint32_t *__restrict__ candHdr, const uint2 *__restrict__ pairs,
+                                     const double *__restrict__ costs, uint32_t cap,
+                                     const double *__restrict__ dist,
+                                     unsigned long long *__restrict__ bestKey)
+{
+    const uint32_t n = min(candHdr[0], cap);
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const uint2 p = pairs[k];
+        const double key = fabs(costs[k] - (dist ? dist[p.y] : 0.0));
+        if (key < __builtin_inf())
+            atomicMin(&bestKey[p.y], (unsigned long long)__double_as_longlong(key));
+    }
+}
+
+__global__ void dtw_final_idx_kernel(const uint32_t *__restrict__ candHdr, const uint2 *__restrict__ pairs,
+                                     const double *__restrict__ costs, uint32_t cap,
+                                     const double *__restrict__ dist,
+                                     const unsigned long long *__restrict__ bestKey,
+                                     uint32_t *__restrict__ bestIdx)
+{
+    const uint32_t n = min(candHdr[0], cap);
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const uint2 p = pairs[k];
+        const double key = fabs(costs[k] - (dist ? dist[p.y] : 0.0));
+        if ((unsigned long long)__double_as_longlong(key) == bestKey[p.y])
+            atomicMin(&bestIdx[p.y], p.x);
+    }
+}
+
+__global__ void dtw_final_out_kernel(const uint32_t *__restrict__ candHdr, const uint2 *__restrict__ pairs,
+                                     const double *__restrict__ costs, uint32_t cap,
+                                     const uint32_t *__restrict__ bestIdx, uint32_t nTgt,
+                                     uint32_t indexBase, uint32_t *__restrict__ outIdx,
+                                     double *__restrict__ outCost)
+{
+    const uint32_t n = min(candHdr[0], cap);
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    // targets with no finite candidate keep the fold start (index 0, +inf)
+    for (uint32_t t = tid; t < nTgt; t += stride) {
+        if (bestIdx[t] == 0xffffffffu) {
+            outIdx[t] = indexBase;
+            if (outCost)
+                outCost[t] = __builtin_inf();
+        }
+    }
+    for (uint32_t k = tid; k < n; k += stride) {
+        const uint2 p = pairs[k];
+        if (bestIdx[p.y] == p.x) {
+            // duplicates of one (s,t) cannot occur: each pair is appended once
+            outIdx[p.y] = p.x + indexBase;
+            if (outCost)
+                outCost[p.y] = costs[k];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Generic first-minimum over a full [nSrc][nTgt] f64 matrix (refcos similarities, or exact dtw
+// costs when the filter is bypassed).  Chunks are folded in source order with a strict '<', so
+// the result equals the reference's sequential fold.
+// ---------------------------------------------------------------------------------------------
+constexpr int kFoldChunk = 128;
+
+__global__ __launch_bounds__(128) void fold_partial_kernel(const double *__restrict__ mat, uint32_t nSrc,
+                                                           uint32_t nTgt, const double *__restrict__ dist,
+                                                           double defaultDist, double init,
+                                                           uint32_t *__restrict__ partIdx,
+                                                           double *__restrict__ partVal)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nTgt)
+        return;
+    const double delta = dist ? dist[t] : defaultDist;
+    const uint32_t s0 = blockIdx.y * kFoldChunk;
+    const uint32_t s1 = min(s0 + kFoldChunk, nSrc);
+    uint32_t minIdx = 0xffffffffu;
+    double minVal = init;
+    for (uint32_t s = s0; s < s1; ++s) {
+        const double v = fabs(mat[(size_t)s * nTgt + t] - delta);   // src/sound.rs:359
+        if (v < minVal) {                                           // src/sound.rs:362 (NaN never wins)
+            minIdx = s;
+            minVal = v;
+        }
+    }
+    partIdx[(size_t)blockIdx.y * nTgt + t] = minIdx;
+    partVal[(size_t)blockIdx.y * nTgt + t] = minVal;
+}
+
+__global__ __launch_bounds__(128) void fold_final_kernel(const uint32_t *__restrict__ partIdx,
+                                                         const double *__restrict__ partVal,
+                                                         uint32_t nChunks, uint32_t nTgt, double init,
+                                                         const double *__restrict__ gatherFrom,
+                                                         uint32_t indexBase, uint32_t *__restrict__ outIdx,
+                                                         double *__restrict__ outCost)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nTgt)
+        return;
+    uint32_t minIdx = 0;       // fold start (0usize, INIT), src/sound.rs:361
+    double minVal = init;
+    for (uint32_t c = 0; c < nChunks; ++c) {
+        const double v = partVal[(size_t)c * nTgt + t];
+        if (v < minVal) {
+            minVal = v;
+            minIdx = partIdx[(size_t)c * nTgt + t];
+        }
+    }
+    outIdx[t] = minIdx + indexBase;
+    if (outCost) {
+        // refcos reports the winning |sim - distance|; dtw reports the winner's cost itself
+        if (gatherFrom && minVal < init)
+            outCost[t] = gatherFrom[(size_t)minIdx * nTgt + t];
+        else
+            outCost[t] = minVal;
+    }
+}
+
+// Source-sharded multi-GPU merge: smallest cost, lowest global index
+// on equal cost.  Shards are ordered by index, so this is the same first-minimum rule.
+__global__ void merge_shards_kernel(uint32_t nShards, uint32_t nTgt, const double *__restrict__ costs,
+                                    const uint32_t *__restrict__ idx, uint32_t *__restrict__ outIdx,
+                                    double *__restrict__ outCost)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nTgt)
+        return;
+    double bc = costs[t];
+    uint32_t bi = idx[t];
+    for (uint32_t g = 1; g < nShards; ++g) {
+        const double c = costs[(size_t)g * nTgt + t];
+        const uint32_t i = idx[(size_t)g * nTgt + t];
+        if (c < bc || (c == bc && i < bi)) {
+            bc = c;
+            bi = i;
+        }
+    }
+    outIdx[t] = bi;
+    if (outCost)
+        outCost[t] = bc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+int32_t launch_dtw_select(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt,
+                          const float *cmat, const double *dist_dev, uint32_t cap)
+{
+    hipStream_t st = ctx->stream;
+    MarginParams mp;
+    mp.na_max = src.max_sqnorm_all;
+    mp.fa_max = (int)src.max_frames;
+    mp.squared = ctx->squared;
+    int32_t rc = ensure(ctx, ctx->tmin, sizeof(unsigned long long) * tgt.n);
+    if (rc != SSYM_OK)
+        return rc;
+    rc = ensure(ctx, ctx->cand, sizeof(uint32_t) * 2 + sizeof(uint2) * (size_t)cap);
+    if (rc != SSYM_OK)
+        return rc;
+    unsigned long long *keymin = (unsigned long long *)ctx->tmin.ptr;
+    uint32_t *hdr = (uint32_t *)ctx->cand.ptr;
+    uint2 *pairs = (uint2 *)(hdr + 2);
+    const unsigned long long infBits = 0x7ff0000000000000ull;
+    fill_u64_kernel<<<(tgt.n + 255) / 256, 256, 0, st>>>(keymin, infBits, tgt.n);
+    SSYM_HIP_CHECK(ctx, hipMemsetAsync(hdr, 0, sizeof(uint32_t) * 2, st));
+    dim3 grid((tgt.n + 255) / 256, (src.n + kSelChunk - 1) / kSelChunk);
+    dtw_colmin_kernel<<<grid, 256, 0, st>>>(cmat, src.n, tgt.n, tgt.n_pad, dist_dev, keymin);
+    dtw_select_kernel<<<grid, 256, 0, st>>>(cmat, src.n, tgt.n, tgt.n_pad, dist_dev, keymin, tgt.len,
+                                            tgt.max_sqnorm, mp, cap, hdr, pairs);
+    SSYM_HIP_CHECK(ctx, hipGetLastError());
+    return SSYM_OK;
+}
+
+int32_t launch_dtw_final(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt,
+                         const double *dist_dev, uint32_t cap, uint32_t index_base,
+                         uint32_t *out_idx_dev, double *out_cost_dev)
+{
+    (void)src;
+    hipStream_t st = ctx->stream;
+    int32_t rc = ensure(ctx, ctx->best, (sizeof(unsigned long long) + sizeof(uint32_t)) * (size_t)tgt.n);
+    if (rc != SSYM_OK)
+        return rc;
+    unsigned long long *bestKey = (unsigned long long *)ctx->best.ptr;
+    uint32_t *bestIdx = (uint32_t *)(bestKey + tgt.n);
+    const uint32_t *hdr = (const uint32_t *)ctx->cand.ptr;
+    const uint2 *pairs = (const uint2 *)(hdr + 2);
+    const double *costs = (const double *)ctx->cand_cost.ptr;
+    fill_u64_kernel<<<(tgt.n + 255) / 256, 256, 0, st>>>(bestKey, 0x7ff0000000000000ull, tgt.n);
+    fill_u32_kernel<<<(tgt.n + 255) / 256, 256, 0, st>>>(bestIdx, 0xffffffffu, tgt.n);
+    const unsigned blocks = std::max(1u, std::min((cap + 255) / 256, 1024u));
+    dtw_final_key_kernel<<<blocks, 256, 0, st>>>(hdr, pairs, costs, cap, dist_dev, bestKey);
+    dtw_final_idx_kernel<<<blocks, 256, 0, st>>>(hdr, pairs, costs, cap, dist_dev, bestKey, bestIdx);
+    const unsigned blocks2 = std::max(blocks, std::min((tgt.n + 255) / 256, 1024u));
+    dtw_final_out_kernel<<<blocks2, 256, 0, st>>>(hdr, pairs, costs, cap, bestIdx, tgt.n, index_base,
+                                                  out_idx_dev, out_cost_dev);
+    SSYM_HIP_CHECK(ctx, hipGetLastError());
+    return SSYM_OK;
+}
+
+static int32_t launch_fold(ssym_ctx *ctx, uint32_t n_src, uint32_t n_tgt, const double *mat,
+                           const double *dist_dev, double default_dist, double init, bool gather,
+                           uint32_t index_base, uint32_t *out_idx_dev, double *out_cost_dev)
+{
+    hipStream_t st = ctx->stream;
+    const uint32_t nChunks = (n_src + kFoldChunk - 1) / kFoldChunk;
+    int32_t rc = ensure(ctx, ctx->part, (sizeof(double) + sizeof(uint32_t)) * (size_t)nChunks * n_tgt);
+    if (rc != SSYM_OK)
+        return rc;
+    double *partVal = (double *)ctx->part.ptr;
+    uint32_t *partIdx = (uint32_t *)(partVal + (size_t)nChunks * n_tgt);
+    dim3 grid((n_tgt + 127) / 128, nChunks);
+    fold_partial_kernel<<<grid, 128, 0, st>>>(mat, n_src, n_tgt, dist_dev, default_dist, init, partIdx,
+                                              partVal);
+    fold_final_kernel<<<(n_tgt + 127) / 128, 128, 0, st>>>(partIdx, partVal, nChunks, n_tgt, init,
+                                                           gather ? mat : nullptr, index_base,
+                                                           out_idx_dev, out_cost_dev);
+    SSYM_HIP_CHECK(ctx, hipGetLastError());
+    return SSYM_OK;
+}
+
+int32_t launch_dtw_final_allpairs(ssym_ctx *ctx, uint32_t n_src, uint32_t n_tgt, const double *costs,
+                                  const double *dist_dev, uint32_t index_base,
+                                  uint32_t *out_idx_dev, double *out_cost_dev)
+{
+    return launch_fold(ctx, n_src, n_tgt, costs, dist_dev, 0.0, (double)INFINITY, true, index_base,
+                       out_idx_dev, out_cost_dev);
+}
+
+int32_t launch_refcos_argmin(ssym_ctx *ctx, uint32_t n_src, uint32_t n_tgt, const double *sims,
+                             const double *dist_dev, uint32_t index_base, uint32_t *out_idx_dev,
+                             double *out_cost_dev)
+{
+    // match_sound = at_distance(1.0, ..) (src/sound.rs:346-348); fold start 2.0 (src/sound.rs:361)
+    return launch_fold(ctx, n_src, n_tgt, sims, dist_dev, 1.0, 2.0, false, index_base, out_idx_dev,
+                       out_cost_dev);
+}
+
+int32_t launch_merge_shards(ssym_ctx *ctx, uint32_t n_shards, uint32_t n_targets, const double *costs,
+                            const uint32_t *idx, uint32_t *out_idx, double *out_cost)
+{
+    if (n_targets == 0)
+        return SSYM_OK;
+    merge_shards_kernel<<<(n_targets + 255) / 256, 256, 0, ctx->stream>>>(n_shards, n_targets, costs, idx,
+                                                                         out_idx, out_cost);
+    SSYM_HIP_CHECK(ctx, hipGetLastError());
+    return SSYM_OK;
+}
+
+}  // namespace ssym

@@ -1,0 +1,158 @@
+// Internal declarations shared by the HIP translation units of libsoundsym_amd.so.
+// Nothing here is part of the C ABI (include/soundsym_amd.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "soundsym_amd.h"
+
+namespace ssym {
+
+// ---------------------------------------------------------------------------------------------
+// Packed record layout for the dtw MFMA filter (see dtw_filter.hip and DESIGN.md).
+// One record per frame = 2 halves of KSP floats; half h holds K-elements [h*KS, h*KS+KS).
+//   source ("A") record element e: -2*a[e] for e < dim, ||a||^2 at e = dim, 0 after
+//   target ("B") record element e:     b[e] for e < dim, 1.0     at e = dim, 0 after
+//   target records also carry ||b||^2 in the LAST float of each half (pad slot, never fed to MFMA)
+// KS = number of 32x32x2 k-steps = ceil((dim+1)/2); KSP = KS rounded up so a pad slot exists and
+// a half is a whole number of 16-byte loads.
+// ---------------------------------------------------------------------------------------------
+constexpr int kRowsPerTile = 16;   // frames of one source per 32x32 MFMA tile
+constexpr int kMaxTiles = 8;       // register-resident DP column: up to 128 source frames
+
+inline int filter_ks(int dim) { return (dim + 1 + 1) / 2; }
+// source rows are padded to a tile count the filter kernel is instantiated for
+inline int filter_rows_pad(int max_frames)
+{
+    const int avail[] = {1, 2, 3, 4, 6, 8};
+    int nt = (max_frames + kRowsPerTile - 1) / kRowsPerTile;
+    if (nt < 1) nt = 1;
+    for (int a : avail)
+        if (nt <= a) return a * kRowsPerTile;
+    return nt * kRowsPerTile;   // beyond the filter's reach; exact kernel only
+}
+inline int filter_ksp(int ks) { return ((ks + 1) + 3) / 4 * 4; }  // >= ks+1 (pad slot for ||b||^2)
+
+struct DeviceBuf {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+};
+
+struct SegmentSet {
+    // raw features, always f64 on device (f32 inputs are widened exactly)
+    double *raw = nullptr;          // [total_frames * dim]
+    uint64_t *off = nullptr;        // device copy of frame offsets, rebased to 0, [n+1]
+    std::vector<uint64_t> h_off;    // host copy, rebased to 0
+    uint32_t n = 0;
+    uint32_t dim = 0;
+    uint64_t total_frames = 0;
+    uint32_t max_frames = 0;
+    // refcos
+    double *norm = nullptr;         // [n]  norm(me) of src/sound.rs:35-38 per segment
+    // dtw filter
+    float *rec = nullptr;           // [n_pad][frames_pad][2*KSP]
+    int32_t *len = nullptr;         // [n_pad] frames per segment (0 for padding segments)
+    float *max_sqnorm = nullptr;    // [n_pad] max_f ||frame||^2 per segment (f32, rounded up)
+    double max_sqnorm_all = 0.0;    // host: max over all segments
+    uint32_t n_pad = 0;
+    uint32_t frames_pad = 0;
+    int ks = 0, ksp = 0;
+    bool is_source = false;
+    size_t raw_capacity_vals = 0;
+};
+
+}  // namespace ssym
+
+struct ssym_ctx {
+    int device = 0;
+    int metric = SSYM_METRIC_DTW;
+    int dtype = SSYM_DTYPE_F32;
+    int band = -1;
+    int squared = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    std::string err;
+    ssym_timings timings{};
+    int num_cus = 256;
+    // scratch (grown on demand, reused across calls)
+    ssym::DeviceBuf cmat;       // dtw filter costs f32 [n_pad][m_pad]  /  refcos sims f64
+    ssym::DeviceBuf tmin;       // per-target min key bits
+    ssym::DeviceBuf cand;       // candidate pairs (uint2) + counter + overflow flag
+    ssym::DeviceBuf cand_cost;  // exact f64 cost per candidate
+    ssym::DeviceBuf best;       // per-target best bits / idx
+    ssym::DeviceBuf dist;       // per-target distance (f64)
+    ssym::DeviceBuf part;       // refcos partial argmin
+    ssym::DeviceBuf out_idx, out_cost;  // staging for host outputs
+    hipEvent_t ev[8]{};
+};
+
+struct ssym_dict {
+    ssym::SegmentSet set;
+};
+
+struct ssym_queries {
+    ssym::SegmentSet set;
+};
+
+namespace ssym {
+
+#define SSYM_HIP_CHECK(ctx, call)                                                         \
+    do {                                                                                  \
+        hipError_t e__ = (call);                                                          \
+        if (e__ != hipSuccess) {                                                          \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);              \
+            return SSYM_E_HIP;                                                            \
+        }                                                                                 \
+    } while (0)
+
+int32_t ensure(ssym_ctx *ctx, DeviceBuf &b, size_t bytes);
+
+// pack.hip
+int32_t pack_segments(ssym_ctx *ctx, SegmentSet &set, const void *feats, bool feats_on_device,
+                      const uint64_t *frame_offsets, uint32_t n, uint32_t dim, bool is_source);
+int32_t append_segments(ssym_ctx *ctx, SegmentSet &set, const void *feats,
+                        const uint64_t *frame_offsets, uint32_t n);
+void free_segments(SegmentSet &set);
+
+// dtw_filter.hip
+bool filter_supported(const ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt);
+int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt,
+                          float *cmat /*[src.n_pad][tgt.n_pad]*/);
+
+// dtw_exact.hip
+// pairs == nullptr: every (s,t) pair, out[s*n_tgt + t]; else out[k] for pairs[k] with k < *count
+int32_t launch_dtw_exact(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt,
+                         const uint2 *pairs, const uint32_t *count_dev, uint32_t max_pairs,
+                         double *out);
+
+// select.hip
+struct SelectParams {
+    uint32_t n_src, n_tgt, n_src_pad, n_tgt_pad;
+    uint32_t cap;           // candidate capacity
+    float cell_err_scale;   // see select.hip
+};
+int32_t launch_dtw_select(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt,
+                          const float *cmat, const double *dist_dev, uint32_t cap);
+int32_t launch_dtw_final(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt,
+                         const double *dist_dev, uint32_t cap, uint32_t index_base,
+                         uint32_t *out_idx_dev, double *out_cost_dev);
+int32_t launch_dtw_final_allpairs(ssym_ctx *ctx, uint32_t n_src, uint32_t n_tgt,
+                                  const double *costs, const double *dist_dev,
+                                  uint32_t index_base, uint32_t *out_idx_dev,
+                                  double *out_cost_dev);
+int32_t launch_merge_shards(ssym_ctx *ctx, uint32_t n_shards, uint32_t n_targets,
+                            const double *costs, const uint32_t *idx, uint32_t *out_idx,
+                            double *out_cost);
+
+// refcos.hip
+int32_t launch_refcos_sims(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt,
+                           double *sims /*[n_src][n_tgt]*/);
+int32_t launch_refcos_argmin(ssym_ctx *ctx, uint32_t n_src, uint32_t n_tgt, const double *sims,
+                             const double *dist_dev, uint32_t index_base, uint32_t *out_idx_dev,
+                             double *out_cost_dev);
+
+}  // namespace ssym

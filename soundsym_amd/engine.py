@@ -1,0 +1,191 @@
+"""Array-level host interface over the C ABI: contexts, resident dictionaries / query sets, match.
+
+Everything here forwards to ``libsoundsym_amd.so``; no arithmetic of the matching path happens in
+Python.  Feature buffers may be numpy arrays (host) or torch CUDA tensors (device, handed over as
+raw pointers -- torch is only the owner of the memory).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _native as nat
+
+
+def pack_segments(segments: Sequence[np.ndarray], dim: int, dtype=np.float64):
+    """List of per-segment arrays (frames_i x dim, or flat) -> (flat values, frame offsets)."""
+    off = np.zeros(len(segments) + 1, dtype=np.uint64)
+    for i, s in enumerate(segments):
+        n = int(np.asarray(s).size)
+        if n % dim:
+            raise ValueError(f"segment {i}: {n} values is not a whole number of {dim}-dim frames")
+        off[i + 1] = off[i] + np.uint64(n // dim)
+    flat = np.zeros(int(off[-1]) * dim, dtype=dtype)
+    for i, s in enumerate(segments):
+        flat[int(off[i]) * dim:int(off[i + 1]) * dim] = np.asarray(s, dtype=dtype).reshape(-1)
+    return flat, off
+
+
+def _is_device_tensor(x) -> bool:
+    return hasattr(x, "data_ptr") and getattr(x, "is_cuda", False)
+
+
+class _Handle:
+    def __init__(self, engine: "Engine", ptr: int, n: int, dim: int, kind: str):
+        self.engine, self.ptr, self.n, self.dim, self.kind = engine, ptr, n, dim, kind
+
+    def close(self):
+        if self.ptr and self.engine.ctx:
+            L = nat.lib()
+            (L.ssym_dict_destroy if self.kind == "dict" else L.ssym_queries_destroy)(
+                self.engine.ctx, self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Engine:
+    """One ssym_ctx: one GPU, one stream, one metric / dtype configuration."""
+
+    def __init__(self, metric: str = "dtw", dtype: str = "f32", device: int = 0, band: int = -1,
+                 squared: bool = False, stream: Optional[int] = None):
+        self.metric, self.dtype = metric, dtype
+        self.np_dtype = {"f64": np.float64, "f32": np.float32}[dtype]
+        self.ctx = None
+        cfg = nat.Config(ctypes.sizeof(nat.Config), device,
+                         {"refcos": nat.METRIC_REFCOS, "dtw": nat.METRIC_DTW}[metric],
+                         {"f64": nat.DTYPE_F64, "f32": nat.DTYPE_F32}[dtype], band,
+                         1 if squared else 0, stream)
+        out = ctypes.c_void_p()
+        nat.check(nat.lib().ssym_ctx_create(ctypes.byref(cfg), ctypes.byref(out)), None)
+        self.ctx = out.value
+        self.device = device
+
+    def close(self):
+        if self.ctx:
+            nat.lib().ssym_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- resident segment sets ---------------------------------------------------------------
+    def _make(self, kind: str, feats, offsets, dim: int) -> _Handle:
+        L = nat.lib()
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = off.size - 1
+        if n < 0:
+            raise ValueError("offsets must hold n+1 entries")
+        out = ctypes.c_void_p()
+        if _is_device_tensor(feats):
+            want = {"f64": "torch.float64", "f32": "torch.float32"}[self.dtype]
+            if str(feats.dtype) != want or not feats.is_contiguous():
+                raise ValueError(f"device features must be contiguous {want}")
+            fn = L.ssym_dict_create_device if kind == "dict" else L.ssym_queries_create_device
+            fptr = feats.data_ptr()
+            keep = feats
+        else:
+            keep = np.ascontiguousarray(feats, dtype=self.np_dtype).reshape(-1)
+            fn = L.ssym_dict_create if kind == "dict" else L.ssym_queries_create
+            fptr = keep.ctypes.data
+        rc = fn(self.ctx, fptr, off.ctypes.data, n, dim, ctypes.byref(out))
+        del keep
+        nat.check(rc, self.ctx)
+        return _Handle(self, out.value, n, dim, kind)
+
+    def dictionary(self, feats, offsets, dim: int) -> _Handle:
+        return self._make("dict", feats, offsets, dim)
+
+    def queries(self, feats, offsets, dim: int) -> _Handle:
+        return self._make("queries", feats, offsets, dim)
+
+    def dictionary_append(self, d: _Handle, feats, offsets) -> None:
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        f = np.ascontiguousarray(feats, dtype=self.np_dtype).reshape(-1)
+        nat.check(nat.lib().ssym_dict_append(self.ctx, d.ptr, f.ctypes.data, off.ctypes.data,
+                                             off.size - 1), self.ctx)
+        d.n += off.size - 1
+
+    # -- the hot path ------------------------------------------------------------------------
+    def match(self, d: _Handle, q: _Handle, distance=None, index_base: int = 0,
+              force_exact: bool = False, out_idx=None, out_cost=None
+              ) -> Tuple[np.ndarray, np.ndarray]:
+        """argmin per target.  With torch CUDA tensors in out_idx (int32/uint32 storage, n
+        entries) and out_cost (float64) the results stay on the device."""
+        L = nat.lib()
+        m = q.n
+        dist_p = None
+        if distance is not None:
+            dist = np.ascontiguousarray(distance, dtype=np.float64)
+            if dist.size != m:
+                raise ValueError("distance must have one entry per target")
+            dist_p = dist.ctypes.data
+        flags = nat.DTW_FORCE_EXACT if force_exact else 0
+        if out_idx is not None and _is_device_tensor(out_idx):
+            flags |= nat.OUT_DEVICE
+            rc = L.ssym_match_queries(self.ctx, d.ptr, q.ptr, dist_p, index_base, out_idx.data_ptr(),
+                                      out_cost.data_ptr() if out_cost is not None else None, flags)
+            nat.check(rc, self.ctx)
+            return out_idx, out_cost
+        idx = np.zeros(m, dtype=np.uint32)
+        cost = np.zeros(m, dtype=np.float64)
+        rc = L.ssym_match_queries(self.ctx, d.ptr, q.ptr, dist_p, index_base, idx.ctypes.data,
+                                  cost.ctypes.data, flags)
+        nat.check(rc, self.ctx)
+        return idx, cost
+
+    def match_batch(self, d: _Handle, feats, offsets, distance=None):
+        """ssym_match_batch: pack host targets, match, release."""
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        f = np.ascontiguousarray(feats, dtype=self.np_dtype).reshape(-1)
+        m = off.size - 1
+        idx = np.zeros(m, dtype=np.uint32)
+        cost = np.zeros(m, dtype=np.float64)
+        dist_p = None
+        if distance is not None:
+            dist = np.ascontiguousarray(distance, dtype=np.float64)
+            dist_p = dist.ctypes.data
+        rc = nat.lib().ssym_match_batch(self.ctx, d.ptr, f.ctypes.data, off.ctypes.data, m, dist_p,
+                                        idx.ctypes.data, cost.ctypes.data)
+        nat.check(rc, self.ctx)
+        return idx, cost
+
+    def match_one(self, d: _Handle, feats, distance: float):
+        f = np.ascontiguousarray(feats, dtype=self.np_dtype).reshape(-1)
+        if f.size % d.dim:
+            raise ValueError("query is not a whole number of frames")
+        idx = ctypes.c_uint32(0)
+        cost = ctypes.c_double(0.0)
+        rc = nat.lib().ssym_match_one(self.ctx, d.ptr, f.ctypes.data, f.size // d.dim,
+                                      float(distance), ctypes.byref(idx), ctypes.byref(cost))
+        nat.check(rc, self.ctx)
+        return int(idx.value), float(cost.value)
+
+    def pair_matrix(self, d: _Handle, q: _Handle, exact: bool = False) -> np.ndarray:
+        out = np.zeros((d.n, q.n), dtype=np.float64)
+        nat.check(nat.lib().ssym_pair_matrix(self.ctx, d.ptr, q.ptr, 1 if exact else 0,
+                                             out.ctypes.data), self.ctx)
+        return out
+
+    def merge_shards(self, costs, idx, out_idx, out_cost) -> None:
+        """costs [G, M] f64, idx [G, M] 32-bit, outputs [M]: torch CUDA tensors on this GPU."""
+        g, m = costs.shape
+        nat.check(nat.lib().ssym_merge_shards(self.ctx, g, m, costs.data_ptr(), idx.data_ptr(),
+                                              out_idx.data_ptr(), out_cost.data_ptr()), self.ctx)
+
+    def timings(self) -> dict:
+        t = nat.Timings()
+        nat.check(nat.lib().ssym_get_timings(self.ctx, ctypes.byref(t)), self.ctx)
+        return t.as_dict()
+
+    def synchronize(self) -> None:
+        nat.check(nat.lib().ssym_ctx_synchronize(self.ctx), self.ctx)

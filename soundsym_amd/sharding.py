@@ -1,0 +1,57 @@
+"""Source-axis sharding across the GPUs of one node.
+
+Rank g of G holds dictionary segments [lo, hi) = shard_range(N, G, g) and ALL targets; it returns
+per target its best (cost, global index).  One all-gather of M x (8 + 4) bytes per rank (RCCL over
+xGMI when the tensors are on GPUs; gloo in the CPU rehearsal tests) gives every rank the G x M
+candidates; the final per-target pick -- smallest cost, lowest global index on equal cost, i.e.
+the reference's first-minimum rule (src/sound.rs:361-367) since shards are ordered by index --
+is the HIP kernel behind ssym_merge_shards.
+
+This module only moves bytes and computes ranges; it contains no arithmetic of the path and no
+CPU substitute for the merge kernel.
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+
+def shard_range(n: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous, ordered, balanced split of [0, n): the first n % world ranks get one extra."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError("bad world/rank")
+    q, r = divmod(n, world)
+    lo = rank * q + min(rank, r)
+    hi = lo + q + (1 if rank < r else 0)
+    return lo, hi
+
+
+def gather_candidates(cost, idx, group=None):
+    """all_gather every rank's per-target (cost f64 [M], global index int32-storage [M]).
+
+    Returns (costs [G, M], idx [G, M]) on the same device as the inputs.  With world size 1 (or
+    no process group) this is a reshape, no collective."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return cost.reshape(1, -1), idx.reshape(1, -1)
+    world = dist.get_world_size(group)
+    m = cost.numel()
+    costs = torch.empty(world * m, dtype=cost.dtype, device=cost.device)
+    idxs = torch.empty(world * m, dtype=idx.dtype, device=idx.device)
+    dist.all_gather_into_tensor(costs, cost.contiguous().reshape(-1), group=group)
+    dist.all_gather_into_tensor(idxs, idx.contiguous().reshape(-1), group=group)
+    return costs.view(world, m), idxs.view(world, m)
+
+
+def merge_shards(engine, costs, idx):
+    """Final G-way reduce on the GPU (ssym_merge_shards).  Inputs must be CUDA tensors."""
+    import torch
+
+    if not costs.is_cuda or not idx.is_cuda:
+        raise RuntimeError("merge_shards runs the HIP kernel: tensors must be on the GPU")
+    g, m = costs.shape
+    out_idx = torch.empty(m, dtype=idx.dtype, device=idx.device)
+    out_cost = torch.empty(m, dtype=torch.float64, device=costs.device)
+    engine.merge_shards(costs.contiguous(), idx.contiguous(), out_idx, out_cost)
+    return out_idx, out_cost

@@ -1,0 +1,119 @@
+"""The oracle against hand-derived known answers and against its own second restatement.
+
+The reference's tests hold no golden vector with numbers for this path:
+these KATs are derived by hand from the reference source text and are what pins the oracle.
+"""
+import json
+import math
+import os
+from fractions import Fraction
+
+import numpy as np
+import pytest
+
+import oracle as oracle_pkg
+from oracle.oracle import pack_segments
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def kat():
+    with open(os.path.join(GOLD, "refcos_kat.json")) as f:
+        return json.load(f)
+
+
+def test_cosine_sim_kats(oracle, kat):
+    for case in kat["cosine_sim"]:
+        want = float(Fraction(case["num"], case["den"]))
+        assert oracle.cosine_sim(case["me"], case["you"]) == want, case
+        assert oracle_pkg.np_cosine_sim(case["me"], case["you"]) == want, case
+
+
+def test_reference_test_angular_distance_arithmetic(oracle, kat):
+    # src/sound.rs:611-615: cosine_sim(m, m) must exceed 1 (squared norms) for the clamp to give 0.0
+    a = kat["angular"]
+    got = oracle.cosine_sim(a["m"], a["m"])
+    assert got > 1.0
+    assert abs(got - a["approx"]) <= a["rtol"] * a["approx"]
+    clamped = 1.0 if (got > 1.0 or got < -1.0) else got      # src/sound.rs:63-67
+    assert math.acos(clamped) / math.pi == 0.0
+
+
+def test_at_distance_kats(oracle, kat):
+    for case in kat["at_distance"]:
+        dim = 1 if len(case["dict"][0]) == 1 else 2
+        flat, off = pack_segments([np.array(s, dtype=np.float64) for s in case["dict"]], dim)
+        idx, val = oracle.at_distance(flat, off, dim, case["distance"], np.array(case["you"], dtype=np.float64))
+        assert idx == case["idx"], case
+        if "val" in case:
+            assert val == case["val"], case
+        idx2, val2 = oracle_pkg.np_at_distance([np.array(s, dtype=np.float64) for s in case["dict"]],
+                                               case["distance"], np.array(case["you"], dtype=np.float64))
+        assert (idx2, val2) == (idx, val)
+
+
+def test_empty_dictionary_is_an_error(oracle):
+    # the reference panics at src/sound.rs:369
+    idx, _ = oracle.at_distance(np.zeros(0), np.zeros(1, dtype=np.uint64), 12, 1.0, np.ones(12))
+    assert idx == -1
+    with pytest.raises(IndexError):
+        oracle_pkg.np_at_distance([], 1.0, np.ones(12))
+
+
+def test_dtw_kats(oracle, kat):
+    for case in kat["dtw"]:
+        a, b = np.array(case["a"], dtype=np.float64), np.array(case["b"], dtype=np.float64)
+        want = float("inf") if case["cost"] == "inf" else case["cost"]
+        sq = bool(case.get("squared", False))
+        assert oracle.dtw(a, b, a.shape[1], case["band"], sq) == want, case
+        assert oracle_pkg.np_dtw(a, b, case["band"], sq) == want, case
+
+
+def test_c_oracle_equals_python_restatement_refcos(oracle):
+    rng = np.random.default_rng(7)
+    for _ in range(50):
+        n1, n2 = rng.integers(0, 60, size=2)
+        x, y = rng.normal(size=n1), rng.normal(size=n2)
+        a, b = oracle.cosine_sim(x, y), oracle_pkg.np_cosine_sim(x, y)
+        assert (a == b) or (math.isnan(a) and math.isnan(b))
+
+
+def test_c_oracle_equals_python_restatement_dtw(oracle):
+    rng = np.random.default_rng(8)
+    for band in (-1, 0, 2, 5):
+        for _ in range(6):
+            fa, fb = rng.integers(1, 12, size=2)
+            a, b = rng.normal(size=(fa, 5)), rng.normal(size=(fb, 5))
+            assert oracle.dtw(a, b, 5, band) == oracle_pkg.np_dtw(a, b, band)
+    assert oracle.dtw(np.zeros((0, 3)), np.ones((2, 3)), 3) == float("inf")
+
+
+def test_dot_order_is_the_eight_accumulator_order(oracle):
+    # a vector where the summation order changes the f64 result: the oracle must follow
+    # rulinalg's order, not a left-to-right sum
+    x = np.array([1e16, 1.0, -1e16, 1.0] * 5, dtype=np.float64)
+    y = np.ones_like(x)
+    from oracle.oracle import _np_dot
+    assert oracle.dot(x, y) == _np_dot(x, y, x.size)
+    assert oracle.dot(x, y) != float(np.sum(x))  # naive order differs here
+
+
+def test_golden_fixtures_match_oracle(oracle):
+    g = np.load(os.path.join(GOLD, "refcos_ragged.npz"))
+    idx, val = oracle.refcos_match_all(g["src"], g["src_off"], g["tgt"], g["tgt_off"], 12)
+    assert np.array_equal(idx, g["idx"]) and np.array_equal(val, g["val"])
+    assert g["idx"][3] == 7 or g["val"][3] <= abs(oracle.cosine_sim(
+        g["src"][int(g["src_off"][7]) * 12:int(g["src_off"][8]) * 12],
+        g["tgt"][int(g["tgt_off"][3]) * 12:int(g["tgt_off"][4]) * 12]) - 1.0)
+    d = np.load(os.path.join(GOLD, "dtw_grid_32x32x16x13.npz"))
+    # planted neighbours are recovered: expected indices known independently of any DTW code
+    assert np.array_equal(d["idx"], d["planted"])
+    assert np.array_equal(d["idx_sq"], d["planted"])
+
+
+def test_length_fit(oracle):
+    m = np.arange(1, 6, dtype=np.float64)
+    assert np.array_equal(oracle.length_fit(m, 8), [1, 2, 3, 4, 5, 0, 0, 0])   # src/sound.rs:457-459
+    assert np.array_equal(oracle.length_fit(m, 3), [1, 2, 3])                  # src/sound.rs:460-462
+    assert np.array_equal(oracle.length_fit(m, 5), m)                          # src/sound.rs:463-464
