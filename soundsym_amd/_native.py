@@ -90,6 +90,25 @@ def build(force: bool = False) -> str:
 
 
 _lib: Optional[ctypes.CDLL] = None
+_hip: Optional[ctypes.CDLL] = None
+
+
+def hip_runtime_path() -> str:
+    """The ONE HIP runtime this process will use.  libsoundsym_amd.so carries no DT_NEEDED on
+    libamdhip64 (see csrc/Makefile): a PyTorch wheel bundles its own runtime, and two runtimes in
+    one process cannot both open the GPU.  When torch is installed its copy is used whether or
+    not torch has been imported yet, so that import order never matters; otherwise ROCm's."""
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec is not None and spec.origin:
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            return cand
+    for cand in (os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "libamdhip64.so"),
+                 "/opt/rocm/lib/libamdhip64.so"):
+        if os.path.exists(cand):
+            return cand
+    raise ImportError("no libamdhip64.so found (torch/lib or $ROCM_PATH/lib)")
 
 
 def lib() -> ctypes.CDLL:
@@ -101,6 +120,8 @@ def lib() -> ctypes.CDLL:
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` or `make -C soundsym_amd/csrc` (there is no CPU fallback)")
+    global _hip
+    _hip = ctypes.CDLL(hip_runtime_path(), mode=ctypes.RTLD_GLOBAL)
     L = ctypes.CDLL(LIB_PATH)
     vp, u32, i32, u64, f64 = (ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int32, ctypes.c_uint64,
                               ctypes.c_double)

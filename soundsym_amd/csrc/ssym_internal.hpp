@@ -24,7 +24,9 @@ namespace ssym {
 constexpr int kRowsPerTile = 16;   // frames of one source per 32x32 MFMA tile
 constexpr int kMaxTiles = 8;       // register-resident DP column: up to 128 source frames
 
-inline int filter_ks(int dim) { return (dim + 1 + 1) / 2; }
+// the filter kernel is instantiated for KS = 7 (dim <= 13, zero-padded below that); larger dims
+// get their natural KS but run on the exact kernel (filter_supported)
+inline int filter_ks(int dim) { return dim <= 13 ? 7 : (dim + 1 + 1) / 2; }
 // source rows are padded to a tile count the filter kernel is instantiated for
 inline int filter_rows_pad(int max_frames)
 {

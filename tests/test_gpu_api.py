@@ -1,0 +1,71 @@
+"""The mirror of the reference interface, read like the reference's own tests (src/sound.rs:534-632)."""
+import numpy as np
+import pytest
+
+from soundsym_amd import Engine, Sound, SoundDictionary, SoundSequence, synth
+from soundsym_amd.api import HOP, NCOEFFS
+
+pytestmark = pytest.mark.gpu
+
+
+def _parent(n_frames, seed):
+    st = synth.Stream(seed)
+    mfccs = st.normal(n_frames * NCOEFFS) * 0.1
+    samples = st.normal(n_frames * HOP) * 0.1
+    return Sound(samples, 44100.0, mfccs)
+
+
+def test_sound_should_match_itself(oracle):
+    # src/sound.rs:600-609, with a dictionary cut from one parent sound by segment lengths
+    parent = _parent(64, 0x5EED0400)
+    d = SoundDictionary.from_segments(parent, [HOP * k for k in (3, 5, 2, 7, 4, 6, 3, 8, 5, 4)])
+    sound = d.sounds[4]
+    got = d.match_sound(sound)
+    # self-match is not guaranteed by the arithmetic (squared norms); the oracle decides
+    from oracle.oracle import pack_segments
+    flat, off = pack_segments([s.mfccs() for s in d.sounds], NCOEFFS)
+    want, _ = oracle.at_distance(flat, off, NCOEFFS, 1.0, sound.mfccs())
+    assert got is d.sounds[want]
+
+
+def test_clone_from_dictionary_and_morph_to(oracle):
+    from oracle.oracle import pack_segments
+    src = _parent(80, 0x5EED0401)
+    tgt = _parent(60, 0x5EED0402)
+    d = SoundDictionary.from_segments(src, [HOP * k for k in (4, 6, 3, 9, 5, 7, 2, 8, 6, 5, 4, 3)])
+    td = SoundDictionary.from_segments(tgt, [HOP * k for k in (5, 5, 7, 3, 6, 4, 8)])
+    seq = SoundSequence.new(td.sounds)
+    out = seq.clone_from_dictionary(d)
+    flat, off = pack_segments([s.mfccs() for s in d.sounds], NCOEFFS)
+    tflat, toff = pack_segments([s.mfccs() for s in td.sounds], NCOEFFS)
+    want, _ = oracle.refcos_match_all(flat, off, tflat, toff, NCOEFFS)
+    assert len(out.sounds()) == len(td.sounds)
+    for o, t, w in zip(out.sounds(), td.sounds, want):
+        assert o.samples().size == t.samples().size                      # src/sound.rs:456-465
+        assert np.array_equal(o.samples(), oracle.length_fit(d.sounds[w].samples(), t.samples().size))
+    assert out.to_sound().samples().size == sum(t.samples().size for t in td.sounds)
+    dist = np.linspace(0.0, 0.05, len(td.sounds))
+    morphed = seq.morph_to(dist, d)
+    want_m, _ = oracle.refcos_match_all(flat, off, tflat, toff, NCOEFFS, dist)
+    assert [m is d.sounds[w] for m, w in zip(morphed.sounds(), want_m)] == [True] * len(want_m)
+    chain = SoundSequence.from_distances([0.01, 0.02, 0.0], d.sounds[0], d)
+    cur = d.sounds[0]
+    for step, dd in zip(chain.sounds()[1:], [0.01, 0.02, 0.0]):
+        w, _ = oracle.at_distance(flat, off, NCOEFFS, dd, cur.mfccs())
+        assert step is d.sounds[w]
+        cur = step
+
+
+def test_dictionary_on_the_dtw_engine(oracle):
+    from oracle.oracle import pack_segments
+    e = Engine(metric="dtw", dtype="f64")
+    src = _parent(70, 0x5EED0403)
+    d = SoundDictionary.from_segments(src, [HOP * k for k in (4, 6, 3, 9, 5, 7, 2, 8, 6, 5)], engine=e)
+    q = d.sounds[6]
+    assert d.match_sound(q) is d.sounds[6]          # DTW of a segment with itself is 0
+    flat, off = pack_segments([s.mfccs() for s in d.sounds], NCOEFFS)
+    probe = _parent(6, 0x5EED0404)
+    pf, po = pack_segments([probe.mfccs()], NCOEFFS)
+    want, _ = oracle.dtw_match_all(flat, off, pf, po, NCOEFFS)
+    assert d.match_sound(probe) is d.sounds[int(want[0])]
+    e.close()

@@ -1,0 +1,334 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the golden fixtures.
+
+Bars: refcos -- similarities, winning values and indices BIT-EXACT (f64, same operation order);
+dtw -- indices identical, costs within 1e-5 relative (north-star tolerance; the exact kernel is
+expected to be bit-exact and is checked at 1e-12), the f32 MFMA filter within its derived bound.
+"""
+import json
+import math
+import os
+from fractions import Fraction
+
+import numpy as np
+import pytest
+
+from soundsym_amd import Engine, EmptyDictionaryError, SsymError, synth
+from soundsym_amd.engine import pack_segments
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+DTW_RTOL = 1e-5      # BASELINE.json north_star: "DTW costs within 1e-5 relative f32"
+EXACT_RTOL = 1e-12   # exact f64 kernel vs f64 oracle (same operation order)
+
+
+@pytest.fixture(scope="module")
+def refcos():
+    e = Engine(metric="refcos", dtype="f64")
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def dtw():
+    e = Engine(metric="dtw", dtype="f32")
+    yield e
+    e.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# refcos
+# ---------------------------------------------------------------------------------------------
+def test_refcos_kats(refcos):
+    kat = json.load(open(os.path.join(GOLD, "refcos_kat.json")))
+    for case in kat["cosine_sim"]:
+        d = refcos.dictionary(np.array(case["me"], dtype=np.float64), [0, len(case["me"])], 1)
+        q = refcos.queries(np.array(case["you"], dtype=np.float64), [0, len(case["you"])], 1)
+        sim = refcos.pair_matrix(d, q)[0, 0]
+        assert sim == float(Fraction(case["num"], case["den"])), case
+    for case in kat["at_distance"]:
+        dim = 1 if len(case["dict"][0]) == 1 else 2
+        flat, off = pack_segments([np.array(s, dtype=np.float64) for s in case["dict"]], dim)
+        d = refcos.dictionary(flat, off, dim)
+        you = np.array(case["you"], dtype=np.float64)
+        idx, val = refcos.match_one(d, you, case["distance"])
+        assert idx == case["idx"], case
+        if "val" in case:
+            assert val == case["val"], case
+
+
+def test_refcos_golden_ragged_bit_exact(refcos, oracle):
+    g = np.load(os.path.join(GOLD, "refcos_ragged.npz"))
+    d = refcos.dictionary(g["src"], g["src_off"], 12)
+    q = refcos.queries(g["tgt"], g["tgt_off"], 12)
+    sims = refcos.pair_matrix(d, q)
+    assert np.array_equal(sims, g["sims"])                 # bit for bit, NaN-free fixture
+    idx, val = refcos.match(d, q)
+    assert np.array_equal(idx, g["idx"]) and np.array_equal(val, g["val"])
+    idx_d, val_d = refcos.match(d, q, distance=g["dist"])  # morph_to: per-target distance
+    assert np.array_equal(idx_d, g["idx_d"]) and np.array_equal(val_d, g["val_d"])
+    # ssym_match_batch and ssym_match_one are the same path
+    idx_b, val_b = refcos.match_batch(d, g["tgt"], g["tgt_off"])
+    assert np.array_equal(idx_b, g["idx"]) and np.array_equal(val_b, g["val"])
+    t0 = g["tgt"][int(g["tgt_off"][5]) * 12:int(g["tgt_off"][6]) * 12]
+    assert refcos.match_one(d, t0, 1.0) == (int(g["idx"][5]), float(g["val"][5]))
+
+
+@pytest.mark.parametrize("n,m,fmin,fmax,dim", [(70, 45, 1, 30, 12), (33, 65, 5, 9, 13), (8, 8, 40, 41, 40)])
+def test_refcos_random_ragged_vs_oracle(refcos, oracle, n, m, fmin, fmax, dim):
+    src, tgt = synth.make_ragged(n, m, fmin, fmax, dim, 0x5EED0200 + n)
+    sf, so = pack_segments([s.astype(np.float64) * 0.03 for s in src], dim)
+    tf, to = pack_segments([t.astype(np.float64) * 0.03 for t in tgt], dim)
+    want_idx, want_val = oracle.refcos_match_all(sf, so, tf, to, dim)
+    d, q = refcos.dictionary(sf, so, dim), refcos.queries(tf, to, dim)
+    idx, val = refcos.match(d, q)
+    assert np.array_equal(idx, want_idx) and np.array_equal(val, want_val)
+    sims = refcos.pair_matrix(d, q)
+    for s in (0, n // 2, n - 1):
+        for t in (0, m - 1):
+            assert sims[s, t] == oracle.cosine_sim(src[s].astype(np.float64) * 0.03,
+                                                   tgt[t].astype(np.float64) * 0.03)
+
+
+def test_refcos_f32_inputs_are_widened_exactly(oracle):
+    e = Engine(metric="refcos", dtype="f32")
+    src, tgt = synth.make_ragged(20, 10, 2, 12, 12, 0x5EED0210)
+    sf, so = pack_segments(src, 12, np.float32)
+    tf, to = pack_segments(tgt, 12, np.float32)
+    idx, val = e.match(e.dictionary(sf, so, 12), e.queries(tf, to, 12))
+    want_idx, want_val = oracle.refcos_match_all(sf.astype(np.float64), so, tf.astype(np.float64), to, 12)
+    assert np.array_equal(idx, want_idx) and np.array_equal(val, want_val)
+    e.close()
+
+
+def test_refcos_edge_cases(refcos, oracle):
+    # empty dictionary: the reference panics (src/sound.rs:369), the ABI reports it
+    d0 = refcos.dictionary(np.zeros(0), [0], 12)
+    q = refcos.queries(np.ones(12), [0, 1], 12)
+    with pytest.raises(EmptyDictionaryError):
+        refcos.match(d0, q)
+    # zero-length target and zero-length dictionary entries: NaN never wins -> (0, 2.0)
+    flat, off = pack_segments([np.ones(12), np.zeros(0), np.full(24, 2.0)], 12)
+    d = refcos.dictionary(flat, off, 12)
+    tflat, toff = pack_segments([np.zeros(0), np.ones(12)], 12)
+    idx, val = refcos.match(d, refcos.queries(tflat, toff, 12))
+    want_idx, want_val = oracle.refcos_match_all(flat, off, tflat, toff, 12)
+    assert np.array_equal(idx, want_idx) and np.array_equal(val, want_val)
+    assert idx[0] == 0 and val[0] == 2.0
+    # no targets: nothing to do
+    idx, val = refcos.match(d, refcos.queries(np.zeros(0), [0], 12))
+    assert idx.size == 0
+    # append == add_segments: indices continue
+    refcos.dictionary_append(d, np.full(12, 0.5), [0, 1])
+    assert d.n == 4
+    idx, _ = refcos.match(d, refcos.queries(np.full(12, 0.5), [0, 1], 12))
+    f2, o2 = pack_segments([np.ones(12), np.zeros(0), np.full(24, 2.0), np.full(12, 0.5)], 12)
+    assert idx[0] == oracle.refcos_match_all(f2, o2, np.full(12, 0.5), np.array([0, 1], dtype=np.uint64), 12)[0][0]
+    with pytest.raises(SsymError):
+        refcos.match(d, refcos.queries(np.ones(13), [0, 1], 13))   # dim mismatch
+
+
+# ---------------------------------------------------------------------------------------------
+# dtw
+# ---------------------------------------------------------------------------------------------
+def _filter_bound(src, tgt, fa, fb):
+    """|C~ - C| bound of the f32 filter as derived in soundsym_amd/csrc/select.hip."""
+    u = 2.0 ** -24
+    na = max(float((s.astype(np.float64) ** 2).sum(-1).max()) for s in src if s.size)
+    nb = max(float((t.astype(np.float64) ** 2).sum(-1).max()) for t in tgt if t.size)
+    cell = math.sqrt(34 * u * (na + nb)) + 3 * u * (math.sqrt(na) + math.sqrt(nb))
+    return (fa + fb - 1) * cell
+
+
+def test_dtw_kats(dtw):
+    kat = json.load(open(os.path.join(GOLD, "refcos_kat.json")))
+    for case in kat["dtw"]:
+        a, b = np.array(case["a"], dtype=np.float32), np.array(case["b"], dtype=np.float32)
+        e = Engine(metric="dtw", dtype="f32", band=case["band"], squared=bool(case.get("squared", False)))
+        d = e.dictionary(a.reshape(-1), [0, a.shape[0]], a.shape[1])
+        q = e.queries(b.reshape(-1), [0, b.shape[0]], a.shape[1])
+        idx, cost = e.match(d, q)
+        want = float("inf") if case["cost"] == "inf" else case["cost"]
+        assert idx[0] == 0 and cost[0] == want, case
+        e.close()
+
+
+def test_dtw_golden_grid(dtw, oracle):
+    g = np.load(os.path.join(GOLD, "dtw_grid_32x32x16x13.npz"))
+    n, f, dim = g["sources"].shape
+    so = np.arange(n + 1, dtype=np.uint64) * f
+    d = dtw.dictionary(g["sources"].reshape(-1), so, dim)
+    q = dtw.queries(g["targets"].reshape(-1), so, dim)
+    idx, cost = dtw.match(d, q)
+    assert dtw.timings()["used_filter"] == 1
+    assert np.array_equal(idx, g["idx"]) and np.array_equal(idx, g["planted"])
+    assert np.allclose(cost, g["cost"], rtol=DTW_RTOL, atol=0)
+    assert np.allclose(cost, g["cost"], rtol=EXACT_RTOL, atol=0)     # refined in f64
+    # the f32 MFMA filter's whole cost matrix against the oracle's, within the derived bound
+    filt = dtw.pair_matrix(d, q, exact=False)
+    bound = _filter_bound(list(g["sources"]), list(g["targets"]), f, f)
+    err = np.abs(filt - g["matrix"])
+    assert (err <= bound + 1e-5 * g["matrix"]).all(), (err.max(), bound)
+    # non-planted pairs are far from cancellation: there the filter is f32-accurate already
+    off_diag = g["matrix"] > 4 * g["cost"].max()
+    assert (err[off_diag] <= 2e-5 * g["matrix"][off_diag]).all()
+    # exact kernel on every pair == oracle matrix
+    exact = dtw.pair_matrix(d, q, exact=True)
+    assert np.allclose(exact, g["matrix"], rtol=EXACT_RTOL, atol=0)
+    # filter bypassed: same answers
+    idx2, cost2 = dtw.match(d, q, force_exact=True)
+    assert np.array_equal(idx2, idx) and np.array_equal(cost2, cost)
+
+
+def test_dtw_golden_band_and_squared(oracle):
+    g = np.load(os.path.join(GOLD, "dtw_grid_32x32x16x13.npz"))
+    n, f, dim = g["sources"].shape
+    so = np.arange(n + 1, dtype=np.uint64) * f
+    eb = Engine(metric="dtw", dtype="f32", band=3)
+    idx, cost = eb.match(eb.dictionary(g["sources"].reshape(-1), so, dim),
+                         eb.queries(g["targets"].reshape(-1), so, dim))
+    assert np.array_equal(idx, g["idx_band3"]) and np.allclose(cost, g["cost_band3"], rtol=EXACT_RTOL)
+    eb.close()
+    es = Engine(metric="dtw", dtype="f32", squared=True)
+    idx, cost = es.match(es.dictionary(g["sources"].reshape(-1), so, dim),
+                         es.queries(g["targets"].reshape(-1), so, dim))
+    assert es.timings()["used_filter"] == 1
+    assert np.array_equal(idx, g["idx_sq"]) and np.allclose(cost, g["cost_sq"], rtol=EXACT_RTOL)
+    es.close()
+
+
+def test_dtw_golden_ragged(dtw):
+    g = np.load(os.path.join(GOLD, "dtw_ragged.npz"))
+    d = dtw.dictionary(g["src"], g["src_off"], 13)
+    q = dtw.queries(g["tgt"], g["tgt_off"], 13)
+    idx, cost = dtw.match(d, q)
+    assert dtw.timings()["used_filter"] == 1
+    assert np.array_equal(idx, g["idx"]) and np.allclose(cost, g["cost"], rtol=EXACT_RTOL, atol=0)
+    filt = dtw.pair_matrix(d, q, exact=False)
+    fa = int(np.diff(g["src_off"]).max())
+    fb = int(np.diff(g["tgt_off"]).max())
+    src = [g["src"][int(a) * 13:int(b) * 13].reshape(-1, 13) for a, b in zip(g["src_off"][:-1], g["src_off"][1:])]
+    tgt = [g["tgt"][int(a) * 13:int(b) * 13].reshape(-1, 13) for a, b in zip(g["tgt_off"][:-1], g["tgt_off"][1:])]
+    bound = _filter_bound(src, tgt, fa, fb)
+    assert (np.abs(filt - g["matrix"]) <= bound + 1e-5 * g["matrix"]).all()
+
+
+@pytest.mark.parametrize("n,m,f,dim", [(40, 70, 64, 13), (17, 33, 100, 12), (9, 5, 128, 13), (64, 32, 7, 5)])
+def test_dtw_grid_vs_oracle(dtw, oracle, n, m, f, dim):
+    g = synth.make_grid(n, m, f, dim, 0x5EED0300 + f)
+    sf, so = g.flat("sources")
+    tf, to = g.flat("targets")
+    want_idx, want_cost = oracle.dtw_match_all(sf.astype(np.float64), so, tf.astype(np.float64), to, dim, nthreads=8)
+    idx, cost = dtw.match(dtw.dictionary(sf, so, dim), dtw.queries(tf, to, dim))
+    assert dtw.timings()["used_filter"] == 1
+    assert np.array_equal(idx, want_idx)
+    assert np.allclose(cost, want_cost, rtol=DTW_RTOL, atol=0)
+    assert np.allclose(cost, want_cost, rtol=EXACT_RTOL, atol=0)
+    if m <= n:
+        assert np.array_equal(idx, g.planted)
+
+
+def test_dtw_ties_take_the_lowest_index(dtw, oracle):
+    g = synth.make_grid(24, 8, 20, 13, 0x5EED0310)
+    g.sources[19] = g.sources[3]                   # exact duplicates among the sources
+    g.sources[11] = g.sources[3]
+    g.targets[0] = g.sources[3]
+    g.planted[0] = 3
+    sf, so = g.flat("sources")
+    tf, to = g.flat("targets")
+    idx, cost = dtw.match(dtw.dictionary(sf, so, 13), dtw.queries(tf, to, 13))
+    want_idx, want_cost = oracle.dtw_match_all(sf.astype(np.float64), so, tf.astype(np.float64), to, 13)
+    assert np.array_equal(idx, want_idx) and idx[0] == 3 and cost[0] == 0.0
+    assert np.allclose(cost, want_cost, rtol=EXACT_RTOL, atol=0)
+
+
+def test_dtw_long_segments_and_wide_frames_use_the_exact_kernel(oracle):
+    # > 128 source frames (two 64-row chunks + boundary hand-off) and dim > 13
+    e = Engine(metric="dtw", dtype="f32")
+    g = synth.make_grid(6, 5, 150, 13, 0x5EED0320)
+    sf, so = g.flat("sources")
+    tf, to = g.flat("targets")
+    idx, cost = e.match(e.dictionary(sf, so, 13), e.queries(tf, to, 13))
+    assert e.timings()["used_filter"] == 0
+    want_idx, want_cost = oracle.dtw_match_all(sf.astype(np.float64), so, tf.astype(np.float64), to, 13)
+    assert np.array_equal(idx, want_idx) and np.allclose(cost, want_cost, rtol=EXACT_RTOL, atol=0)
+    g = synth.make_grid(6, 5, 40, 40, 0x5EED0321)
+    sf, so = g.flat("sources")
+    tf, to = g.flat("targets")
+    eb = Engine(metric="dtw", dtype="f32", band=8)
+    idx, cost = eb.match(eb.dictionary(sf, so, 40), eb.queries(tf, to, 40))
+    want_idx, want_cost = oracle.dtw_match_all(sf.astype(np.float64), so, tf.astype(np.float64), to, 40, band=8)
+    assert np.array_equal(idx, want_idx) and np.allclose(cost, want_cost, rtol=EXACT_RTOL, atol=0)
+    e.close()
+    eb.close()
+
+
+def test_dtw_f64_inputs_and_distance(oracle):
+    e = Engine(metric="dtw", dtype="f64")
+    src, tgt = synth.make_ragged(30, 14, 4, 33, 13, 0x5EED0330)
+    rng = np.random.default_rng(3)
+    src = [s.astype(np.float64) + 1e-9 * rng.normal(size=s.shape) for s in src]   # not f32-representable
+    tgt = [t.astype(np.float64) for t in tgt]
+    sf, so = pack_segments(src, 13)
+    tf, to = pack_segments(tgt, 13)
+    d, q = e.dictionary(sf, so, 13), e.queries(tf, to, 13)
+    idx, cost = e.match(d, q)
+    assert e.timings()["used_filter"] == 1
+    want_idx, want_cost, mat = oracle.dtw_match_all(sf, so, tf, to, 13, want_matrix=True)
+    assert np.array_equal(idx, want_idx) and np.allclose(cost, want_cost, rtol=EXACT_RTOL, atol=0)
+    # per-target distance (morph_to semantics on the dtw metric): argmin |cost - distance|
+    dist = np.median(mat, axis=0)
+    idx_d, cost_d = e.match(d, q, distance=dist)
+    want = np.abs(mat - dist[None, :]).argmin(axis=0)
+    assert np.array_equal(idx_d, want)
+    assert np.allclose(cost_d, mat[want, np.arange(mat.shape[1])], rtol=EXACT_RTOL, atol=0)
+    e.close()
+
+
+def test_dtw_edge_cases(dtw, oracle):
+    d0 = dtw.dictionary(np.zeros(0, dtype=np.float32), [0], 13)
+    q = dtw.queries(np.ones(13, dtype=np.float32), [0, 1], 13)
+    with pytest.raises(EmptyDictionaryError):
+        dtw.match(d0, q)
+    # empty segments on either side cost +inf; all-inf keeps the fold start (0, +inf)
+    flat, off = pack_segments([np.zeros(0), np.ones(26)], 13, np.float32)
+    d = dtw.dictionary(flat, off, 13)
+    tflat, toff = pack_segments([np.zeros(0), np.ones(13), np.zeros(39)], 13, np.float32)
+    idx, cost = dtw.match(d, dtw.queries(tflat, toff, 13))
+    want_idx, want_cost = oracle.dtw_match_all(flat.astype(np.float64), off, tflat.astype(np.float64), toff, 13)
+    assert np.array_equal(idx, want_idx) and np.array_equal(cost, want_cost)
+    assert idx[0] == 0 and cost[0] == float("inf") and idx[1] == 1
+    # single frames, single pair
+    idx, cost = dtw.match_batch(d, np.full(13, 3.0, dtype=np.float32), [0, 1])
+    assert idx[0] == 1 and abs(cost[0] - 2 * math.sqrt(13 * 4.0)) < 1e-12
+    # index_base shifts the returned indices (source shard of a multi-GPU run)
+    idx_b, _ = dtw.match(d, dtw.queries(tflat, toff, 13), index_base=1000)
+    assert np.array_equal(idx_b, want_idx + 1000)
+
+
+def test_merge_shards_kernel(dtw):
+    import torch
+    from soundsym_amd import sharding
+    rng = np.random.default_rng(11)
+    g, m = 8, 1000
+    costs = rng.integers(0, 5, size=(g, m)).astype(np.float64)       # many exact ties
+    costs[rng.random((g, m)) < 0.05] = np.inf
+    idx = (np.arange(g)[:, None] * 100000 + rng.integers(0, 100000, size=(g, m))).astype(np.int32)
+    oi, oc = sharding.merge_shards(dtw, torch.from_numpy(costs).cuda(), torch.from_numpy(idx).cuda())
+    order = np.lexsort((idx, costs), axis=0)[0]
+    assert np.array_equal(oi.cpu().numpy(), idx[order, np.arange(m)])
+    assert np.array_equal(oc.cpu().numpy(), costs[order, np.arange(m)])
+
+
+def test_device_resident_inputs_and_outputs(dtw, oracle):
+    import torch
+    g = synth.make_grid(48, 40, 32, 13, 0x5EED0340)
+    sf, so = g.flat("sources")
+    tf, to = g.flat("targets")
+    d = dtw.dictionary(torch.from_numpy(sf).cuda(), so, 13)
+    q = dtw.queries(torch.from_numpy(tf).cuda(), to, 13)
+    out_idx = torch.empty(40, dtype=torch.int32, device="cuda")
+    out_cost = torch.empty(40, dtype=torch.float64, device="cuda")
+    dtw.match(d, q, out_idx=out_idx, out_cost=out_cost)
+    want_idx, want_cost = oracle.dtw_match_all(sf.astype(np.float64), so, tf.astype(np.float64), to, 13)
+    assert np.array_equal(out_idx.cpu().numpy(), want_idx)
+    assert np.allclose(out_cost.cpu().numpy(), want_cost, rtol=EXACT_RTOL, atol=0)
