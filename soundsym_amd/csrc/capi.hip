@@ -95,7 +95,7 @@ int32_t ssym_ctx_destroy(ssym_ctx *ctx)
         return SSYM_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    DeviceBuf *bufs[] = {&ctx->cmat, &ctx->tmin, &ctx->cand, &ctx->cand_cost, &ctx->best,
+    DeviceBuf *bufs[] = {&ctx->handoff, &ctx->cmat, &ctx->tmin, &ctx->cand, &ctx->cand_cost, &ctx->best,
                          &ctx->dist, &ctx->part, &ctx->out_idx, &ctx->out_cost};
     for (DeviceBuf *b : bufs)
         if (b->ptr)

@@ -1,241 +1,185 @@
-// dtw_filter.hip -- all-pairs DTW cost fill on the f32 MFMA pipe (gfx950), one pair per lane.
+// dtw_filter.hip -- all-pairs DTW cost fill on the f16 matrix pipe (gfx950), one pair per lane.
 //
 // Role on the path: replaces the N x M evaluations of the reference's inner loop
 // (SoundDictionary::at_distance, src/sound.rs:352-359, called once per target by
 // clone_from_dictionary, src/sound.rs:453-454) for the dtw metric.  Output is the f32 cost of every
 // (source, target) pair; select.hip picks candidates from it and dtw_exact.hip re-scores them.
+// The kernel itself is in dtw_filter_kernel.hpp; this file builds its operand records and
+// dispatches the (tiles per wave, row blocks) instantiation for the dictionary's longest segment.
 //
-// Mapping (DESIGN.md "dtw filter kernel"):
-//   * one wave = 2 sources x 32 targets = 64 pairs, ONE PAIR PER LANE;
-//   * v_mfma_f32_32x32x2_f32: the 32 A-rows are 16 consecutive frames of source 0 interleaved (in
-//     groups of four) with 16 frames of source 1, so that the accumulator rows a lane receives
-//     ((reg&3) + 8*(reg>>2) + 4*(lane>>5)) are exactly frames 0..15 of ITS source; the 32 B-columns
-//     are frame j of 32 DIFFERENT targets, so column (lane&31) is ITS target.  After KS k-steps
-//     register r of a lane holds -2 a_r.b_j + |a_r|^2 for its own pair;
-//   * the DP column D(., j) of the pair lives in NT*16 VGPRs of the lane; the min-of-three
-//     recurrence is purely lane-local (no shuffles, no LDS), VALU work overlaps the MFMA pipe;
-//   * |b_j|^2 rides in the pad slot of the B record and is added on the VALU; the local cost is
-//     sqrt(|x|) (v_sqrt_f32 with the abs modifier) or |x| for squared-L2.
-//
-// Numerics: f32 expanded form, so costs of near-identical pairs carry cancellation error; the
-// bound used by select.hip is derived there.  This kernel is a FILTER; returned costs and indices
-// come from the exact f64 kernel.
+// Numerics: operands are scaled by a common power of two s so that max |s v| < 64, split into two
+// f16 pieces, squared norms into three; products are exact in the f32 accumulator, the residual
+// per product is <= 2^-22 relative.  The filter's error bound is derived in select.hip; returned
+// costs and indices always come from the exact f64 kernel.
 #include "ssym_internal.hpp"
+#include "dtw_filter_kernel.hpp"
 
 #include <algorithm>
+#include <cmath>
 
 namespace ssym {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-template <int N>
-struct FloatVec {
-    float v[N];
-};
-
-template <int KSP>
-__device__ __forceinline__ void load_half(const float *__restrict__ p, float (&dst)[KSP])
+// One thread per (segment, record slot).  Targets: frame f -> slot f.  Sources: END-ALIGNED, frame f
+// of nf -> slot frames_pad - nf + f; the slots above (and all slots of padding segments) get
+// |a|^2 = +inf so that their DP rows stay at +inf.
+__global__ void build_filter_records_kernel(const double *__restrict__ raw, const uint64_t *__restrict__ off,
+                                            uint32_t n, uint32_t dim, uint32_t frames_pad, int is_source,
+                                            double scale, _Float16 *__restrict__ rec)
 {
-    static_assert(KSP % 4 == 0, "half record must be whole float4s");
+    const uint32_t s = blockIdx.y;                              // < n_pad
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= frames_pad)
+        return;
+    _Float16 out[kFilterRecHalfs];
 #pragma unroll
-    for (int q = 0; q < KSP / 4; ++q) {
-        float4 t = *reinterpret_cast<const float4 *>(p + 4 * q);
-        dst[4 * q + 0] = t.x;
-        dst[4 * q + 1] = t.y;
-        dst[4 * q + 2] = t.z;
-        dst[4 * q + 3] = t.w;
-    }
-}
-
-// One 32x32 tile of the cost block: KS dependent k-steps into one accumulator.
-template <int KS, int KSP>
-__device__ __forceinline__ f32x16 mfma_tile(const float (&a)[KS], const float (&b)[KSP])
-{
-    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int s = 0; s < KS; ++s)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
-    return acc;
-}
-
-template <int NT, int KS, bool SQ>
-__global__ __launch_bounds__(256, 2) void dtw_filter_kernel(
-    const float *__restrict__ srcRec, const float *__restrict__ tgtRec,
-    const int *__restrict__ srcLen, const int *__restrict__ tgtLen, int tgtFramesPad, int mPad,
-    int nSrcBlocks, float *__restrict__ cmat)
-{
-    constexpr int KSP = ((KS + 1) + 3) / 4 * 4;
-    constexpr int REC = 2 * KSP;
-    constexpr int ROWS = NT * 16;
-    const float INF = __builtin_inff();
-
-    // XCD-aware task order: blocks b, b+8, b+16, ... share an XCD (round-robin dispatch); give each
-    // XCD a contiguous range of the (target group, source block) space so that the 32 targets of a
-    // group stay in that XCD's L2 while the source blocks stream past.
-    const unsigned nBlocks = gridDim.x;
-    const unsigned b = blockIdx.x;
-    const unsigned xcd = b & 7u, qd = nBlocks >> 3, rm = nBlocks & 7u;
-    const unsigned lin = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (b >> 3);
-    const int tg = (int)(lin / (unsigned)nSrcBlocks);
-    const int sb = (int)(lin % (unsigned)nSrcBlocks);
-
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int sp = sb * 4 + wave;      // source pair handled by this wave
-    const int col = lane & 31;         // B column / output column: target 32*tg + col
-    const int half = lane >> 5;        // operand role: K half; output role: source 2*sp + half
-
-    // ---- A operands: NT tiles x KS k-steps, resident for the whole task --------------------
-    // Source frames are END-ALIGNED in their ROWS slots (pack.hip): a source of fa frames sits in
-    // rows [ROWS-fa, ROWS); the rows above it carry |a|^2 = +inf, so their D stays +inf.
-    float A[NT][KS];
-    {
-        const int arow = lane & 31;
-        const int a_src = 2 * sp + ((arow >> 2) & 1);
-        const int a_frm = (arow & 3) + 4 * (arow >> 3);
-        const float *abase = srcRec + ((size_t)a_src * ROWS + a_frm) * REC + half * KSP;
-#pragma unroll
-        for (int T = 0; T < NT; ++T) {
-            float tmp[KSP];
-            load_half<KSP>(abase + (size_t)T * kRowsPerTile * REC, tmp);
-#pragma unroll
-            for (int s = 0; s < KS; ++s)
-                A[T][s] = tmp[s];
+    for (int i = 0; i < kFilterRecHalfs; ++i)
+        out[i] = (_Float16)0.0f;
+    const uint32_t nf = s < n ? (uint32_t)(off[s + 1] - off[s]) : 0u;
+    bool real = false;
+    uint32_t f = 0;
+    if (is_source) {
+        if (slot >= frames_pad - nf) {
+            real = true;
+            f = slot - (frames_pad - nf);
+        } else {
+            out[filter_slot_offset(39)] = (_Float16)__builtin_inff();   // pad row: cost +inf
         }
+    } else if (slot < nf) {
+        real = true;
+        f = slot;
     }
-
-    const int fa = srcLen[2 * sp + half];
-    const int fb_m1 = tgtLen[32 * tg + col] - 1;
-    const int r0 = ROWS - fa;          // first real row of this lane's source
-
-    // wave-uniform column bound: the longest target of the group
-    int nCols = fb_m1 + 1;
-#pragma unroll
-    for (int o = 16; o >= 1; o >>= 1)
-        nCols = max(nCols, __shfl_xor(nCols, o));
-    nCols = __builtin_amdgcn_readfirstlane(nCols);
-
-    // left[i] = D(i, j-1).  The virtual D(r0-1, -1) = 0 that starts the recurrence is planted in
-    // the row above the first real row (or handed in as the column's first diagonal when r0 = 0).
-    float left[ROWS];
-#pragma unroll
-    for (int i = 0; i < ROWS; ++i)
-        left[i] = (i == r0 - 1) ? 0.0f : INF;
-    const float diag0 = (r0 == 0) ? 0.0f : INF;
-    float res = INF;
-
-    const float *bbase = tgtRec + ((size_t)(32 * tg + col) * tgtFramesPad) * REC + half * KSP;
-    float Bc[KSP], Bn[KSP];
-#pragma unroll
-    for (int s = 0; s < KSP; ++s)
-        Bc[s] = 0.0f;
-    if (nCols > 0)
-        load_half<KSP>(bbase, Bc);
-    f32x16 acc = mfma_tile<KS, KSP>(A[0], Bc);
-
-    for (int j = 0; j < nCols; ++j) {
-        const int jn = min(j + 1, nCols - 1);
-        load_half<KSP>(bbase + (size_t)jn * REC, Bn);
-
-        const float nb = Bc[KSP - 1];
-        float up = INF;
-        float diag = (j == 0) ? diag0 : INF;
-
-#pragma unroll
-        for (int T = 0; T < NT; ++T) {
-            // software pipeline: the MFMA chain of the NEXT tile (next column's first tile after
-            // the last one) is issued ahead of this tile's DP, which only needs `acc`
-            f32x16 accn;
-            if (T + 1 < NT)
-                accn = mfma_tile<KS, KSP>(A[T + 1], Bc);
-            else
-                accn = mfma_tile<KS, KSP>(A[0], Bn);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int idx = T * 16 + r;
-                const float x = acc[r] + nb;
-                const float c = SQ ? __builtin_fabsf(x) : __builtin_amdgcn_sqrtf(__builtin_fabsf(x));
-                const float m = __builtin_fminf(__builtin_fminf(up, diag), left[idx]);
-                diag = left[idx];
-                const float cur = c + m;
-                left[idx] = cur;
-                up = cur;
+    if (real) {
+        const double *p = raw + (off[s] + f) * dim;
+        double nrm = 0.0;
+        for (uint32_t e = 0; e < dim; ++e) {
+            const double v = p[e] * scale;                       // exact: scale is a power of two
+            const _Float16 h1 = (_Float16)v;
+            const _Float16 h2 = (_Float16)(v - (double)h1);
+            const double vh = (double)h1 + (double)h2;           // the value the MFMA will see
+            nrm += vh * vh;
+            if (is_source) {
+                const _Float16 m1 = (_Float16)(-2.0f * (float)h1), m2 = (_Float16)(-2.0f * (float)h2);
+                out[filter_slot_offset(3 * e + 0)] = m1;
+                out[filter_slot_offset(3 * e + 1)] = m1;
+                out[filter_slot_offset(3 * e + 2)] = m2;
+            } else {
+                out[filter_slot_offset(3 * e + 0)] = h1;
+                out[filter_slot_offset(3 * e + 1)] = h2;
+                out[filter_slot_offset(3 * e + 2)] = h1;
             }
-            acc = accn;
         }
-
-        res = (j == fb_m1) ? up : res;   // D(fa-1, fb-1): the bottom row at the target's last frame
-#pragma unroll
-        for (int s = 0; s < KSP; ++s)
-            Bc[s] = Bn[s];
+        const _Float16 p1 = (_Float16)nrm;
+        const _Float16 p2 = (_Float16)(nrm - (double)p1);
+        const _Float16 p3 = (_Float16)(nrm - (double)p1 - (double)p2);
+        const int mine = is_source ? 39 : 42, other = is_source ? 42 : 39;
+        out[filter_slot_offset(mine + 0)] = p1;
+        out[filter_slot_offset(mine + 1)] = p2;
+        out[filter_slot_offset(mine + 2)] = p3;
+        out[filter_slot_offset(other + 0)] = (_Float16)1.0f;
+        out[filter_slot_offset(other + 1)] = (_Float16)1.0f;
+        out[filter_slot_offset(other + 2)] = (_Float16)1.0f;
     }
-
-    cmat[(size_t)(2 * sp + half) * mPad + 32 * tg + col] = res;
-}
-
-// -------------------------------------------------------------------------------------------------
-// host side
-// -------------------------------------------------------------------------------------------------
-static int pick_nt(int frames_pad)
-{
-    int nt = frames_pad / kRowsPerTile;
-    const int avail[] = {1, 2, 3, 4, 6, 8};
-    for (int a : avail)
-        if (nt <= a)
-            return a;
-    return -1;
+    _Float16 *dst = rec + ((size_t)s * frames_pad + slot) * kFilterRecHalfs;
+#pragma unroll
+    for (int i = 0; i < kFilterRecHalfs; ++i)
+        dst[i] = out[i];
 }
 
 bool filter_supported(const ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt)
 {
     if (ctx->band >= 0)
         return false;   // banded shapes run on the exact kernel (DESIGN.md "limits")
-    if (src.dim != tgt.dim || src.ks != tgt.ks)
+    if (src.dim != tgt.dim || (int)src.dim > kFilterMaxDim)
         return false;
-    if (src.ks > 7)
-        return false;   // dim <= 13 on the MFMA path for now
-    if (pick_nt((int)src.frames_pad) < 0)
-        return false;   // more than 128 source frames
+    if (filter_shape((int)src.max_frames).nt == 0)
+        return false;   // more than 512 source frames
+    if (!std::isfinite(src.max_abs) || !std::isfinite(tgt.max_abs))
+        return false;   // inf / NaN features: exact kernel keeps IEEE semantics
     return src.n > 0 && tgt.n > 0;
 }
 
-template <int NT, bool SQ>
-static void launch_one(hipStream_t st, const SegmentSet &src, const SegmentSet &tgt, float *cmat)
+// common power-of-two scale: max |s v| in [32, 64) (1 when everything is zero)
+static double common_scale(const SegmentSet &src, const SegmentSet &tgt)
 {
-    const int nSrcBlocks = (int)src.n_pad / 8;
+    const double m = std::max(src.max_abs, tgt.max_abs);
+    if (!(m > 0.0))
+        return 1.0;
+    int e = 0;
+    (void)std::frexp(m, &e);          // m = f * 2^e, f in [0.5, 1)
+    e = std::min(std::max(6 - e, -100), 100);
+    return std::ldexp(1.0, e);
+}
+
+static int32_t ensure_records(ssym_ctx *ctx, const SegmentSet &set, double scale)
+{
+    const size_t bytes = (size_t)set.n_pad * set.frames_pad * kFilterRecHalfs * sizeof(_Float16);
+    if (set.rec && set.rec_scale == scale && set.rec_bytes == bytes)
+        return SSYM_OK;
+    if (set.rec && set.rec_bytes != bytes) {
+        SSYM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(set.rec);
+        set.rec = nullptr;
+    }
+    if (!set.rec)
+        SSYM_HIP_CHECK(ctx, hipMalloc(&set.rec, bytes));
+    set.rec_bytes = bytes;
+    dim3 grid((set.frames_pad + 63) / 64, set.n_pad);
+    build_filter_records_kernel<<<grid, 64, 0, ctx->stream>>>(set.raw, set.off, set.n, set.dim,
+                                                              set.frames_pad, set.is_source ? 1 : 0, scale,
+                                                              (_Float16 *)set.rec);
+    SSYM_HIP_CHECK(ctx, hipGetLastError());
+    set.rec_scale = scale;
+    return SSYM_OK;
+}
+
+template <int NT, bool SQ>
+static void launch_one(hipStream_t st, const SegmentSet &src, const SegmentSet &tgt, int nPasses,
+                       int gridBlocks, float outScale, float *handoff, float *cmat)
+{
+    const int nSrcBlocks = (int)src.n_pad / (2 * kFilterWavesPerBlock);
     const int nTgtGroups = (int)tgt.n_pad / 32;
-    dim3 grid((unsigned)nSrcBlocks * (unsigned)nTgtGroups);
-    dtw_filter_kernel<NT, 7, SQ><<<grid, 256, 0, st>>>(src.rec, tgt.rec, src.len, tgt.len,
-                                                       (int)tgt.frames_pad, (int)tgt.n_pad,
-                                                       nSrcBlocks, cmat);
+    const int nTasks = nSrcBlocks * nTgtGroups;
+    dtw_filter_kernel<NT, SQ><<<dim3(std::min(gridBlocks, (nTasks + 7) / 8 * 8)), 64 * kFilterWavesPerBlock, 0, st>>>(
+        (const _Float16 *)src.rec, (const _Float16 *)tgt.rec, src.len, tgt.len, (int)src.frames_pad, nPasses,
+        (int)tgt.frames_pad, (int)tgt.n_pad, nSrcBlocks, nTasks, outScale, handoff, cmat);
 }
 
 int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, float *cmat)
 {
-    const int nt = pick_nt((int)src.frames_pad);
-    if (nt < 0 || (int)src.frames_pad != nt * kRowsPerTile) {
-        ctx->err = "dtw filter: source records not padded to a supported tile count";
+    const FilterShape shape = filter_shape((int)src.max_frames);
+    if (shape.nt == 0 || (int)src.frames_pad != shape.rows() || src.n_pad % 8 != 0 || tgt.n_pad % 32 != 0) {
+        ctx->err = "dtw filter: segment set not padded for the filter kernel";
         return SSYM_E_UNSUPPORTED;
     }
+    const double scale = common_scale(src, tgt);
+    int32_t rc = ensure_records(ctx, src, scale);
+    if (rc != SSYM_OK)
+        return rc;
+    rc = ensure_records(ctx, tgt, scale);
+    if (rc != SSYM_OK)
+        return rc;
+    // persistent grid: 2 workgroups of 4 waves per CU (2 waves per SIMD), a multiple of 8 so that
+    // task & 7 is the XCD group; one hand-off row of [target frames][64] floats per wave
+    const int gridBlocks = std::max(8, ctx->num_cus * 2 / 8 * 8);
+    rc = ensure(ctx, ctx->handoff, (size_t)gridBlocks * kFilterWavesPerBlock * tgt.frames_pad * 64 * sizeof(float));
+    if (rc != SSYM_OK)
+        return rc;
     hipStream_t st = ctx->stream;
     const bool sq = ctx->squared != 0;
-#define SSYM_LAUNCH_NT(N)                                                      \
-    case N:                                                                    \
-        if (sq) launch_one<N, true>(st, src, tgt, cmat);                       \
-        else launch_one<N, false>(st, src, tgt, cmat);                         \
+    const float outScale = (float)(sq ? 1.0 / (scale * scale) : 1.0 / scale);
+    float *hand = (float *)ctx->handoff.ptr;
+#define SSYM_CASE(NT_)                                                                          \
+    case NT_:                                                                                   \
+        if (sq) launch_one<NT_, true>(st, src, tgt, shape.rb, gridBlocks, outScale, hand, cmat);  \
+        else launch_one<NT_, false>(st, src, tgt, shape.rb, gridBlocks, outScale, hand, cmat);    \
         break;
-    switch (nt) {
-        SSYM_LAUNCH_NT(1)
-        SSYM_LAUNCH_NT(2)
-        SSYM_LAUNCH_NT(3)
-        SSYM_LAUNCH_NT(4)
-        SSYM_LAUNCH_NT(6)
-        SSYM_LAUNCH_NT(8)
+    switch (shape.nt) {
+        SSYM_CASE(1) SSYM_CASE(2) SSYM_CASE(3) SSYM_CASE(4)
     default:
-        ctx->err = "dtw filter: unsupported tile count";
+        ctx->err = "dtw filter: unsupported shape";
         return SSYM_E_UNSUPPORTED;
     }
-#undef SSYM_LAUNCH_NT
+#undef SSYM_CASE
     SSYM_HIP_CHECK(ctx, hipGetLastError());
     return SSYM_OK;
 }

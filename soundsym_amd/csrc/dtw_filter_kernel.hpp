@@ -1,0 +1,237 @@
+// dtw_filter_kernel.hpp -- device code of the dtw MFMA filter (included by dtw_filter.hip and by
+// tools/filter_bench.hip, which times ablated variants of the same source).
+//
+// One (source, target) pair per lane; the DP column of the pair lives in the lane's registers.
+//
+//   * cost block on the MATRIX pipe: v_mfma_f32_32x32x16_f16.  (The f32-input MFMA was measured
+//     first: on gfx950 it does not co-execute with VALU work -- kernel time was MFMA time PLUS DP
+//     time -- whereas the f16 matrix pipe runs beside the VALU.)  f32 accuracy is recovered by
+//     splitting every operand into two f16 pieces v = H1 + H2 (22 bits) and feeding the three
+//     significant cross products through the K dimension; both squared norms ride along in three
+//     f16 pieces each, so the accumulator IS |a - b|^2 (scaled), no VALU add:
+//         K slots 3e+0..3e+2 : (-2a_e)1 * (b_e)1,  (-2a_e)1 * (b_e)2,  (-2a_e)2 * (b_e)1     e < 13
+//         K slots 39..41     : |a|^2 pieces * 1          K slots 42..44 : 1 * |b|^2 pieces
+//     = 45 of the 48 slots of three chained 32x32x16 MFMAs per 32x32 tile;
+//   * tile = 16 frames of source 0 interleaved (groups of four) with 16 frames of source 1 as the
+//     32 A-rows, frame j of 32 DIFFERENT targets as the 32 B-columns: accumulator register r of
+//     lane (col = lane&31, half = lane>>5) is cell (row r, column j) of the pair
+//     (source 2*sp+half, target 32*tg+col);
+//   * DP: min-of-three recurrence, lane-local, 3 VALU instructions per cell (v_sqrt_f32 |x|,
+//     v_min3_f32, v_add_f32); the previous column is read from one register array and the new
+//     column written to the other (ping-pong, no register moves);
+//   * a wave keeps 16*NT rows of the column in registers; longer sources are processed in row-block
+//     PASSES by the same wave: pass p sweeps all columns for rows [p*16*NT, (p+1)*16*NT) and leaves
+//     the bottom row of its block, D(last row, j), in a per-wave hand-off row in global memory
+//     (256 coalesced bytes per column, L2 / Infinity-Cache resident because the grid is
+//     persistent); pass p+1 reads it back as its top boundary.  Waves never synchronise with each
+//     other -- a first version that pipelined row blocks across waves with one workgroup barrier
+//     per column spent half of its wave-cycles waiting (profiles/);
+//   * measured on MI355X (rocprofv3 PMC): plain VALU instructions occupy the SIMD for 4 cycles,
+//     v_sqrt_f32 for 8, whatever the occupancy -- 16 cycles per cell is the floor of this
+//     recurrence, and the kernel is VALU-bound, not MFMA- or HBM-bound.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#ifndef SSYM_FILTER_MODE
+#define SSYM_FILTER_MODE 0   // 0 = product; tools only: 1 = MFMA without DP, 2 = DP without MFMA
+#endif
+
+namespace ssym {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kFilterRowsPerTile = 16;   // frames of one source per 32x32 tile
+constexpr int kFilterKM = 3;             // chained K=16 MFMAs per tile
+constexpr int kFilterRecHalfs = 48;      // f16 values per frame record (96 bytes)
+constexpr int kFilterMaxDim = 13;        // 3*13 product slots + 6 norm slots <= 48
+
+// Record layout (both sides): [khalf 0: 3 x 8 f16][khalf 1: 3 x 8 f16]; MFMA m of lane half h
+// reads its 8 K-values at f16 offset h*24 + m*8, i.e. logical K slot 16*m + 8*h + j.
+__host__ __device__ constexpr int filter_slot_offset(int k) { return ((k >> 3) & 1) * 24 + (k >> 4) * 8 + (k & 7); }
+
+template <int KM>
+__device__ __forceinline__ f32x16 mfma_tile(const half8 (&a)[KM], const half8 (&b)[KM])
+{
+    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#if SSYM_FILTER_MODE == 2
+    float z = (float)a[0][0] + (float)b[0][0];
+    asm volatile("" : "+v"(z));
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        acc[r] = z + (float)r;
+    return acc;
+#else
+#pragma unroll
+    for (int m = 0; m < KM; ++m)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m], b[m], acc, 0, 0, 0);
+    return acc;
+#endif
+}
+
+__device__ __forceinline__ void load_rec(const _Float16 *__restrict__ p, half8 (&dst)[kFilterKM])
+{
+#pragma unroll
+    for (int m = 0; m < kFilterKM; ++m)
+        dst[m] = *reinterpret_cast<const half8 *>(p + 8 * m);
+}
+
+// One column of one row block: NT tiles, software-pipelined (the next tile's MFMA chain is in
+// flight while this tile's 16 cells run on the VALU).  Lr = D(., j-1), Lw = D(., j).
+template <int NT, bool SQ>
+__device__ __forceinline__ float dp_column(const half8 (&A)[NT][kFilterKM], const half8 (&Bc)[kFilterKM],
+                                           const half8 (&Bn)[kFilterKM], f32x16 &acc, float up, float diag,
+                                           const float (&Lr)[NT * 16], float (&Lw)[NT * 16])
+{
+#pragma unroll
+    for (int T = 0; T < NT; ++T) {
+        f32x16 accn;
+        if (T + 1 < NT)
+            accn = mfma_tile<kFilterKM>(A[T + 1], Bc);
+        else
+            accn = mfma_tile<kFilterKM>(A[0], Bn);   // first tile of the next column
+#if SSYM_FILTER_MODE == 1
+        asm volatile("" ::"v"(acc[0]), "v"(acc[15]));
+        up = acc[3];
+        Lw[T * 16] = Lr[T * 16];
+#else
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int idx = T * 16 + r;
+            const float x = acc[r];
+            const float c = SQ ? __builtin_fabsf(x) : __builtin_amdgcn_sqrtf(__builtin_fabsf(x));
+            const float m = __builtin_fminf(__builtin_fminf(up, diag), Lr[idx]);
+            diag = Lr[idx];
+            const float cur = c + m;
+            Lw[idx] = cur;
+            up = cur;
+        }
+#endif
+        acc = accn;
+    }
+    return up;   // D(last row of the block, j)
+}
+
+constexpr int kFilterWavesPerBlock = 4;
+
+// Persistent kernel: workgroup b works on tasks b, b + gridDim.x, ...; a task is (target group of
+// 32, block of 8 sources); each of the 4 waves owns one source pair of the block = 64 pairs.
+template <int NT, bool SQ>
+__global__ __launch_bounds__(64 * kFilterWavesPerBlock, 2) void dtw_filter_kernel(
+    const _Float16 *__restrict__ srcRec, const _Float16 *__restrict__ tgtRec,
+    const int *__restrict__ srcLen, const int *__restrict__ tgtLen, int srcRows, int nPasses,
+    int tgtFramesPad, int mPad, int nSrcBlocks, int nTasks, float outScale,
+    float *__restrict__ handoff, float *__restrict__ cmat)
+{
+    constexpr int REC = kFilterRecHalfs;
+    constexpr int BR = NT * 16;            // rows per pass
+    const float INF = __builtin_inff();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col = lane & 31;         // output column: target 32*tg + col
+    const int half = lane >> 5;        // operand role: K half; output role: source 2*sp + half
+    // this wave's hand-off row: [tgtFramesPad][64] floats
+    float *const hand = handoff + ((size_t)blockIdx.x * kFilterWavesPerBlock + wave) * (size_t)tgtFramesPad * 64 + lane;
+
+    for (unsigned task = blockIdx.x; task < (unsigned)nTasks; task += gridDim.x) {
+        // XCD-aware task order: workgroups b, b+8, ... share an XCD and gridDim.x is a multiple of
+        // 8, so task & 7 names the XCD group; give each group a contiguous range of the
+        // (target group, source block) space so a group's 32 targets stay in that XCD's L2.
+        const unsigned xcd = task & 7u, qd = (unsigned)nTasks >> 3, rm = (unsigned)nTasks & 7u;
+        const unsigned lin = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (task >> 3);
+        const int tg = (int)(lin / (unsigned)nSrcBlocks);
+        const int sb = (int)(lin % (unsigned)nSrcBlocks);
+        const int sp = sb * kFilterWavesPerBlock + wave;    // source pair of this wave
+
+        const int fa = srcLen[2 * sp + half];
+        const int fb_m1 = tgtLen[32 * tg + col] - 1;
+        const int r0 = srcRows - fa;   // first real row: sources are END-ALIGNED in their row slots
+
+        // wave-uniform bounds: columns up to the longest target of the group; passes that hold
+        // nothing but padding rows of BOTH sources are skipped
+        int nCols = fb_m1 + 1, r0min = r0;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            nCols = max(nCols, __shfl_xor(nCols, o));
+            r0min = min(r0min, __shfl_xor(r0min, o));
+        }
+        nCols = __builtin_amdgcn_readfirstlane(nCols);
+        r0min = __builtin_amdgcn_readfirstlane(r0min);
+        const int firstPass = min(max(r0min - 1, 0) / BR, nPasses - 1);
+
+        float res = INF;
+        const _Float16 *bbase = tgtRec + ((size_t)(32 * tg + col) * tgtFramesPad) * REC + half * 24;
+
+        for (int pass = firstPass; pass < nPasses; ++pass) {
+            const int rowBase = pass * BR;
+            const bool haveTop = pass > firstPass;      // wave-uniform
+            const bool lastPass = pass == nPasses - 1;
+
+            // A operands of this pass: the pad rows above a source carry |a|^2 = +inf
+            half8 A[NT][kFilterKM];
+            {
+                const int arow = lane & 31;
+                const int a_src = 2 * sp + ((arow >> 2) & 1);
+                const int a_frm = rowBase + (arow & 3) + 4 * (arow >> 3);
+                const _Float16 *abase = srcRec + ((size_t)a_src * srcRows + a_frm) * REC + half * 24;
+#pragma unroll
+                for (int T = 0; T < NT; ++T)
+                    load_rec(abase + (size_t)T * kFilterRowsPerTile * REC, A[T]);
+            }
+
+            // D(., -1): +inf, except the virtual D(r0-1, -1) = 0 that starts the recurrence
+            float L0[BR], L1[BR];
+#pragma unroll
+            for (int i = 0; i < BR; ++i) {
+                L0[i] = (rowBase + i == r0 - 1) ? 0.0f : INF;
+                L1[i] = L0[i];
+            }
+            const float diagCol0 = (rowBase == r0) ? 0.0f : INF;   // D(rowBase-1, -1)
+            float prevTop = INF;                                    // D(rowBase-1, j-1)
+
+            half8 Bc[kFilterKM], Bn[kFilterKM];
+#pragma unroll
+            for (int m = 0; m < kFilterKM; ++m)
+                Bc[m] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+            float topN = INF;                                       // D(rowBase-1, j) prefetched
+            if (nCols > 0) {
+                load_rec(bbase, Bc);
+                if (haveTop)
+                    topN = hand[0];
+            }
+            f32x16 acc = mfma_tile<kFilterKM>(A[0], Bc);
+
+            for (int j0 = 0; j0 < nCols; j0 += 2) {
+#pragma unroll
+                for (int par = 0; par < 2; ++par) {
+                    const int j = j0 + par;
+                    if (j < nCols) {                                // wave-uniform
+                        const int jn = min(j + 1, nCols - 1);
+                        load_rec(bbase + (size_t)jn * REC, Bn);
+                        const float up = haveTop ? topN : INF;
+                        const float diag = (j == 0) ? diagCol0 : prevTop;
+                        prevTop = up;
+                        if (haveTop)
+                            topN = hand[(size_t)jn * 64];           // next column's top boundary
+                        float bottom;
+                        if (par == 0)
+                            bottom = dp_column<NT, SQ>(A, Bc, Bn, acc, up, diag, L0, L1);
+                        else
+                            bottom = dp_column<NT, SQ>(A, Bc, Bn, acc, up, diag, L1, L0);
+                        if (!lastPass)
+                            hand[(size_t)j * 64] = bottom;          // top boundary of the next pass
+                        else
+                            res = (j == fb_m1) ? bottom : res;      // D(fa-1, fb-1)
+#pragma unroll
+                        for (int m = 0; m < kFilterKM; ++m)
+                            Bc[m] = Bn[m];
+                    }
+                }
+            }
+        }
+        cmat[(size_t)(2 * sp + half) * mPad + 32 * tg + col] = res * outScale;
+    }
+}
+
+}  // namespace ssym

@@ -54,54 +54,35 @@ __global__ void segment_norm_kernel(const double *__restrict__ raw, const uint64
     norm[s] = memo;
 }
 
-// dtw filter records: one thread per (segment, record slot).
-//   targets: frame f sits in slot f.
-//   sources: END-ALIGNED -- frame f of a segment with nf frames sits in slot frames_pad - nf + f;
-//            the slots above it (and every slot of a padding segment) carry |a|^2 = +inf, which
-//            keeps their DP rows at +inf in dtw_filter.hip.
-__global__ void build_records_kernel(const double *__restrict__ raw, const uint64_t *__restrict__ off,
-                                     uint32_t n, uint32_t dim, uint32_t frames_pad, int ks, int ksp,
-                                     int is_source, float *__restrict__ rec,
-                                     int32_t *__restrict__ len, unsigned *__restrict__ max_sqnorm_bits)
+// dtw: per-segment frame count and max squared frame norm, and the set-wide max |value|
+// (bits of non-negative floats order like unsigned integers; a non-finite value poisons the max).
+__global__ void segment_stats_kernel(const double *__restrict__ raw, const uint64_t *__restrict__ off,
+                                     uint32_t n, uint32_t dim, int32_t *__restrict__ len,
+                                     unsigned *__restrict__ max_sqnorm_bits,
+                                     unsigned *__restrict__ max_abs_bits)
 {
-    const uint32_t s = blockIdx.y;                              // < n_pad
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= frames_pad)
+    const uint32_t s = blockIdx.y;
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n)
         return;
-    const uint32_t nf = s < n ? (uint32_t)(off[s + 1] - off[s]) : 0u;
-    if (slot == 0)
+    const uint32_t nf = (uint32_t)(off[s + 1] - off[s]);
+    if (f == 0)
         len[s] = (int32_t)nf;
-    float *r = rec + ((size_t)s * frames_pad + slot) * (size_t)(2 * ksp);
-    const int nh = (int)dim / ks, nk = (int)dim % ks;           // where the norm element lives
-    uint32_t f;
-    if (is_source) {
-        if (slot < frames_pad - nf) {
-            r[nh * ksp + nk] = __builtin_inff();
-            return;
-        }
-        f = slot - (frames_pad - nf);
-    } else {
-        if (slot >= nf)
-            return;
-        f = slot;
-    }
+    if (f >= nf)
+        return;
     const double *p = raw + (off[s] + f) * dim;
-    double sq = 0.0;
+    double sq = 0.0, ma = 0.0;
     for (uint32_t e = 0; e < dim; ++e) {
-        float v = (float)p[e];               // f32 operand the MFMA will see
-        sq += (double)v * (double)v;          // norm of the ROUNDED frame (self-consistent expansion)
-        int h = (int)e / ks, k = (int)e % ks;
-        r[h * ksp + k] = is_source ? -2.0f * v : v;
+        const double v = p[e];
+        sq += v * v;
+        const double av = fabs(v);
+        ma = (av > ma || av != av) ? av : ma;     // NaN sticks
     }
-    float sqf = (float)sq;
-    r[nh * ksp + nk] = is_source ? sqf : 1.0f;
-    if (!is_source) {
-        r[ksp - 1] = sqf;       // pad slot of half 0
-        r[2 * ksp - 1] = sqf;   // pad slot of half 1
-    }
-    // upper bound of the true squared norm as f32 bits (non-negative floats order like uints)
-    float up = sqf * 1.000001f;
-    atomicMax(&max_sqnorm_bits[s], __float_as_uint(up));
+    float sqf = (float)sq * 1.000001f;            // rounded up
+    float maf = (float)ma * 1.000001f;
+    if (!(sqf == sqf) || !(maf == maf)) { sqf = __builtin_inff(); maf = __builtin_inff(); }
+    atomicMax(&max_sqnorm_bits[s], __float_as_uint(sqf));
+    atomicMax(max_abs_bits, __float_as_uint(maf));
 }
 
 void free_segments(SegmentSet &set)
@@ -110,6 +91,7 @@ void free_segments(SegmentSet &set)
     if (set.off) (void)hipFree(set.off);
     if (set.norm) (void)hipFree(set.norm);
     if (set.rec) (void)hipFree(set.rec);
+    set.rec = nullptr;
     if (set.len) (void)hipFree(set.len);
     if (set.max_sqnorm) (void)hipFree(set.max_sqnorm);
     set = SegmentSet{};
@@ -122,7 +104,6 @@ static int32_t build_derived(ssym_ctx *ctx, SegmentSet &set)
     const uint32_t n = set.n, dim = set.dim;
     if (set.off) { (void)hipFree(set.off); set.off = nullptr; }
     if (set.norm) { (void)hipFree(set.norm); set.norm = nullptr; }
-    if (set.rec) { (void)hipFree(set.rec); set.rec = nullptr; }
     if (set.len) { (void)hipFree(set.len); set.len = nullptr; }
     if (set.max_sqnorm) { (void)hipFree(set.max_sqnorm); set.max_sqnorm = nullptr; }
 
@@ -143,32 +124,34 @@ static int32_t build_derived(ssym_ctx *ctx, SegmentSet &set)
         segment_norm_kernel<<<(n + 63) / 64, 64, 0, st>>>(set.raw, set.off, n, dim, set.norm);
         SSYM_HIP_CHECK(ctx, hipGetLastError());
     } else {
-        set.ks = filter_ks((int)dim);
-        set.ksp = filter_ksp(set.ks);
-        const uint32_t quantum = set.is_source ? 8u : 32u;
-        set.n_pad = (n + quantum - 1) / quantum * quantum;
+        set.n_pad = (n + 31) / 32 * 32;       // sources: 8 per workgroup; targets: 32 per group
         uint32_t mf = std::max<uint32_t>(set.max_frames, 1);
-        set.frames_pad = set.is_source ? (uint32_t)filter_rows_pad((int)mf) : mf;
-        size_t rec_bytes = (size_t)set.n_pad * set.frames_pad * 2 * set.ksp * sizeof(float);
-        SSYM_HIP_CHECK(ctx, hipMalloc((void **)&set.rec, rec_bytes));
-        SSYM_HIP_CHECK(ctx, hipMemsetAsync(set.rec, 0, rec_bytes, st));
+        FilterShape shape = filter_shape((int)mf);
+        set.frames_pad = set.is_source ? (shape.nt ? (uint32_t)shape.rows() : mf) : mf;
         SSYM_HIP_CHECK(ctx, hipMalloc((void **)&set.len, sizeof(int32_t) * set.n_pad));
         SSYM_HIP_CHECK(ctx, hipMemsetAsync(set.len, 0, sizeof(int32_t) * set.n_pad, st));
-        SSYM_HIP_CHECK(ctx, hipMalloc((void **)&set.max_sqnorm, sizeof(float) * set.n_pad));
-        SSYM_HIP_CHECK(ctx, hipMemsetAsync(set.max_sqnorm, 0, sizeof(float) * set.n_pad, st));
-        dim3 grid((set.frames_pad + 63) / 64, set.n_pad);
-        build_records_kernel<<<grid, 64, 0, st>>>(set.raw, set.off, n, dim, set.frames_pad, set.ks,
-                                                  set.ksp, set.is_source ? 1 : 0, set.rec, set.len,
-                                                  (unsigned *)set.max_sqnorm);
+        SSYM_HIP_CHECK(ctx, hipMalloc((void **)&set.max_sqnorm, sizeof(float) * (set.n_pad + 1)));
+        SSYM_HIP_CHECK(ctx, hipMemsetAsync(set.max_sqnorm, 0, sizeof(float) * (set.n_pad + 1), st));
+        dim3 grid((mf + 63) / 64, n);
+        segment_stats_kernel<<<grid, 64, 0, st>>>(set.raw, set.off, n, dim, set.len,
+                                                  (unsigned *)set.max_sqnorm,
+                                                  (unsigned *)set.max_sqnorm + set.n_pad);
         SSYM_HIP_CHECK(ctx, hipGetLastError());
-        std::vector<float> h(set.n_pad);
-        SSYM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), set.max_sqnorm, sizeof(float) * set.n_pad,
+        std::vector<float> h(set.n_pad + 1);
+        SSYM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), set.max_sqnorm, sizeof(float) * (set.n_pad + 1),
                                            hipMemcpyDeviceToHost, st));
         SSYM_HIP_CHECK(ctx, hipStreamSynchronize(st));
         float m = 0.f;
-        for (float v : h)
-            m = std::max(m, v);
+        for (uint32_t i = 0; i < set.n_pad; ++i)
+            m = std::max(m, h[i]);
         set.max_sqnorm_all = (double)m;
+        set.max_abs = (double)h[set.n_pad];
+        if (set.rec) {
+            (void)hipFree(set.rec);
+            set.rec = nullptr;
+        }
+        set.rec_scale = 0.0;
+        set.rec_bytes = 0;
     }
     SSYM_HIP_CHECK(ctx, hipStreamSynchronize(st));
     return SSYM_OK;

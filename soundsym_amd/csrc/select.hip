@@ -16,28 +16,30 @@
 namespace ssym {
 
 // ---------------------------------------------------------------------------------------------
-// Error bound of the f32 MFMA filter (dtw_filter.hip), u = 2^-24.
+// Error bound of the f16-split MFMA filter (dtw_filter_kernel.hpp), u = 2^-24, s = common scale.
 //
-//  x~ = |fl( sum of 2*KS products, then + |b|^2 )| with true value x = |a - b|^2 >= 0:
-//       the fma chain has at most 2*KS+1 <= 15 roundings (dim <= 13) over the terms |a|^2, |b|^2,
-//       -2 a_k b_k, and the two stored norms are themselves rounded once:
-//          |x~ - x| <= (gamma_15 + u(1 + gamma_15)) (|a|^2 + |b|^2 + 2 sum|a_k b_k|)
-//                   <= 33 u (|a|^2 + |b|^2)            =: E            (2 sum|a_k b_k| <= |a|^2+|b|^2)
-//  local cost c~ = sqrt~(x~), v_sqrt_f32 within 1 ulp:  |c~ - c| <= sqrt(E) + 2u c
+//  Per cell the accumulator holds x~ for the true x = |a - b|^2 (both in units scaled by s^2):
+//    * operand split: every scaled value v is fed as H1 + H2 with |v - H1 - H2| <= max(2^-22 |v|, 2^-25)
+//      (f16 pieces, the second may be subnormal); the product H2a*H2b is dropped.  Over the 13
+//      dims this moves x by at most 12 u (|a|^2 + |b|^2) + 2^-12            (|s v| < 64);
+//    * norms are fed in three f16 pieces (error < 2^-33 relative, negligible);
+//    * accumulation of the 45 products inside three chained K=16 MFMAs, f32 accumulator: at most
+//      48 roundings (counted twice in case the matrix pipe truncates): 2 * 48 u * 2(|a|^2+|b|^2);
+//      together  |x~ - x| <= 204 u (|a|^2 + |b|^2) + 2^-12   -- the code uses 256 u.
+//  local cost c~ = v_sqrt_f32(|x~|) (1 ulp):  |c~ - c| <= sqrt(E) + 2u c,  E = 256u nsum + 2^-12/s^2
 //       (|sqrt(y) - sqrt(x)| <= sqrt(|y - x|));  squared-L2 mode: |c~ - c| <= E.
-//  f64 inputs rounded to f32 move every frame by at most u|a|, so c moves by <= u(|a| + |b|)
-//       (squared mode: <= 2 u (|a|+|b|)^2 (1+u) <= 4.1 u (|a|^2 + |b|^2)).
 //  DP: min is exact, each of the <= Fa+Fb-1 additions along a path rounds once (relative u), and
 //       DTW is monotone and 1-Lipschitz in the cell costs along the optimal path of either side:
-//          |C~ - C| <= P * cell + rho * C,   P = Fa + Fb - 1,  rho = (P + 2) u.
+//          |C~ - C| <= P * cell + rho * C,   P = Fa + Fb - 1,  rho = (P + 4) u.
 //  Selection: with s^ the filter's argmin of key = |C~ - delta| and s* the exact one,
 //          key~(s*) <= key~(s^) + 2 P cell + rho (C(s*) + C(s^)),
 //       so every target keeps all s with key~(s) <= keymin~ + margin,
 //          margin = 2.05 P cell + 3.1 rho (delta + keymin~) .
-//  The constants below add slack on top (34 instead of 33, maxima over the whole dictionary).
+//  Maxima over the whole dictionary are used for |a|^2 and Fa (more slack).
 // ---------------------------------------------------------------------------------------------
 struct MarginParams {
-    double na_max;    // max_f |a_f|^2 over the dictionary (rounded up)
+    double na_max;      // max_f |a_f|^2 over the dictionary (rounded up), unscaled
+    double inv_scale2;  // 1 / s^2
     int fa_max;
     int squared;
 };
@@ -47,13 +49,10 @@ __device__ __forceinline__ double dtw_margin(const MarginParams &mp, double nb_m
 {
     const double u = 5.9604644775390625e-8;   // 2^-24
     const double nsum = mp.na_max + nb_max;
-    double cell;
-    if (mp.squared)
-        cell = (34.0 + 4.1) * u * nsum;
-    else
-        cell = sqrt(34.0 * u * nsum) + 3.0 * u * (sqrt(mp.na_max) + sqrt(nb_max));
+    const double E = 256.0 * u * nsum + 0.000244140625 * mp.inv_scale2;
+    const double cell = mp.squared ? E : sqrt(E) + 2.0 * u * (sqrt(mp.na_max) + sqrt(nb_max));
     const double P = (double)(mp.fa_max + fb - 1);
-    const double rho = (P + 2.0) * u;
+    const double rho = (P + 4.0) * u;
     return 2.05 * P * cell + 3.1 * rho * (delta + keymin) + 1e-300;
 }
 
@@ -277,6 +276,7 @@ int32_t launch_dtw_select(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
     hipStream_t st = ctx->stream;
     MarginParams mp;
     mp.na_max = src.max_sqnorm_all;
+    mp.inv_scale2 = src.rec_scale > 0.0 ? 1.0 / (src.rec_scale * src.rec_scale) : 1.0;
     mp.fa_max = (int)src.max_frames;
     mp.squared = ctx->squared;
     int32_t rc = ensure(ctx, ctx->tmin, sizeof(unsigned long long) * tgt.n);

@@ -12,32 +12,20 @@
 
 namespace ssym {
 
-// ---------------------------------------------------------------------------------------------
-// Packed record layout for the dtw MFMA filter (see dtw_filter.hip and DESIGN.md).
-// One record per frame = 2 halves of KSP floats; half h holds K-elements [h*KS, h*KS+KS).
-//   source ("A") record element e: -2*a[e] for e < dim, ||a||^2 at e = dim, 0 after
-//   target ("B") record element e:     b[e] for e < dim, 1.0     at e = dim, 0 after
-//   target records also carry ||b||^2 in the LAST float of each half (pad slot, never fed to MFMA)
-// KS = number of 32x32x2 k-steps = ceil((dim+1)/2); KSP = KS rounded up so a pad slot exists and
-// a half is a whole number of 16-byte loads.
-// ---------------------------------------------------------------------------------------------
-constexpr int kRowsPerTile = 16;   // frames of one source per 32x32 MFMA tile
-constexpr int kMaxTiles = 8;       // register-resident DP column: up to 128 source frames
-
-// the filter kernel is instantiated for KS = 7 (dim <= 13, zero-padded below that); larger dims
-// get their natural KS but run on the exact kernel (filter_supported)
-inline int filter_ks(int dim) { return dim <= 13 ? 7 : (dim + 1 + 1) / 2; }
-// source rows are padded to a tile count the filter kernel is instantiated for
-inline int filter_rows_pad(int max_frames)
+// dtw filter geometry (see dtw_filter_kernel.hpp): a source slot holds 16*nt*rb rows, processed by
+// one wave in rb passes of nt 32x32 tiles each.
+struct FilterShape {
+    int nt = 0, rb = 0;
+    int rows() const { return 16 * nt * rb; }
+};
+inline FilterShape filter_shape(int max_frames)
 {
-    const int avail[] = {1, 2, 3, 4, 6, 8};
-    int nt = (max_frames + kRowsPerTile - 1) / kRowsPerTile;
-    if (nt < 1) nt = 1;
-    for (int a : avail)
-        if (nt <= a) return a * kRowsPerTile;
-    return nt * kRowsPerTile;   // beyond the filter's reach; exact kernel only
+    if (max_frames <= 16) return FilterShape{1, 1};
+    if (max_frames <= 32) return FilterShape{2, 1};
+    if (max_frames <= 48) return FilterShape{3, 1};
+    if (max_frames <= 4096) return FilterShape{4, (max_frames + 63) / 64};
+    return FilterShape{};   // beyond the filter's reach: exact kernel only
 }
-inline int filter_ksp(int ks) { return ((ks + 1) + 3) / 4 * 4; }  // >= ks+1 (pad slot for ||b||^2)
 
 struct DeviceBuf {
     void *ptr = nullptr;
@@ -56,14 +44,17 @@ struct SegmentSet {
     // refcos
     double *norm = nullptr;         // [n]  norm(me) of src/sound.rs:35-38 per segment
     // dtw filter
-    float *rec = nullptr;           // [n_pad][frames_pad][2*KSP]
     int32_t *len = nullptr;         // [n_pad] frames per segment (0 for padding segments)
     float *max_sqnorm = nullptr;    // [n_pad] max_f ||frame||^2 per segment (f32, rounded up)
     double max_sqnorm_all = 0.0;    // host: max over all segments
+    double max_abs = 0.0;           // host: max |value| over the set (inf if any value is not finite)
     uint32_t n_pad = 0;
-    uint32_t frames_pad = 0;
-    int ks = 0, ksp = 0;
+    uint32_t frames_pad = 0;        // record slots per segment
     bool is_source = false;
+    // f16 operand records, (re)built by dtw_filter.hip whenever the common scale changes
+    mutable void *rec = nullptr;    // [n_pad][frames_pad][48] _Float16
+    mutable double rec_scale = 0.0;
+    mutable size_t rec_bytes = 0;
     size_t raw_capacity_vals = 0;
 };
 
@@ -81,6 +72,7 @@ struct ssym_ctx {
     ssym_timings timings{};
     int num_cus = 256;
     // scratch (grown on demand, reused across calls)
+    ssym::DeviceBuf handoff;    // dtw filter: per-wave row hand-off between row-block passes
     ssym::DeviceBuf cmat;       // dtw filter costs f32 [n_pad][m_pad]  /  refcos sims f64
     ssym::DeviceBuf tmin;       // per-target min key bits
     ssym::DeviceBuf cand;       // candidate pairs (uint2) + counter + overflow flag

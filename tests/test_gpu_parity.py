@@ -131,11 +131,14 @@ def test_refcos_edge_cases(refcos, oracle):
 # dtw
 # ---------------------------------------------------------------------------------------------
 def _filter_bound(src, tgt, fa, fb):
-    """|C~ - C| bound of the f32 filter as derived in soundsym_amd/csrc/select.hip."""
+    """|C~ - C| bound of the f16-split MFMA filter as derived in soundsym_amd/csrc/select.hip."""
     u = 2.0 ** -24
     na = max(float((s.astype(np.float64) ** 2).sum(-1).max()) for s in src if s.size)
     nb = max(float((t.astype(np.float64) ** 2).sum(-1).max()) for t in tgt if t.size)
-    cell = math.sqrt(34 * u * (na + nb)) + 3 * u * (math.sqrt(na) + math.sqrt(nb))
+    vmax = max(max(float(np.abs(s).max()) for s in src if s.size), max(float(np.abs(t).max()) for t in tgt if t.size))
+    scale = 2.0 ** (6 - math.frexp(vmax)[1]) if vmax > 0 else 1.0
+    E = 256 * u * (na + nb) + 2.0 ** -12 / scale ** 2
+    cell = math.sqrt(E) + 2 * u * (math.sqrt(na) + math.sqrt(nb))
     return (fa + fb - 1) * cell
 
 
@@ -163,7 +166,7 @@ def test_dtw_golden_grid(dtw, oracle):
     assert np.array_equal(idx, g["idx"]) and np.array_equal(idx, g["planted"])
     assert np.allclose(cost, g["cost"], rtol=DTW_RTOL, atol=0)
     assert np.allclose(cost, g["cost"], rtol=EXACT_RTOL, atol=0)     # refined in f64
-    # the f32 MFMA filter's whole cost matrix against the oracle's, within the derived bound
+    # the f16-split MFMA filter's whole cost matrix against the oracle's, within the derived bound
     filt = dtw.pair_matrix(d, q, exact=False)
     bound = _filter_bound(list(g["sources"]), list(g["targets"]), f, f)
     err = np.abs(filt - g["matrix"])
@@ -241,25 +244,46 @@ def test_dtw_ties_take_the_lowest_index(dtw, oracle):
     assert np.allclose(cost, want_cost, rtol=EXACT_RTOL, atol=0)
 
 
-def test_dtw_long_segments_and_wide_frames_use_the_exact_kernel(oracle):
-    # > 128 source frames (two 64-row chunks + boundary hand-off) and dim > 13
+def test_dtw_long_segments_take_several_row_block_passes(oracle):
+    # 150 and 300 source frames: 3 and 5 passes of 64 rows with the boundary row handed over
     e = Engine(metric="dtw", dtype="f32")
-    g = synth.make_grid(6, 5, 150, 13, 0x5EED0320)
-    sf, so = g.flat("sources")
-    tf, to = g.flat("targets")
-    idx, cost = e.match(e.dictionary(sf, so, 13), e.queries(tf, to, 13))
-    assert e.timings()["used_filter"] == 0
-    want_idx, want_cost = oracle.dtw_match_all(sf.astype(np.float64), so, tf.astype(np.float64), to, 13)
-    assert np.array_equal(idx, want_idx) and np.allclose(cost, want_cost, rtol=EXACT_RTOL, atol=0)
+    for n, m, f in ((6, 5, 150), (4, 3, 300)):
+        g = synth.make_grid(n, m, f, 13, 0x5EED0320 + f)
+        sf, so = g.flat("sources")
+        tf, to = g.flat("targets")
+        d, q = e.dictionary(sf, so, 13), e.queries(tf, to, 13)
+        idx, cost = e.match(d, q)
+        assert e.timings()["used_filter"] == 1
+        want_idx, want_cost, mat = oracle.dtw_match_all(sf.astype(np.float64), so, tf.astype(np.float64), to, 13,
+                                                        want_matrix=True)
+        assert np.array_equal(idx, want_idx) and np.allclose(cost, want_cost, rtol=EXACT_RTOL, atol=0)
+        filt = e.pair_matrix(d, q, exact=False)
+        bound = _filter_bound(list(g.sources), list(g.targets), f, f)
+        assert (np.abs(filt - mat) <= bound + 1e-5 * mat).all()
+    e.close()
+
+
+def test_dtw_wide_frames_and_bands_use_the_exact_kernel(oracle):
+    # dim > 13 and Sakoe-Chiba bands are outside the MFMA filter: exact f64 kernel on every pair,
+    # including its own 64-row chunking (150 frames = 3 chunks)
     g = synth.make_grid(6, 5, 40, 40, 0x5EED0321)
     sf, so = g.flat("sources")
     tf, to = g.flat("targets")
     eb = Engine(metric="dtw", dtype="f32", band=8)
     idx, cost = eb.match(eb.dictionary(sf, so, 40), eb.queries(tf, to, 40))
+    assert eb.timings()["used_filter"] == 0
     want_idx, want_cost = oracle.dtw_match_all(sf.astype(np.float64), so, tf.astype(np.float64), to, 40, band=8)
     assert np.array_equal(idx, want_idx) and np.allclose(cost, want_cost, rtol=EXACT_RTOL, atol=0)
-    e.close()
     eb.close()
+    e = Engine(metric="dtw", dtype="f32")
+    g = synth.make_grid(5, 4, 150, 13, 0x5EED0322)
+    sf, so = g.flat("sources")
+    tf, to = g.flat("targets")
+    idx, cost = e.match(e.dictionary(sf, so, 13), e.queries(tf, to, 13), force_exact=True)
+    assert e.timings()["used_filter"] == 0
+    want_idx, want_cost = oracle.dtw_match_all(sf.astype(np.float64), so, tf.astype(np.float64), to, 13)
+    assert np.array_equal(idx, want_idx) and np.allclose(cost, want_cost, rtol=EXACT_RTOL, atol=0)
+    e.close()
 
 
 def test_dtw_f64_inputs_and_distance(oracle):
