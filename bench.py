@@ -12,6 +12,7 @@ run"; the metric is quoted on it).  N > 1: source-axis sharding with 4096 source
 4096 targets on every GPU (weak scaling; 8 GPUs = 32768 x 4096).
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -31,17 +32,12 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA peak
 PEAK_HBM_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
-def cpu_baseline(grid, gpu_idx, sample_src=256, sample_tgt=256):
-    """The CPU oracle (a port: the reference is Rust and cannot be built here) on a bounded
-    sample of the same workload, all host cores, OpenMP over targets."""
-    import oracle
-    o = oracle.load()
-    threads = min(o.max_threads(), os.cpu_count() or 1)
-    tsel = np.arange(sample_tgt)
-    # make sure each sampled target's planted source is inside the sampled source block
+def _oracle_sample(o, grid, gpu_idx, n_src, n_tgt, threads):
+    tsel = np.arange(n_tgt)
+    # keep each sampled target's planted source inside the sampled source block
     planted = grid.planted[tsel]
-    rest = np.setdiff1d(np.arange(grid.sources.shape[0]), planted)[:max(0, sample_src - planted.size)]
-    ssel = np.sort(np.concatenate([planted, rest]))[:max(sample_src, planted.size)]
+    rest = np.setdiff1d(np.arange(grid.sources.shape[0]), planted)[:max(0, n_src - planted.size)]
+    ssel = np.sort(np.concatenate([planted, rest]))
     sf = np.ascontiguousarray(grid.sources[ssel], dtype=np.float64).reshape(-1)
     tf = np.ascontiguousarray(grid.targets[tsel], dtype=np.float64).reshape(-1)
     so = np.arange(ssel.size + 1, dtype=np.uint64) * grid.frames
@@ -50,13 +46,32 @@ def cpu_baseline(grid, gpu_idx, sample_src=256, sample_tgt=256):
     idx, _ = o.dtw_match_all(sf, so, tf, to, grid.dim, nthreads=threads)
     dt = time.perf_counter() - t0
     ok = bool(np.array_equal(ssel[idx], gpu_idx[tsel])) if gpu_idx is not None else None
+    return ssel.size * tsel.size, dt, ok
+
+
+def cpu_baseline(grid, gpu_idx, budget_s=12.0):
+    """The CPU oracle (a port: the reference is Rust and cannot be built here) on a bounded
+    sample of the same workload, all host cores, OpenMP over targets.  A small probe sizes the
+    sample so that it takes about `budget_s` seconds on whatever host this is."""
+    import oracle
+    o = oracle.load()
+    threads = max(1, min(o.max_threads(), os.cpu_count() or 1))
+    n_all_s, n_all_t = grid.sources.shape[0], grid.targets.shape[0]
+    pairs, dt, _ = _oracle_sample(o, grid, None, 64, min(n_all_t, 4 * threads), threads)
+    rate = pairs / max(dt, 1e-6)
+    want = max(pairs, rate * budget_s)
+    n_tgt = int(min(n_all_t, max(threads, 256)))
+    n_src = int(min(n_all_s, max(n_tgt, want // n_tgt)))
+    if n_src == n_all_s:
+        n_tgt = int(min(n_all_t, max(n_tgt, want // n_src)))
+    pairs, dt, ok = _oracle_sample(o, grid, gpu_idx, n_src, n_tgt, threads)
     return {
-        "value": ssel.size * tsel.size / dt,
+        "value": pairs / dt,
         "unit": "segment-pairs/s",
         "cores": threads,
         "kind": "port",
-        "sample": f"{ssel.size}x{tsel.size} sub-grid of the workload ({ssel.size * tsel.size} pairs, "
-                  f"{dt:.1f} s, f64 oracle, OpenMP over targets); indices equal the GPU's: {ok}",
+        "sample": f"{n_src}x{n_tgt} sub-grid of the workload ({pairs} pairs, {dt:.1f} s, f64 oracle, "
+                  f"OpenMP over targets); indices equal the GPU's: {ok}",
     }
 
 
@@ -139,13 +154,24 @@ def main():
     planted_ok = bool(np.array_equal(idx_host, grid.planted))
 
     if rank == 0:
-        # roofline of the dominant kernel (dtw_filter_kernel), measured with HIP events on the
-        # library's stream (ssym_get_timings): algorithmic flops 2*F^2*d per pair
+        # Roofline of the dominant kernel (dtw_filter_kernel).  Its duration is measured live with
+        # HIP events on the library's own stream (ssym_get_timings).  Algorithmic work per pair is
+        # SURVEY.md 8(d)'s: bytes 2*F*d*4 (per-pair operand-streaming model -- the model the
+        # north star's ">= 60 % HBM roofline" is stated in), matrix flops 2*F^2*d, DP cells F^2.
         k_ms = float(np.mean(main_ms))
+        k_s = k_ms * 1e-3
         pairs_launch = (hi - lo) * m
-        flops = 2.0 * args.frames * args.frames * DIM * pairs_launch
-        achieved_tf = flops / (k_ms * 1e-3) / 1e12
-        stream_gbps = pairs_launch * 2 * args.frames * DIM * 4 / (k_ms * 1e-3) / 1e9
+        f, dd = args.frames, DIM
+        stream_gbps = pairs_launch * 2 * f * dd * 4 / k_s / 1e9
+        flops_tf = pairs_launch * 2.0 * f * f * dd / k_s / 1e12
+        cells_per_s = pairs_launch * float(f) * f / k_s
+        traffic = None
+        prof = sorted(glob.glob(os.path.join(ROOT, "profiles", "*bench_1gpu.json")))
+        if prof and n_gpus == 1 and (hi - lo, m, f) == (SRC_PER_GPU, N_TGT, FRAMES):
+            traffic = json.load(open(prof[-1])).get("hbm_traffic_bytes_per_launch")
+        # VALU floor measured on MI355X (profiles/): v_sqrt_f32 8 + v_min3_f32 4 + v_add_f32 4
+        # cycles per wave-instruction = 16 cycles per 64 cells per SIMD, 1024 SIMDs
+        valu_peak_cells = 1024 * 64 / 16.0 * 2.4e9
         line = {
             "metric": "segment-pairs/sec (DTW cost+argmin)",
             "value": value,
@@ -160,7 +186,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{n_src_total}x{m} segments, {args.frames} frames x {DIM} dims, f32, "
+                "workload": f"{n_src_total}x{m} segments, {f} frames x {dd} dims, f32, "
                             f"dtw (L2 local cost, full matrix), planted neighbours, seed 0x{SEED:X}",
                 "sources_per_gpu": hi - lo,
                 "parallelism": f"source-shard x{n_gpus}" if n_gpus > 1 else "single GPU",
@@ -168,20 +194,24 @@ def main():
                 "pairs_refined_f64": int(refined),
             },
             "roofline": {
-                "bound": "mfma",
+                "bound": "hbm",
                 "kernel": "dtw_filter_kernel",
-                "achieved": achieved_tf,
-                "peak": PEAK_F32_MFMA_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": achieved_tf / PEAK_F32_MFMA_TFLOPS,
-                "traffic": None,
+                "model": "per-pair operand-streaming bytes 2*F*d*4 (SURVEY.md 8(d)); the kernel keeps "
+                         "operands on chip, so measured HBM traffic is far below this and the "
+                         "limiter is VALU issue, see 'valu' and DESIGN.md",
+                "achieved": stream_gbps,
+                "peak": PEAK_HBM_GBPS,
+                "unit": "GB/s",
+                "frac": stream_gbps / PEAK_HBM_GBPS,
+                "traffic": traffic,
                 "kernel_ms": k_ms,
-                "hbm_streaming_model": {
-                    "achieved": stream_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                    "frac": stream_gbps / PEAK_HBM_GBPS,
-                    "note": "per-pair operand-streaming byte model 2*F*d*4 B/pair (SURVEY 8(d)); "
-                            "real HBM traffic is far lower, operands stay in L2/Infinity Cache",
-                },
+                "mfma": {"achieved": flops_tf, "unit": "TFLOP/s", "algorithmic_flops_per_pair": 2 * f * f * dd,
+                         "peak_f32_mfma": PEAK_F32_MFMA_TFLOPS, "frac_of_f32_mfma_peak": flops_tf / PEAK_F32_MFMA_TFLOPS,
+                         "note": "cost block runs on the f16 matrix pipe (3 x 32x32x16 per 32x32 tile, "
+                                 "two-piece operand split); algorithmic flops, not issued flops"},
+                "valu": {"achieved": cells_per_s, "unit": "DP cells/s", "peak": valu_peak_cells,
+                         "frac": cells_per_s / valu_peak_cells,
+                         "note": "16 VALU cycles per cell per SIMD at 2.4 GHz (measured issue costs)"},
             },
         }
         if n_gpus == 1 and not args.no_cpu_baseline:

@@ -190,17 +190,18 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, 2) void dtw_filter_kerne
             const float diagCol0 = (rowBase == r0) ? 0.0f : INF;   // D(rowBase-1, -1)
             float prevTop = INF;                                    // D(rowBase-1, j-1)
 
-            half8 Bc[kFilterKM], Bn[kFilterKM];
+            // B operands of the current and the next column swap roles every column (no copies)
+            half8 B0[kFilterKM], B1[kFilterKM];
 #pragma unroll
             for (int m = 0; m < kFilterKM; ++m)
-                Bc[m] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+                B0[m] = half8{0, 0, 0, 0, 0, 0, 0, 0};
             float topN = INF;                                       // D(rowBase-1, j) prefetched
             if (nCols > 0) {
-                load_rec(bbase, Bc);
+                load_rec(bbase, B0);
                 if (haveTop)
                     topN = hand[0];
             }
-            f32x16 acc = mfma_tile<kFilterKM>(A[0], Bc);
+            f32x16 acc = mfma_tile<kFilterKM>(A[0], B0);
 
             for (int j0 = 0; j0 < nCols; j0 += 2) {
 #pragma unroll
@@ -208,7 +209,10 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, 2) void dtw_filter_kerne
                     const int j = j0 + par;
                     if (j < nCols) {                                // wave-uniform
                         const int jn = min(j + 1, nCols - 1);
-                        load_rec(bbase + (size_t)jn * REC, Bn);
+                        if (par == 0)
+                            load_rec(bbase + (size_t)jn * REC, B1);
+                        else
+                            load_rec(bbase + (size_t)jn * REC, B0);
                         const float up = haveTop ? topN : INF;
                         const float diag = (j == 0) ? diagCol0 : prevTop;
                         prevTop = up;
@@ -216,16 +220,13 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, 2) void dtw_filter_kerne
                             topN = hand[(size_t)jn * 64];           // next column's top boundary
                         float bottom;
                         if (par == 0)
-                            bottom = dp_column<NT, SQ>(A, Bc, Bn, acc, up, diag, L0, L1);
+                            bottom = dp_column<NT, SQ>(A, B0, B1, acc, up, diag, L0, L1);
                         else
-                            bottom = dp_column<NT, SQ>(A, Bc, Bn, acc, up, diag, L1, L0);
+                            bottom = dp_column<NT, SQ>(A, B1, B0, acc, up, diag, L1, L0);
                         if (!lastPass)
                             hand[(size_t)j * 64] = bottom;          // top boundary of the next pass
                         else
                             res = (j == fb_m1) ? bottom : res;      // D(fa-1, fb-1)
-#pragma unroll
-                        for (int m = 0; m < kFilterKM; ++m)
-                            Bc[m] = Bn[m];
                     }
                 }
             }
