@@ -96,10 +96,19 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.gpus > 1 and world == 1:
+        sys.exit("bench.py --gpus N > 1 must be launched with `python -m torch.distributed.run "
+                 "--nproc-per-node N ... bench.py --gpus N` (one rank per GPU)")
+    # SSYM_BENCH_BACKEND=gloo rehearses the N > 1 code path on a box with fewer GPUs than ranks
+    backend = os.environ.get("SSYM_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % max(torch.cuda.device_count(), 1) if backend == "gloo" else local_rank
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     n_gpus = max(world, 1)
     n_src_total = args.src_per_gpu * n_gpus
     m = args.targets

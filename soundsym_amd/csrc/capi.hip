@@ -351,12 +351,14 @@ int32_t ssym_match_queries(ssym_ctx *ctx, const ssym_dict *dict, const ssym_quer
         const bool useFilter = !(flags & SSYM_DTW_FORCE_EXACT) && filter_supported(ctx, src, tgt);
         tm.used_filter = useFilter ? 1 : 0;
         if (useFilter) {
-            rc = ensure(ctx, ctx->cmat, sizeof(float) * (size_t)src.n_pad * tgt.n_pad);
+            const size_t matElems = (size_t)src.n_pad * tgt.n_pad;
+            rc = ensure(ctx, ctx->cmat, sizeof(float) * 2 * matElems);
             if (rc != SSYM_OK)
                 return rc;
             float *cmat = (float *)ctx->cmat.ptr;
+            float *xminmat = cmat + matElems;
             SSYM_HIP_CHECK(ctx, hipEventRecord(ev[0], st));
-            rc = launch_dtw_filter(ctx, src, tgt, cmat);
+            rc = launch_dtw_filter(ctx, src, tgt, cmat, xminmat);
             if (rc != SSYM_OK)
                 return rc;
             SSYM_HIP_CHECK(ctx, hipEventRecord(ev[1], st));
@@ -368,7 +370,7 @@ int32_t ssym_match_queries(ssym_ctx *ctx, const ssym_dict *dict, const ssym_quer
             float sel_ms = 0.f, ref_ms = 0.f, red_ms = 0.f;
             for (int attempt = 0; attempt < 2; ++attempt) {
                 SSYM_HIP_CHECK(ctx, hipEventRecord(ev[2], st));
-                rc = launch_dtw_select(ctx, src, tgt, cmat, distDev, (uint32_t)cap);
+                rc = launch_dtw_select(ctx, src, tgt, cmat, xminmat, distDev, (uint32_t)cap);
                 if (rc != SSYM_OK)
                     return rc;
                 SSYM_HIP_CHECK(ctx, hipEventRecord(ev[3], st));
@@ -517,10 +519,11 @@ int32_t ssym_pair_matrix(ssym_ctx *ctx, const ssym_dict *dict, const ssym_querie
             ctx->err = "dtw filter does not cover this shape (band / frames / dim); ask for exact = 1";
             return SSYM_E_UNSUPPORTED;
         }
-        rc = ensure(ctx, ctx->cmat, sizeof(float) * (size_t)src.n_pad * tgt.n_pad);
+        const size_t matElems = (size_t)src.n_pad * tgt.n_pad;
+        rc = ensure(ctx, ctx->cmat, sizeof(float) * 2 * matElems);
         if (rc != SSYM_OK)
             return rc;
-        rc = launch_dtw_filter(ctx, src, tgt, (float *)ctx->cmat.ptr);
+        rc = launch_dtw_filter(ctx, src, tgt, (float *)ctx->cmat.ptr, (float *)ctx->cmat.ptr + matElems);
         if (rc == SSYM_OK) {
             dim3 grid((M + 255) / 256, N);
             f32_to_f64_matrix_kernel<<<grid, 256, 0, st>>>((const float *)ctx->cmat.ptr, N, M, tgt.n_pad, mat);

@@ -134,17 +134,19 @@ static int32_t ensure_records(ssym_ctx *ctx, const SegmentSet &set, double scale
 
 template <int NT, bool SQ>
 static void launch_one(hipStream_t st, const SegmentSet &src, const SegmentSet &tgt, int nPasses,
-                       int gridBlocks, float outScale, float *handoff, float *cmat)
+                       int gridBlocks, float outScale, float outScaleSq, float *handoff, float *cmat,
+                       float *xminmat)
 {
     const int nSrcBlocks = (int)src.n_pad / (2 * kFilterWavesPerBlock);
     const int nTgtGroups = (int)tgt.n_pad / 32;
     const int nTasks = nSrcBlocks * nTgtGroups;
     dtw_filter_kernel<NT, SQ><<<dim3(std::min(gridBlocks, (nTasks + 7) / 8 * 8)), 64 * kFilterWavesPerBlock, 0, st>>>(
         (const _Float16 *)src.rec, (const _Float16 *)tgt.rec, src.len, tgt.len, (int)src.frames_pad, nPasses,
-        (int)tgt.frames_pad, (int)tgt.n_pad, nSrcBlocks, nTasks, outScale, handoff, cmat);
+        (int)tgt.frames_pad, (int)tgt.n_pad, nSrcBlocks, nTasks, outScale, outScaleSq, handoff, cmat, xminmat);
 }
 
-int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, float *cmat)
+int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, float *cmat,
+                          float *xminmat)
 {
     const FilterShape shape = filter_shape((int)src.max_frames);
     if (shape.nt == 0 || (int)src.frames_pad != shape.rows() || src.n_pad % 8 != 0 || tgt.n_pad % 32 != 0) {
@@ -166,12 +168,13 @@ int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
         return rc;
     hipStream_t st = ctx->stream;
     const bool sq = ctx->squared != 0;
-    const float outScale = (float)(sq ? 1.0 / (scale * scale) : 1.0 / scale);
+    const float outScaleSq = (float)(1.0 / (scale * scale));
+    const float outScale = sq ? outScaleSq : (float)(1.0 / scale);
     float *hand = (float *)ctx->handoff.ptr;
 #define SSYM_CASE(NT_)                                                                          \
     case NT_:                                                                                   \
-        if (sq) launch_one<NT_, true>(st, src, tgt, shape.rb, gridBlocks, outScale, hand, cmat);  \
-        else launch_one<NT_, false>(st, src, tgt, shape.rb, gridBlocks, outScale, hand, cmat);    \
+        if (sq) launch_one<NT_, true>(st, src, tgt, shape.rb, gridBlocks, outScale, outScaleSq, hand, cmat, xminmat);  \
+        else launch_one<NT_, false>(st, src, tgt, shape.rb, gridBlocks, outScale, outScaleSq, hand, cmat, xminmat);    \
         break;
     switch (shape.nt) {
         SSYM_CASE(1) SSYM_CASE(2) SSYM_CASE(3) SSYM_CASE(4)

@@ -25,35 +25,49 @@ namespace ssym {
 //    * norms are fed in three f16 pieces (error < 2^-33 relative, negligible);
 //    * accumulation of the 45 products inside three chained K=16 MFMAs, f32 accumulator: at most
 //      48 roundings (counted twice in case the matrix pipe truncates): 2 * 48 u * 2(|a|^2+|b|^2);
-//      together  |x~ - x| <= 204 u (|a|^2 + |b|^2) + 2^-12   -- the code uses 256 u.
-//  local cost c~ = v_sqrt_f32(|x~|) (1 ulp):  |c~ - c| <= sqrt(E) + 2u c,  E = 256u nsum + 2^-12/s^2
-//       (|sqrt(y) - sqrt(x)| <= sqrt(|y - x|));  squared-L2 mode: |c~ - c| <= E.
-//  DP: min is exact, each of the <= Fa+Fb-1 additions along a path rounds once (relative u), and
-//       DTW is monotone and 1-Lipschitz in the cell costs along the optimal path of either side:
-//          |C~ - C| <= P * cell + rho * C,   P = Fa + Fb - 1,  rho = (P + 4) u.
-//  Selection: with s^ the filter's argmin of key = |C~ - delta| and s* the exact one,
-//          key~(s*) <= key~(s^) + 2 P cell + rho (C(s*) + C(s^)),
-//       so every target keeps all s with key~(s) <= keymin~ + margin,
-//          margin = 2.05 P cell + 3.1 rho (delta + keymin~) .
-//  Maxima over the whole dictionary are used for |a|^2 and Fa (more slack).
+//      together  |x~ - x| <= 204 u (|a|^2 + |b|^2) + 2^-12   -- the code uses
+//          E = 256 u (max|a|^2 of the source + max|b|^2 of the target) + 2^-12 / s^2   (unscaled).
+//  local cost c~ = v_sqrt_f32(|x~|):  |c~ - c| = |x~ - x| / (c~ + c).  The kernel reports, per pair,
+//      m = the smallest accumulator value over all of the pair's cells, so every cell has
+//      x~ >= m and x >= m - E:
+//          m > 4E :  |c~ - c| <= E / (2 sqrt(m - E))          (no cell is near zero)
+//          else   :  |c~ - c| <= sqrt(E)                      (|sqrt(y) - sqrt(x)| <= sqrt|y - x|)
+//      squared-L2 mode: |c~ - c| <= E.   Inputs rounded to the f16 pair move c by <= 4u(|a| + |b|).
+//  DP: min is exact; each of the <= L = Fa+Fb-1 additions along a path rounds once and v_sqrt_f32 is
+//      within 1 ulp, and DTW is monotone and 1-Lipschitz in the cell costs along the optimal path
+//      of either side, so for EVERY pair
+//          |C~ - C| <= err := L * cell + (L + 6) u * C~ .
+//  Selection (rigorous): C lies in [C~ - err, C~ + err], hence key = |C - delta| lies in
+//      [key_lo, key_hi]; the exact first minimum over s is attained by some s with
+//      key_lo(s) <= min_s' key_hi(s'), and only those pairs are re-scored exactly.
 // ---------------------------------------------------------------------------------------------
 struct MarginParams {
-    double na_max;      // max_f |a_f|^2 over the dictionary (rounded up), unscaled
     double inv_scale2;  // 1 / s^2
-    int fa_max;
     int squared;
 };
 
-__device__ __forceinline__ double dtw_margin(const MarginParams &mp, double nb_max, int fb,
-                                             double delta, double keymin)
+__device__ __forceinline__ void dtw_key_interval(const MarginParams &mp, double cst, double xmin,
+                                                 double na, double nb, int fa, int fb, double delta,
+                                                 double &key_lo, double &key_hi)
 {
+    const double INF = __builtin_inf();
+    if (!(cst < INF)) {          // unreachable / empty / NaN: never a candidate
+        key_lo = INF;
+        key_hi = INF;
+        return;
+    }
     const double u = 5.9604644775390625e-8;   // 2^-24
-    const double nsum = mp.na_max + nb_max;
-    const double E = 256.0 * u * nsum + 0.000244140625 * mp.inv_scale2;
-    const double cell = mp.squared ? E : sqrt(E) + 2.0 * u * (sqrt(mp.na_max) + sqrt(nb_max));
-    const double P = (double)(mp.fa_max + fb - 1);
-    const double rho = (P + 4.0) * u;
-    return 2.05 * P * cell + 3.1 * rho * (delta + keymin) + 1e-300;
+    const double E = 256.0 * u * (na + nb) + 0.000244140625 * mp.inv_scale2;
+    double cell;
+    if (mp.squared)
+        cell = E + 8.2 * u * (na + nb);
+    else
+        cell = (xmin > 4.0 * E ? E / (2.0 * sqrt(xmin - E)) : sqrt(E)) + 4.0 * u * (sqrt(na) + sqrt(nb));
+    const double L = (double)(fa + fb - 1);
+    const double err = 1.02 * L * cell + (L + 6.0) * u * cst + 1e-300;
+    const double lo = fmax(cst - err, 0.0), hi = cst + err;
+    key_lo = fmax(fmax(lo - delta, delta - hi), 0.0);
+    key_hi = fmax(fabs(lo - delta), fabs(hi - delta));
 }
 
 __global__ void fill_u64_kernel(unsigned long long *p, unsigned long long v, uint32_t n)
@@ -72,48 +86,59 @@ __global__ void fill_u32_kernel(uint32_t *p, uint32_t v, uint32_t n)
 
 constexpr int kSelChunk = 64;   // sources scanned per thread
 
-// key~(s,t) = |C~(s,t) - delta_t|; keymin[t] = min_s key~ as order-preserving u64 bits.
-__global__ __launch_bounds__(256) void dtw_colmin_kernel(const float *__restrict__ cmat, uint32_t nSrc,
-                                                         uint32_t nTgt, uint32_t mPad,
-                                                         const double *__restrict__ dist,
-                                                         unsigned long long *__restrict__ keymin)
+// ub[t] = min_s key_hi(s,t) as order-preserving u64 bits
+__global__ __launch_bounds__(256) void dtw_colmin_kernel(
+    const float *__restrict__ cmat, const float *__restrict__ xminmat, uint32_t nSrc, uint32_t nTgt,
+    uint32_t mPad, const double *__restrict__ dist, const int *__restrict__ srcLen,
+    const float *__restrict__ srcMaxSq, const int *__restrict__ tgtLen, const float *__restrict__ tgtMaxSq,
+    MarginParams mp, unsigned long long *__restrict__ ub)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nTgt)
         return;
     const double delta = dist ? dist[t] : 0.0;
+    const double nb = (double)tgtMaxSq[t];
+    const int fb = tgtLen[t];
     const uint32_t s0 = blockIdx.y * kSelChunk;
     const uint32_t s1 = min(s0 + kSelChunk, nSrc);
     double best = __builtin_inf();
     for (uint32_t s = s0; s < s1; ++s) {
-        const double key = fabs((double)cmat[(size_t)s * mPad + t] - delta);
-        if (key < best)
-            best = key;
+        const size_t o = (size_t)s * mPad + t;
+        double klo, khi;
+        dtw_key_interval(mp, (double)cmat[o], (double)xminmat[o], (double)srcMaxSq[s], nb, srcLen[s], fb, delta,
+                         klo, khi);
+        if (khi < best)
+            best = khi;
     }
     if (best < __builtin_inf())
-        atomicMin(&keymin[t], (unsigned long long)__double_as_longlong(best));
+        atomicMin(&ub[t], (unsigned long long)__double_as_longlong(best));
 }
 
 // cand layout: [0] = count, [1] = overflow flag, pairs start at cand + 2 (as uint2)
 __global__ __launch_bounds__(256) void dtw_select_kernel(
-    const float *__restrict__ cmat, uint32_t nSrc, uint32_t nTgt, uint32_t mPad,
-    const double *__restrict__ dist, const unsigned long long *__restrict__ keymin,
-    const int *__restrict__ tgtLen, const float *__restrict__ tgtMaxSq, MarginParams mp,
-    uint32_t cap, uint32_t *__restrict__ candHdr, uint2 *__restrict__ candPairs)
+    const float *__restrict__ cmat, const float *__restrict__ xminmat, uint32_t nSrc, uint32_t nTgt,
+    uint32_t mPad, const double *__restrict__ dist, const int *__restrict__ srcLen,
+    const float *__restrict__ srcMaxSq, const int *__restrict__ tgtLen, const float *__restrict__ tgtMaxSq,
+    MarginParams mp, const unsigned long long *__restrict__ ub, uint32_t cap,
+    uint32_t *__restrict__ candHdr, uint2 *__restrict__ candPairs)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nTgt)
         return;
-    const double km = __longlong_as_double((long long)keymin[t]);
-    if (!(km < __builtin_inf()))
+    const double thr = __longlong_as_double((long long)ub[t]);
+    if (!(thr < __builtin_inf()))
         return;   // no finite cost for this target: the fold keeps (0, +inf)
     const double delta = dist ? dist[t] : 0.0;
-    const double thr = km + dtw_margin(mp, (double)tgtMaxSq[t], tgtLen[t], delta, km);
+    const double nb = (double)tgtMaxSq[t];
+    const int fb = tgtLen[t];
     const uint32_t s0 = blockIdx.y * kSelChunk;
     const uint32_t s1 = min(s0 + kSelChunk, nSrc);
     for (uint32_t s = s0; s < s1; ++s) {
-        const double key = fabs((double)cmat[(size_t)s * mPad + t] - delta);
-        if (key <= thr) {
+        const size_t o = (size_t)s * mPad + t;
+        double klo, khi;
+        dtw_key_interval(mp, (double)cmat[o], (double)xminmat[o], (double)srcMaxSq[s], nb, srcLen[s], fb, delta,
+                         klo, khi);
+        if (klo <= thr) {
             const uint32_t slot = atomicAdd(&candHdr[0], 1u);
             if (slot < cap)
                 candPairs[slot] = make_uint2(s, t);
@@ -271,13 +296,11 @@ __global__ void merge_shards_kernel(uint32_t nShards, uint32_t nTgt, const doubl
 // host side
 // ---------------------------------------------------------------------------------------------
 int32_t launch_dtw_select(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt,
-                          const float *cmat, const double *dist_dev, uint32_t cap)
+                          const float *cmat, const float *xminmat, const double *dist_dev, uint32_t cap)
 {
     hipStream_t st = ctx->stream;
     MarginParams mp;
-    mp.na_max = src.max_sqnorm_all;
     mp.inv_scale2 = src.rec_scale > 0.0 ? 1.0 / (src.rec_scale * src.rec_scale) : 1.0;
-    mp.fa_max = (int)src.max_frames;
     mp.squared = ctx->squared;
     int32_t rc = ensure(ctx, ctx->tmin, sizeof(unsigned long long) * tgt.n);
     if (rc != SSYM_OK)
@@ -285,16 +308,17 @@ int32_t launch_dtw_select(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
     rc = ensure(ctx, ctx->cand, sizeof(uint32_t) * 2 + sizeof(uint2) * (size_t)cap);
     if (rc != SSYM_OK)
         return rc;
-    unsigned long long *keymin = (unsigned long long *)ctx->tmin.ptr;
+    unsigned long long *ub = (unsigned long long *)ctx->tmin.ptr;
     uint32_t *hdr = (uint32_t *)ctx->cand.ptr;
     uint2 *pairs = (uint2 *)(hdr + 2);
     const unsigned long long infBits = 0x7ff0000000000000ull;
-    fill_u64_kernel<<<(tgt.n + 255) / 256, 256, 0, st>>>(keymin, infBits, tgt.n);
+    fill_u64_kernel<<<(tgt.n + 255) / 256, 256, 0, st>>>(ub, infBits, tgt.n);
     SSYM_HIP_CHECK(ctx, hipMemsetAsync(hdr, 0, sizeof(uint32_t) * 2, st));
     dim3 grid((tgt.n + 255) / 256, (src.n + kSelChunk - 1) / kSelChunk);
-    dtw_colmin_kernel<<<grid, 256, 0, st>>>(cmat, src.n, tgt.n, tgt.n_pad, dist_dev, keymin);
-    dtw_select_kernel<<<grid, 256, 0, st>>>(cmat, src.n, tgt.n, tgt.n_pad, dist_dev, keymin, tgt.len,
-                                            tgt.max_sqnorm, mp, cap, hdr, pairs);
+    dtw_colmin_kernel<<<grid, 256, 0, st>>>(cmat, xminmat, src.n, tgt.n, tgt.n_pad, dist_dev, src.len,
+                                            src.max_sqnorm, tgt.len, tgt.max_sqnorm, mp, ub);
+    dtw_select_kernel<<<grid, 256, 0, st>>>(cmat, xminmat, src.n, tgt.n, tgt.n_pad, dist_dev, src.len,
+                                            src.max_sqnorm, tgt.len, tgt.max_sqnorm, mp, ub, cap, hdr, pairs);
     SSYM_HIP_CHECK(ctx, hipGetLastError());
     return SSYM_OK;
 }

@@ -115,7 +115,7 @@ void free_segments(SegmentSet &set);
 // dtw_filter.hip
 bool filter_supported(const ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt);
 int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt,
-                          float *cmat /*[src.n_pad][tgt.n_pad]*/);
+                          float *cmat /*[src.n_pad][tgt.n_pad]*/, float *xminmat /*same shape*/);
 
 // dtw_exact.hip
 // pairs == nullptr: every (s,t) pair, out[s*n_tgt + t]; else out[k] for pairs[k] with k < *count
@@ -130,7 +130,7 @@ struct SelectParams {
     float cell_err_scale;   // see select.hip
 };
 int32_t launch_dtw_select(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt,
-                          const float *cmat, const double *dist_dev, uint32_t cap);
+                          const float *cmat, const float *xminmat, const double *dist_dev, uint32_t cap);
 int32_t launch_dtw_final(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt,
                          const double *dist_dev, uint32_t cap, uint32_t index_base,
                          uint32_t *out_idx_dev, double *out_cost_dev);

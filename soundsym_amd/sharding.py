@@ -37,10 +37,20 @@ def gather_candidates(cost, idx, group=None):
         return cost.reshape(1, -1), idx.reshape(1, -1)
     world = dist.get_world_size(group)
     m = cost.numel()
-    costs = torch.empty(world * m, dtype=cost.dtype, device=cost.device)
-    idxs = torch.empty(world * m, dtype=idx.dtype, device=idx.device)
-    dist.all_gather_into_tensor(costs, cost.contiguous().reshape(-1), group=group)
-    dist.all_gather_into_tensor(idxs, idx.contiguous().reshape(-1), group=group)
+    dev = cost.device
+    # gloo (CPU rehearsal of the exchange, also with GPU-resident results) moves bytes through host
+    # memory; nccl (= RCCL over xGMI) gathers device to device
+    via_host = dist.get_backend(group) == "gloo" and cost.is_cuda
+    src_c = cost.contiguous().reshape(-1)
+    src_i = idx.contiguous().reshape(-1)
+    if via_host:
+        src_c, src_i = src_c.cpu(), src_i.cpu()
+    costs = torch.empty(world * m, dtype=cost.dtype, device=src_c.device)
+    idxs = torch.empty(world * m, dtype=idx.dtype, device=src_i.device)
+    dist.all_gather_into_tensor(costs, src_c, group=group)
+    dist.all_gather_into_tensor(idxs, src_i, group=group)
+    if via_host:
+        costs, idxs = costs.to(dev), idxs.to(dev)
     return costs.view(world, m), idxs.view(world, m)
 
 

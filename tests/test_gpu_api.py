@@ -69,3 +69,16 @@ def test_dictionary_on_the_dtw_engine(oracle):
     want, _ = oracle.dtw_match_all(flat, off, pf, po, NCOEFFS)
     assert d.match_sound(probe) is d.sounds[int(want[0])]
     e.close()
+
+
+def test_cpp_mirror_reads_like_the_reference_tests():
+    """include/soundsym.hpp driven by tests/cpp/test_mirror.cpp (built by __graft_entry__.build())."""
+    import os
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = os.path.join(here, "cpp", "test_mirror")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(here, "cpp")])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all checks passed" in r.stdout

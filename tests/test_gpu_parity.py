@@ -230,6 +230,23 @@ def test_dtw_grid_vs_oracle(dtw, oracle, n, m, f, dim):
         assert np.array_equal(idx, g.planted)
 
 
+def test_dtw_unplanted_targets_keep_the_candidate_set_small(dtw, oracle):
+    # targets that have NO near-identical source (what a rank sees when a target's neighbour lives in
+    # another shard): all costs are of similar size, and only the per-pair error bound -- built on
+    # the smallest cell the filter saw in each pair -- keeps the exact re-scoring to a few pairs
+    src = synth.make_grid(192, 1, 64, 13, 0x5EED0350).sources
+    tgt = synth.make_grid(96, 1, 64, 13, 0x5EED0351).sources
+    so = np.arange(src.shape[0] + 1, dtype=np.uint64) * 64
+    to = np.arange(tgt.shape[0] + 1, dtype=np.uint64) * 64
+    sf, tf = src.reshape(-1), tgt.reshape(-1)
+    idx, cost = dtw.match(dtw.dictionary(sf, so, 13), dtw.queries(tf, to, 13))
+    tm = dtw.timings()
+    want_idx, want_cost = oracle.dtw_match_all(sf.astype(np.float64), so, tf.astype(np.float64), to, 13, nthreads=8)
+    assert np.array_equal(idx, want_idx)
+    assert np.allclose(cost, want_cost, rtol=EXACT_RTOL, atol=0)
+    assert tm["used_filter"] == 1 and tm["n_refined"] <= 3 * tgt.shape[0], tm
+
+
 def test_dtw_ties_take_the_lowest_index(dtw, oracle):
     g = synth.make_grid(24, 8, 20, 13, 0x5EED0310)
     g.sources[19] = g.sources[3]                   # exact duplicates among the sources

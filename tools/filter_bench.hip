@@ -26,11 +26,11 @@ int run(int N, int M, int F, int reps, int blocksPerCU)
     for (auto &v : hs) v = (_Float16)(4.0f * rnd());
     for (auto &v : ht) v = (_Float16)(4.0f * rnd());
     std::vector<int> ls(N, F), lt(M, F);
-    _Float16 *ds, *dt; float *dc, *dh; int *dls, *dlt;
+    _Float16 *ds, *dt; float *dc, *dc2, *dh; int *dls, *dlt;
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
     const int grid = prop.multiProcessorCount * blocksPerCU / 8 * 8;
     CK(hipMalloc(&ds, hs.size() * 2)); CK(hipMalloc(&dt, ht.size() * 2));
-    CK(hipMalloc(&dc, (size_t)N * M * 4)); CK(hipMalloc(&dls, N * 4)); CK(hipMalloc(&dlt, M * 4));
+    CK(hipMalloc(&dc, (size_t)N * M * 4)); CK(hipMalloc(&dc2, (size_t)N * M * 4)); CK(hipMalloc(&dls, N * 4)); CK(hipMalloc(&dlt, M * 4));
     CK(hipMalloc(&dh, (size_t)grid * kFilterWavesPerBlock * F * 64 * 4));
     CK(hipMemcpy(ds, hs.data(), hs.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(dt, ht.data(), ht.size() * 2, hipMemcpyHostToDevice));
@@ -41,7 +41,7 @@ int run(int N, int M, int F, int reps, int blocksPerCU)
     const int nTasks = nSrcBlocks * (M / 32);
     auto launch = [&]() {
         dtw_filter_kernel<NT, SSYM_TOOL_SQ><<<grid, 64 * kFilterWavesPerBlock>>>(ds, dt, dls, dlt, rows, nPasses, F, M, nSrcBlocks,
-                                                                         nTasks, 1.0f, dh, dc);
+                                                                         nTasks, 1.0f, 1.0f, dh, dc, dc2);
     };
     for (int w = 0; w < 2; ++w) launch();
     CK(hipDeviceSynchronize());
