@@ -93,8 +93,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # SSYM_BENCH_FORCE_DIST=1: run the collective code path (RCCL init, all-gather, merge) even with
+    # one rank -- a smoke check of the N > 1 plumbing on a single-GPU box
+    force_dist = os.environ.get("SSYM_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.gpus > 1 and world == 1:
         sys.exit("bench.py --gpus N > 1 must be launched with `python -m torch.distributed.run "
@@ -103,7 +107,7 @@ def main():
     backend = os.environ.get("SSYM_BENCH_BACKEND", "nccl")
     local_rank = local_rank % max(torch.cuda.device_count(), 1) if backend == "gloo" else local_rank
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or force_dist:
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local_rank))
@@ -128,7 +132,7 @@ def main():
 
     def step():
         eng.match(d, q, index_base=lo, out_idx=out_idx, out_cost=out_cost)
-        if world > 1:
+        if world > 1 or force_dist:
             costs, idxs = sharding.gather_candidates(out_cost, out_idx)
             return sharding.merge_shards(eng, costs, idxs)
         return out_idx, out_cost
@@ -227,7 +231,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(grid, idx_host)
         print(json.dumps(line), flush=True)
     eng.close()
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

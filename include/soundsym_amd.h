@@ -54,6 +54,7 @@ extern "C" {
 typedef struct ssym_ctx ssym_ctx;         /* one GPU + one stream + scratch                      */
 typedef struct ssym_dict ssym_dict;       /* SoundDictionary's feature side (src/sound.rs:290)   */
 typedef struct ssym_queries ssym_queries; /* the targets of one batch (SoundSequence::sounds)    */
+typedef struct ssym_samples ssym_samples; /* the dictionary sounds' SAMPLES, resident on the GPU   */
 
 enum {
     SSYM_OK = 0,
@@ -177,6 +178,26 @@ SSYM_API int32_t ssym_pair_matrix(ssym_ctx *ctx, const ssym_dict *dict, const ss
 SSYM_API int32_t ssym_merge_shards(ssym_ctx *ctx, uint32_t n_shards, uint32_t n_targets,
                           const double *costs_dev, const uint32_t *idx_dev, uint32_t *out_idx_dev,
                           double *out_cost_dev);
+
+/* Reconstruction tail (the step right after the hot path): the samples of every dictionary sound,
+ * resident on the GPU (Sound::samples(), src/sound.rs:181; `sample_offsets` = n_sounds+1 SAMPLE
+ * offsets into `samples`, f64, HOST memory). */
+SSYM_API int32_t ssym_samples_create(ssym_ctx *ctx, const double *samples, const uint64_t *sample_offsets,
+                            uint32_t n_sounds, ssym_samples **out);
+SSYM_API int32_t ssym_samples_destroy(ssym_ctx *ctx, ssym_samples *s);
+
+/* clone_from_dictionary's length fit (src/sound.rs:456-465) + to_sound's concatenation (:475-480):
+ * for target t the samples of dictionary sound idx[t], zero-padded or truncated to
+ * out_offsets[t+1]-out_offsets[t] samples, written at out_offsets[t].
+ *   idx          n_targets dictionary indices (HOST), as returned by ssym_match_*
+ *   out_offsets  n_targets+1 SAMPLE offsets of the output (HOST); out_offsets[0] must be 0
+ *   out_samples  nullable, out_offsets[n] f64 (HOST)
+ *   out_pcm32    nullable, out_offsets[n] i32 (HOST): Sound::write_file's conversion
+ *                `(i32::MAX as f64 * sample) as i32` (src/sound.rs:139; truncating, saturating,
+ *                NaN -> 0) */
+SSYM_API int32_t ssym_reconstruct(ssym_ctx *ctx, const ssym_samples *s, const uint32_t *idx,
+                         const uint64_t *out_offsets, uint32_t n_targets, double *out_samples,
+                         int32_t *out_pcm32);
 
 #ifdef __cplusplus
 }

@@ -68,6 +68,10 @@ class Oracle:
                                                    _i64p, _f64p]
         L.ssym_oracle_length_fit.restype = None
         L.ssym_oracle_length_fit.argtypes = [_f64p, ctypes.c_uint64, ctypes.c_uint64, _f64p]
+        L.ssym_oracle_reconstruct.restype = None
+        L.ssym_oracle_reconstruct.argtypes = [_f64p, _u64p, _i64p, _u64p, ctypes.c_uint32, _f64p]
+        L.ssym_oracle_pcm32.restype = ctypes.c_int32
+        L.ssym_oracle_pcm32.argtypes = [ctypes.c_double]
         L.ssym_oracle_dtw.restype = ctypes.c_double
         L.ssym_oracle_dtw.argtypes = [_f64p, ctypes.c_uint64, _f64p, ctypes.c_uint64,
                                       ctypes.c_uint32, ctypes.c_int64, ctypes.c_int]
@@ -129,6 +133,20 @@ class Oracle:
         self.lib.ssym_oracle_length_fit(_ptr(matched, _f64p), matched.size, n_target,
                                         _ptr(out, _f64p))
         return out
+
+    def reconstruct(self, src_samples, src_off, idx, out_off) -> np.ndarray:
+        src_samples = np.ascontiguousarray(src_samples, dtype=np.float64)
+        src_off = np.ascontiguousarray(src_off, dtype=np.uint64)
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        out_off = np.ascontiguousarray(out_off, dtype=np.uint64)
+        out = np.empty(int(out_off[-1]), dtype=np.float64)
+        self.lib.ssym_oracle_reconstruct(_ptr(src_samples, _f64p), _ptr(src_off, _u64p), _ptr(idx, _i64p),
+                                         _ptr(out_off, _u64p), idx.size, _ptr(out, _f64p))
+        return out
+
+    def pcm32(self, samples) -> np.ndarray:
+        return np.array([self.lib.ssym_oracle_pcm32(float(v)) for v in np.asarray(samples).reshape(-1)],
+                        dtype=np.int32)
 
     # -- dtw ------------------------------------------------------------------------------
     def dtw(self, a, b, dim, band: int = -1, squared: bool = False) -> float:

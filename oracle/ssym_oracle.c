@@ -12,6 +12,7 @@
  *             src/sound.rs:351-370 at_distance     (|sim - distance|, fold (0, 2.0), strict <)
  *             src/sound.rs:451-455 clone_from_dictionary (one match_sound per target, in order)
  *             src/sound.rs:456-465 length fit of the matched samples (zero-pad / truncate)
+ *             src/sound.rs:475-480 to_sound concatenation, :139 write_file sample conversion
  *   third-party arithmetic on the path: `rulinalg::utils::dot`, crate rulinalg = "0.4.2"
  *             (Cargo.toml:15; call site src/sound.rs:31).  Its source is NOT under
  *             /root/reference; the published 0.4.2 algorithm is restated in ssym_oracle_dot below.
@@ -156,6 +157,34 @@ SSYM_ORACLE_API void ssym_oracle_length_fit(const double *matched, uint64_t n_ma
     memcpy(out, matched, (size_t)ncopy * sizeof(double));
     for (uint64_t i = ncopy; i < n_target; ++i)
         out[i] = 0.0;
+}
+
+/* The tail of clone_from_dictionary + to_sound (src/sound.rs:456-465, 475-480): every matched
+ * sound's samples fitted to its target's sample count, concatenated in target order.
+ * src_off / out_off are SAMPLE offsets (n+1 entries each). */
+SSYM_ORACLE_API void ssym_oracle_reconstruct(const double *src_samples, const uint64_t *src_off,
+                                             const int64_t *idx, const uint64_t *out_off,
+                                             uint32_t n_tgt, double *out)
+{
+    for (uint32_t t = 0; t < n_tgt; ++t) {
+        const uint64_t s = (uint64_t)idx[t];
+        ssym_oracle_length_fit(src_samples + src_off[s], src_off[s + 1] - src_off[s],
+                               out_off[t + 1] - out_off[t], out + out_off[t]);
+    }
+}
+
+/* Sound::write_file's sample conversion, src/sound.rs:139: `(i32::max_value() as f64 * sample) as
+ * i32` -- Rust's float-to-int `as` truncates toward zero, saturates, and maps NaN to 0. */
+SSYM_ORACLE_API int32_t ssym_oracle_pcm32(double sample)
+{
+    double v = 2147483647.0 * sample;
+    if (v != v)
+        return 0;
+    if (v >= 2147483647.0)
+        return INT32_MAX;
+    if (v <= -2147483648.0)
+        return INT32_MIN;
+    return (int32_t)v;
 }
 
 /* ------------------------------------------------------------------------------------------

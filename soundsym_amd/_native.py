@@ -36,7 +36,8 @@ ABI_SYMBOLS = [
     "ssym_ctx_synchronize", "ssym_get_timings", "ssym_dict_create", "ssym_dict_create_device",
     "ssym_dict_append", "ssym_dict_size", "ssym_dict_destroy", "ssym_queries_create",
     "ssym_queries_create_device", "ssym_queries_destroy", "ssym_match_queries", "ssym_match_batch",
-    "ssym_match_one", "ssym_pair_matrix", "ssym_merge_shards",
+    "ssym_match_one", "ssym_pair_matrix", "ssym_merge_shards", "ssym_samples_create",
+    "ssym_samples_destroy", "ssym_reconstruct",
 ]
 
 
@@ -161,6 +162,12 @@ def lib() -> ctypes.CDLL:
     L.ssym_pair_matrix.argtypes = [vp, vp, vp, i32, vp]
     L.ssym_merge_shards.restype = i32
     L.ssym_merge_shards.argtypes = [vp, u32, u32, vp, vp, vp, vp]
+    L.ssym_samples_create.restype = i32
+    L.ssym_samples_create.argtypes = [vp, vp, vp, u32, pvp]
+    L.ssym_samples_destroy.restype = i32
+    L.ssym_samples_destroy.argtypes = [vp, vp]
+    L.ssym_reconstruct.restype = i32
+    L.ssym_reconstruct.argtypes = [vp, vp, vp, vp, u32, vp, vp]
     _lib = L
     return L
 

@@ -136,6 +136,16 @@ class SoundDictionary:
             self._resident_n = len(self.sounds)
         return self._resident
 
+    def resident_samples(self):
+        """The sounds' samples on the GPU, for the reconstruction tail (ssym_samples_create)."""
+        if getattr(self, "_samples_res", None) is None or self._samples_n != len(self.sounds):
+            smp = [s.samples() for s in self.sounds]
+            off = np.concatenate([[0], np.cumsum([x.size for x in smp])]).astype(np.uint64)
+            flat = np.concatenate(smp) if smp else np.zeros(0)
+            self._samples_res = self.engine.samples(flat, off)
+            self._samples_n = len(self.sounds)
+        return self._samples_res
+
     # queries ------------------------------------------------------------------------------------
     def match_sound(self, other: Sound) -> Sound:                       # src/sound.rs:346
         if not self.sounds:
@@ -214,6 +224,17 @@ class SoundSequence:
                 out.append(Sound(length_fit(s.samples(), sound.samples().size), sound.sample_rate(),
                                  None, None, s.ncoeffs))
         return SoundSequence(out)
+
+    def reconstruct_from_dictionary(self, dict_: "SoundDictionary", want_pcm32: bool = False):
+        """clone_from_dictionary(dict).to_sound().samples() in one go (src/sound.rs:451-480): match
+        on the GPU, then gather / length-fit / concatenate on the GPU (ssym_reconstruct), optionally
+        with write_file's 32-bit conversion (:139)."""
+        if not self._sounds:
+            return (np.zeros(0), np.zeros(0, dtype=np.int32)) if want_pcm32 else np.zeros(0)
+        idx, _ = dict_.match_indices(self._sounds, None)
+        lens = np.array([s.samples().size for s in self._sounds], dtype=np.uint64)
+        out_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        return dict_.engine.reconstruct(dict_.resident_samples(), idx, out_off, want_pcm32)
 
     def to_sound(self) -> Sound:                                        # src/sound.rs:475-483
         parts = [s.samples() for s in self._sounds]

@@ -50,6 +50,22 @@ class _Handle:
             pass
 
 
+class _SamplesHandle:
+    def __init__(self, engine, ptr, n):
+        self.engine, self.ptr, self.n = engine, ptr, n
+
+    def close(self):
+        if self.ptr and self.engine.ctx:
+            nat.lib().ssym_samples_destroy(self.engine.ctx, self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Engine:
     """One ssym_ctx: one GPU, one stream, one metric / dtype configuration."""
 
@@ -175,6 +191,28 @@ class Engine:
         nat.check(nat.lib().ssym_pair_matrix(self.ctx, d.ptr, q.ptr, 1 if exact else 0,
                                              out.ctypes.data), self.ctx)
         return out
+
+    # -- reconstruction tail (F2) ------------------------------------------------------------
+    def samples(self, samples, sample_offsets):
+        """Make the dictionary sounds' samples resident (ssym_samples_create)."""
+        smp = np.ascontiguousarray(samples, dtype=np.float64).reshape(-1)
+        off = np.ascontiguousarray(sample_offsets, dtype=np.uint64)
+        out = ctypes.c_void_p()
+        nat.check(nat.lib().ssym_samples_create(self.ctx, smp.ctypes.data, off.ctypes.data, off.size - 1,
+                                                ctypes.byref(out)), self.ctx)
+        return _SamplesHandle(self, out.value, off.size - 1)
+
+    def reconstruct(self, smp, idx, out_offsets, want_pcm32: bool = False):
+        """Length-fitted, concatenated samples of the matched sounds (ssym_reconstruct)."""
+        idx = np.ascontiguousarray(idx, dtype=np.uint32)
+        off = np.ascontiguousarray(out_offsets, dtype=np.uint64)
+        total = int(off[-1])
+        out = np.zeros(total, dtype=np.float64)
+        pcm = np.zeros(total, dtype=np.int32) if want_pcm32 else None
+        nat.check(nat.lib().ssym_reconstruct(self.ctx, smp.ptr, idx.ctypes.data, off.ctypes.data, idx.size,
+                                             out.ctypes.data, pcm.ctypes.data if pcm is not None else None),
+                  self.ctx)
+        return (out, pcm) if want_pcm32 else out
 
     def merge_shards(self, costs, idx, out_idx, out_cost) -> None:
         """costs [G, M] f64, idx [G, M] 32-bit, outputs [M]: torch CUDA tensors on this GPU."""

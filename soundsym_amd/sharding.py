@@ -33,7 +33,7 @@ def gather_candidates(cost, idx, group=None):
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return cost.reshape(1, -1), idx.reshape(1, -1)
     world = dist.get_world_size(group)
     m = cost.numel()

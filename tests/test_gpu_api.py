@@ -82,3 +82,30 @@ def test_cpp_mirror_reads_like_the_reference_tests():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all checks passed" in r.stdout
+
+
+def test_reconstruction_tail_on_the_gpu(oracle):
+    """ssym_reconstruct: gather + length fit + concatenation + 32-bit conversion, bit-exact."""
+    from oracle.oracle import pack_segments
+    src = _parent(90, 0x5EED0410)
+    tgt = _parent(50, 0x5EED0411)
+    d = SoundDictionary.from_segments(src, [HOP * k for k in (4, 6, 3, 9, 5, 7, 2, 8, 6, 5, 4, 3, 7, 9, 6)])
+    td = SoundDictionary.from_segments(tgt, [HOP * k for k in (5, 5, 7, 3, 6, 4, 8, 2, 10)])
+    seq = SoundSequence.new(td.sounds)
+    got, pcm = seq.reconstruct_from_dictionary(d, want_pcm32=True)
+    want_seq = seq.clone_from_dictionary(d).to_sound().samples()     # host path of the mirror
+    assert np.array_equal(got, want_seq)
+    flat, off = pack_segments([s.mfccs() for s in d.sounds], NCOEFFS)
+    tflat, toff = pack_segments([s.mfccs() for s in td.sounds], NCOEFFS)
+    idx, _ = oracle.refcos_match_all(flat, off, tflat, toff, NCOEFFS)
+    smp = np.concatenate([s.samples() for s in d.sounds])
+    soff = np.concatenate([[0], np.cumsum([s.samples().size for s in d.sounds])]).astype(np.uint64)
+    ooff = np.concatenate([[0], np.cumsum([s.samples().size for s in td.sounds])]).astype(np.uint64)
+    assert np.array_equal(got, oracle.reconstruct(smp, soff, idx, ooff))
+    # conversion: scale some samples past full scale to hit the saturation branches
+    e = d.engine
+    big = np.array([0.0, 0.25, -0.25, 1.0, 1.5, -1.5, np.nan, 3e-10, -0.9999999999])
+    h = e.samples(big, [0, big.size])
+    out, q = e.reconstruct(h, [0], [0, big.size + 2], want_pcm32=True)
+    assert np.array_equal(q[:big.size], oracle.pcm32(big)) and q[big.size:].tolist() == [0, 0]
+    assert np.array_equal(out[:big.size][~np.isnan(big)], big[~np.isnan(big)])

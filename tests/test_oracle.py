@@ -117,3 +117,13 @@ def test_length_fit(oracle):
     assert np.array_equal(oracle.length_fit(m, 8), [1, 2, 3, 4, 5, 0, 0, 0])   # src/sound.rs:457-459
     assert np.array_equal(oracle.length_fit(m, 3), [1, 2, 3])                  # src/sound.rs:460-462
     assert np.array_equal(oracle.length_fit(m, 5), m)                          # src/sound.rs:463-464
+
+
+def test_reconstruct_and_pcm32(oracle):
+    # src/sound.rs:456-465 + :475-480 on three targets; :139 conversion incl. saturation and NaN
+    src = np.arange(1, 11, dtype=np.float64)             # sounds: [1,2,3], [4..10]
+    src_off = np.array([0, 3, 10], dtype=np.uint64)
+    out = oracle.reconstruct(src, src_off, [1, 0, 0], np.array([0, 2, 7, 10], dtype=np.uint64))
+    assert out.tolist() == [4, 5, 1, 2, 3, 0, 0, 1, 2, 3]
+    assert oracle.pcm32([0.0, 0.5, -0.5, 1.0, 2.0, -2.0, float("nan"), 1e-10]).tolist() == [
+        0, 1073741823, -1073741823, 2147483647, 2147483647, -2147483648, 0, 0]
