@@ -346,6 +346,54 @@ def test_dtw_edge_cases(dtw, oracle):
     assert np.array_equal(idx_b, want_idx + 1000)
 
 
+def test_dtw_degenerate_values(oracle):
+    e = Engine(metric="dtw", dtype="f32")
+    # all zeros: every cost is 0, the first minimum is index 0
+    z = np.zeros((5, 9, 13), dtype=np.float32)
+    so = np.arange(6, dtype=np.uint64) * 9
+    idx, cost = e.match(e.dictionary(z.reshape(-1), so, 13), e.queries(z[:3].reshape(-1), so[:4], 13))
+    assert idx.tolist() == [0, 0, 0] and cost.tolist() == [0.0, 0.0, 0.0]
+    # wide dynamic range: large values next to tiny ones (common scale, f16 pieces, subnormal tails)
+    g = synth.make_grid(40, 24, 30, 13, 0x5EED0360)
+    src = g.sources.copy()
+    tgt = g.targets.copy()
+    src[::3] *= 4096.0
+    tgt[::2] *= 1e-3
+    sf, tf = src.reshape(-1), tgt.reshape(-1)
+    so = np.arange(41, dtype=np.uint64) * 30
+    to = np.arange(25, dtype=np.uint64) * 30
+    idx, cost = e.match(e.dictionary(sf, so, 13), e.queries(tf, to, 13))
+    assert e.timings()["used_filter"] == 1
+    want_idx, want_cost = oracle.dtw_match_all(sf.astype(np.float64), so, tf.astype(np.float64), to, 13)
+    assert np.array_equal(idx, want_idx) and np.allclose(cost, want_cost, rtol=EXACT_RTOL, atol=0)
+    # non-finite features: the filter steps aside, the exact kernel keeps IEEE semantics
+    bad = g.sources.copy()
+    bad[3, 5, 2] = np.nan
+    bad[7, 0, 0] = np.inf
+    idx, cost = e.match(e.dictionary(bad.reshape(-1), so, 13), e.queries(g.targets.reshape(-1), to, 13))
+    assert e.timings()["used_filter"] == 0
+    want_idx, want_cost = oracle.dtw_match_all(bad.reshape(-1).astype(np.float64), so,
+                                               g.targets.reshape(-1).astype(np.float64), to, 13)
+    assert np.array_equal(idx, want_idx) and np.array_equal(cost, want_cost)
+    e.close()
+
+
+def test_dtw_dictionary_append_and_device_create(oracle):
+    import torch
+    e = Engine(metric="dtw", dtype="f32")
+    g = synth.make_grid(30, 10, 20, 13, 0x5EED0361)
+    sf, so = g.flat("sources")
+    tf, to = g.flat("targets")
+    d = e.dictionary(sf[:10 * 20 * 13], so[:11], 13)
+    e.dictionary_append(d, sf[10 * 20 * 13:], so[10:] - so[10])       # add_segments: indices continue
+    assert d.n == 30
+    q = e.queries(torch.from_numpy(tf).cuda(), to, 13)                  # device-resident targets
+    idx, cost = e.match(d, q)
+    want_idx, want_cost = oracle.dtw_match_all(sf.astype(np.float64), so, tf.astype(np.float64), to, 13)
+    assert np.array_equal(idx, want_idx) and np.allclose(cost, want_cost, rtol=EXACT_RTOL, atol=0)
+    e.close()
+
+
 def test_merge_shards_kernel(dtw):
     import torch
     from soundsym_amd import sharding
