@@ -24,7 +24,7 @@ namespace ssym {
 // |a|^2 = +inf so that their DP rows stay at +inf.
 __global__ void build_filter_records_kernel(const double *__restrict__ raw, const uint64_t *__restrict__ off,
                                             uint32_t n, uint32_t dim, uint32_t frames_pad, int is_source,
-                                            double scale, _Float16 *__restrict__ rec)
+                                            int pieces, double scale, _Float16 *__restrict__ rec)
 {
     const uint32_t s = blockIdx.y;                              // < n_pad
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
@@ -42,7 +42,8 @@ __global__ void build_filter_records_kernel(const double *__restrict__ raw, cons
             real = true;
             f = slot - (frames_pad - nf);
         } else {
-            out[filter_slot_offset(39)] = (_Float16)__builtin_inff();   // pad row: cost +inf
+            out[filter_slot_offset((is_source ? 0 : 3) + (pieces == 2 ? 3 : 1) * (int)dim)] =
+                (_Float16)__builtin_inff();                               // pad row: |a|^2 = +inf
         }
     } else if (slot < nf) {
         real = true;
@@ -54,24 +55,23 @@ __global__ void build_filter_records_kernel(const double *__restrict__ raw, cons
         for (uint32_t e = 0; e < dim; ++e) {
             const double v = p[e] * scale;                       // exact: scale is a power of two
             const _Float16 h1 = (_Float16)v;
-            const _Float16 h2 = (_Float16)(v - (double)h1);
+            const _Float16 h2 = pieces == 2 ? (_Float16)(v - (double)h1) : (_Float16)0.0f;
             const double vh = (double)h1 + (double)h2;           // the value the MFMA will see
-            nrm += vh * vh;
-            if (is_source) {
-                const _Float16 m1 = (_Float16)(-2.0f * (float)h1), m2 = (_Float16)(-2.0f * (float)h2);
-                out[filter_slot_offset(3 * e + 0)] = m1;
-                out[filter_slot_offset(3 * e + 1)] = m1;
-                out[filter_slot_offset(3 * e + 2)] = m2;
+            nrm += vh * vh;                                      // norms of the REPRESENTED frame
+            const _Float16 m1 = (_Float16)(-2.0f * (float)h1), m2 = (_Float16)(-2.0f * (float)h2);
+            if (pieces == 2) {
+                out[filter_slot_offset(3 * e + 0)] = is_source ? m1 : h1;
+                out[filter_slot_offset(3 * e + 1)] = is_source ? m1 : h2;
+                out[filter_slot_offset(3 * e + 2)] = is_source ? m2 : h1;
             } else {
-                out[filter_slot_offset(3 * e + 0)] = h1;
-                out[filter_slot_offset(3 * e + 1)] = h2;
-                out[filter_slot_offset(3 * e + 2)] = h1;
+                out[filter_slot_offset(e)] = is_source ? m1 : h1;
             }
         }
         const _Float16 p1 = (_Float16)nrm;
         const _Float16 p2 = (_Float16)(nrm - (double)p1);
         const _Float16 p3 = (_Float16)(nrm - (double)p1 - (double)p2);
-        const int mine = is_source ? 39 : 42, other = is_source ? 42 : 39;
+        const int nbase = (pieces == 2 ? 3 : 1) * (int)dim;
+        const int mine = nbase + (is_source ? 0 : 3), other = nbase + (is_source ? 3 : 0);
         out[filter_slot_offset(mine + 0)] = p1;
         out[filter_slot_offset(mine + 1)] = p2;
         out[filter_slot_offset(mine + 2)] = p3;
@@ -89,7 +89,7 @@ bool filter_supported(const ssym_ctx *ctx, const SegmentSet &src, const SegmentS
 {
     if (ctx->band >= 0)
         return false;   // banded shapes run on the exact kernel (DESIGN.md "limits")
-    if (src.dim != tgt.dim || (int)src.dim > kFilterMaxDim)
+    if (src.dim != tgt.dim || (int)src.dim > kFilterMaxDim1)
         return false;
     if (filter_shape((int)src.max_frames).nt == 0)
         return false;   // more than 512 source frames
@@ -125,7 +125,8 @@ static int32_t ensure_records(ssym_ctx *ctx, const SegmentSet &set, double scale
     set.rec_bytes = bytes;
     dim3 grid((set.frames_pad + 63) / 64, set.n_pad);
     build_filter_records_kernel<<<grid, 64, 0, ctx->stream>>>(set.raw, set.off, set.n, set.dim,
-                                                              set.frames_pad, set.is_source ? 1 : 0, scale,
+                                                              set.frames_pad, set.is_source ? 1 : 0,
+                                                              filter_pieces((int)set.dim), scale,
                                                               (_Float16 *)set.rec);
     SSYM_HIP_CHECK(ctx, hipGetLastError());
     set.rec_scale = scale;

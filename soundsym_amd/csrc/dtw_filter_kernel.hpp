@@ -11,7 +11,9 @@
 //     f16 pieces each, so the accumulator IS |a - b|^2 (scaled), no VALU add:
 //         K slots 3e+0..3e+2 : (-2a_e)1 * (b_e)1,  (-2a_e)1 * (b_e)2,  (-2a_e)2 * (b_e)1     e < 13
 //         K slots 39..41     : |a|^2 pieces * 1          K slots 42..44 : 1 * |b|^2 pieces
-//     = 45 of the 48 slots of three chained 32x32x16 MFMAs per 32x32 tile;
+//     = 45 of the 48 slots of three chained 32x32x16 MFMAs per 32x32 tile.  Frames wider than 13
+//     values (up to 42) use ONE f16 piece per value (slot e: (-2a_e)1 * (b_e)1, norms after them):
+//     the filter then sees data rounded to 11 bits, which select.hip prices per cell;
 //   * tile = 16 frames of source 0 interleaved (groups of four) with 16 frames of source 1 as the
 //     32 A-rows, frame j of 32 DIFFERENT targets as the 32 B-columns: accumulator register r of
 //     lane (col = lane&31, half = lane>>5) is cell (row r, column j) of the pair
@@ -47,7 +49,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kFilterRowsPerTile = 16;   // frames of one source per 32x32 tile
 constexpr int kFilterKM = 3;             // chained K=16 MFMAs per tile
 constexpr int kFilterRecHalfs = 48;      // f16 values per frame record (96 bytes)
-constexpr int kFilterMaxDim = 13;        // 3*13 product slots + 6 norm slots <= 48
+constexpr int kFilterMaxDim2 = 13;       // two f16 pieces per value: 3*13 product slots + 6 norm slots <= 48
+constexpr int kFilterMaxDim1 = 42;       // one f16 piece per value:  42 product slots + 6 norm slots <= 48
 
 // Record layout (both sides): [khalf 0: 3 x 8 f16][khalf 1: 3 x 8 f16]; MFMA m of lane half h
 // reads its 8 K-values at f16 offset h*24 + m*8, i.e. logical K slot 16*m + 8*h + j.

@@ -32,7 +32,10 @@ namespace ssym {
 //      x~ >= m and x >= m - E:
 //          m > 4E :  |c~ - c| <= E / (2 sqrt(m - E))          (no cell is near zero)
 //          else   :  |c~ - c| <= sqrt(E)                      (|sqrt(y) - sqrt(x)| <= sqrt|y - x|)
-//      squared-L2 mode: |c~ - c| <= E.   Inputs rounded to the f16 pair move c by <= 4u(|a| + |b|).
+//      squared-L2 mode: |c~ - c| <= E.   The norms in the records are those of the REPRESENTED
+//      frames, so x is the squared distance of the rounded frames; rounding to the f16 piece(s)
+//      moves every frame by <= rho |frame| (rho = 2^-22 with two pieces, 2^-11 with one, dims 14..42)
+//      and therefore c by <= rho (|a| + |b|) -- an absolute term, no square root involved.
 //  DP: min is exact; each of the <= L = Fa+Fb-1 additions along a path rounds once and v_sqrt_f32 is
 //      within 1 ulp, and DTW is monotone and 1-Lipschitz in the cell costs along the optimal path
 //      of either side, so for EVERY pair
@@ -43,6 +46,7 @@ namespace ssym {
 // ---------------------------------------------------------------------------------------------
 struct MarginParams {
     double inv_scale2;  // 1 / s^2
+    double in_round;    // relative rounding of the operands the filter sees: 2^-22 (two f16 pieces) or 2^-11
     int squared;
 };
 
@@ -59,10 +63,12 @@ __device__ __forceinline__ void dtw_key_interval(const MarginParams &mp, double 
     const double u = 5.9604644775390625e-8;   // 2^-24
     const double E = 256.0 * u * (na + nb) + 0.000244140625 * mp.inv_scale2;
     double cell;
+    // operands rounded to their f16 piece(s) move every frame by <= in_round * |frame|, hence c by
+    // <= in_round (|a| + |b|) and c^2 by <= 2.05 in_round (|a| + |b|)^2 <= 4.1 in_round (|a|^2 + |b|^2)
     if (mp.squared)
-        cell = E + 8.2 * u * (na + nb);
+        cell = E + 4.1 * mp.in_round * (na + nb);
     else
-        cell = (xmin > 4.0 * E ? E / (2.0 * sqrt(xmin - E)) : sqrt(E)) + 4.0 * u * (sqrt(na) + sqrt(nb));
+        cell = (xmin > 4.0 * E ? E / (2.0 * sqrt(xmin - E)) : sqrt(E)) + 1.001 * mp.in_round * (sqrt(na) + sqrt(nb));
     const double L = (double)(fa + fb - 1);
     const double err = 1.02 * L * cell + (L + 6.0) * u * cst + 1e-300;
     const double lo = fmax(cst - err, 0.0), hi = cst + err;
@@ -301,6 +307,7 @@ int32_t launch_dtw_select(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
     hipStream_t st = ctx->stream;
     MarginParams mp;
     mp.inv_scale2 = src.rec_scale > 0.0 ? 1.0 / (src.rec_scale * src.rec_scale) : 1.0;
+    mp.in_round = filter_pieces((int)src.dim) == 2 ? 2.384185791015625e-07 : 4.8828125e-04;
     mp.squared = ctx->squared;
     int32_t rc = ensure(ctx, ctx->tmin, sizeof(unsigned long long) * tgt.n);
     if (rc != SSYM_OK)

@@ -27,6 +27,9 @@ inline FilterShape filter_shape(int max_frames)
     return FilterShape{};   // beyond the filter's reach: exact kernel only
 }
 
+// f16 pieces per value in the filter records: two up to 13 dims, one up to 42 (dtw_filter_kernel.hpp)
+inline int filter_pieces(int dim) { return dim <= 13 ? 2 : 1; }
+
 struct DeviceBuf {
     void *ptr = nullptr;
     size_t bytes = 0;

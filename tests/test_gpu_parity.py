@@ -130,15 +130,17 @@ def test_refcos_edge_cases(refcos, oracle):
 # ---------------------------------------------------------------------------------------------
 # dtw
 # ---------------------------------------------------------------------------------------------
-def _filter_bound(src, tgt, fa, fb):
-    """|C~ - C| bound of the f16-split MFMA filter as derived in soundsym_amd/csrc/select.hip."""
+def _filter_bound(src, tgt, fa, fb, dim=13):
+    """|C~ - C| bound of the f16-split MFMA filter as derived in soundsym_amd/csrc/select.hip
+    (worst case over pairs: no use of the per-pair smallest-cell certificate)."""
     u = 2.0 ** -24
+    in_round = 2.0 ** -22 if dim <= 13 else 2.0 ** -11
     na = max(float((s.astype(np.float64) ** 2).sum(-1).max()) for s in src if s.size)
     nb = max(float((t.astype(np.float64) ** 2).sum(-1).max()) for t in tgt if t.size)
     vmax = max(max(float(np.abs(s).max()) for s in src if s.size), max(float(np.abs(t).max()) for t in tgt if t.size))
     scale = 2.0 ** (6 - math.frexp(vmax)[1]) if vmax > 0 else 1.0
     E = 256 * u * (na + nb) + 2.0 ** -12 / scale ** 2
-    cell = math.sqrt(E) + 2 * u * (math.sqrt(na) + math.sqrt(nb))
+    cell = math.sqrt(E) + 1.001 * in_round * (math.sqrt(na) + math.sqrt(nb))
     return (fa + fb - 1) * cell
 
 
@@ -280,9 +282,40 @@ def test_dtw_long_segments_take_several_row_block_passes(oracle):
     e.close()
 
 
-def test_dtw_wide_frames_and_bands_use_the_exact_kernel(oracle):
-    # dim > 13 and Sakoe-Chiba bands are outside the MFMA filter: exact f64 kernel on every pair,
-    # including its own 64-row chunking (150 frames = 3 chunks)
+@pytest.mark.parametrize("dim,f", [(40, 40), (20, 70), (42, 17)])
+def test_dtw_wide_frames_use_single_piece_records(oracle, dim, f):
+    # 14..42 values per frame: one f16 piece per value in the MFMA records, exact refine as always
+    e = Engine(metric="dtw", dtype="f32")
+    g = synth.make_grid(24, 16, f, dim, 0x5EED0370 + dim)
+    sf, so = g.flat("sources")
+    tf, to = g.flat("targets")
+    d, q = e.dictionary(sf, so, dim), e.queries(tf, to, dim)
+    idx, cost = e.match(d, q)
+    tm = e.timings()
+    assert tm["used_filter"] == 1
+    want_idx, want_cost, mat = oracle.dtw_match_all(sf.astype(np.float64), so, tf.astype(np.float64), to, dim,
+                                                    want_matrix=True)
+    assert np.array_equal(idx, want_idx) and np.allclose(cost, want_cost, rtol=EXACT_RTOL, atol=0)
+    assert np.array_equal(idx, g.planted)
+    filt = e.pair_matrix(d, q, exact=False)
+    bound = _filter_bound(list(g.sources), list(g.targets), f, f, dim)
+    assert (np.abs(filt - mat) <= bound + 1e-5 * mat).all(), (np.abs(filt - mat).max(), bound)
+    assert tm["n_refined"] <= 4 * 16, tm
+    e.close()
+
+
+def test_dtw_bands_and_very_wide_frames_use_the_exact_kernel(oracle):
+    # Sakoe-Chiba bands and more than 42 values per frame are outside the MFMA filter: exact f64
+    # kernel on every pair, including its own 64-row chunking (150 frames = 3 chunks)
+    g = synth.make_grid(5, 4, 20, 50, 0x5EED0323)
+    sf, so = g.flat("sources")
+    tf, to = g.flat("targets")
+    ew = Engine(metric="dtw", dtype="f32")
+    idx, cost = ew.match(ew.dictionary(sf, so, 50), ew.queries(tf, to, 50))
+    assert ew.timings()["used_filter"] == 0
+    want_idx, want_cost = oracle.dtw_match_all(sf.astype(np.float64), so, tf.astype(np.float64), to, 50)
+    assert np.array_equal(idx, want_idx) and np.allclose(cost, want_cost, rtol=EXACT_RTOL, atol=0)
+    ew.close()
     g = synth.make_grid(6, 5, 40, 40, 0x5EED0321)
     sf, so = g.flat("sources")
     tf, to = g.flat("targets")
