@@ -1,0 +1,159 @@
+// dtw_band_kernel.hpp -- Sakoe-Chiba banded variant of the dtw MFMA filter (|i - j| <= r).
+//
+// Same idea as dtw_filter_kernel.hpp -- one (source, target) pair per lane, cost block on the f16
+// matrix pipe, lane-local recurrence on the VALU -- but in DIAGONAL coordinates: column j keeps
+// the 2r+1 in-band cells k = i - j + r in registers L[0..2r].  Then
+//     D(j,k) = c + min3( D(j,k-1) [cell (i-1,j)],  Dprev(k+1) [cell (i,j-1)],  Dprev(k) [cell (i-1,j-1)] )
+// updates L in place for ascending k (L[k] is consumed as the diagonal of cell k after it served as
+// the left neighbour of cell k-1), the band edges need no masks (k = 0 has no upper neighbour,
+// L[2r+1] stays +inf), and the work per pair is F*(2r+1) cells instead of F^2.
+// The price: the 16 source frames an MFMA tile needs move down by one frame per column.  A
+// workgroup therefore keeps ITS source pair (all frames, padded with |a|^2 = +inf records before
+// frame 0 and after the last frame) in LDS; its 8 waves work on 8 different target groups against
+// that pair, never synchronising except when the workgroup moves to the next source pair.
+#pragma once
+#include "dtw_filter_kernel.hpp"
+
+namespace ssym {
+
+constexpr int kBandTgtQuantum = 256;   // targets are padded to this (8 groups of 32)
+
+// Records of one source in the banded layout: slot s holds frame s - lead, lead = r.
+// WB = waves per workgroup = target groups (of 32) per task; OCC = waves per SIMD the register
+// budget is held to.  Up to 3 tiles of diagonals fit two waves per SIMD; wider bands (r = 32 is
+// 5 tiles: 81 column registers) run one wave per SIMD with the whole 512-register file.
+template <int NTB, int WB, int OCC, bool SQ>
+__global__ __launch_bounds__(64 * WB, OCC) void dtw_band_kernel(
+    const _Float16 *__restrict__ srcRec, const _Float16 *__restrict__ tgtRec,
+    const int *__restrict__ srcLen, const int *__restrict__ tgtLen, int srcSlots, int radius,
+    int tgtFramesPad, int mPad, int nTgtBlocks, int nTasks, int tasksPerBlock, float outScale,
+    float outScaleSq, float *__restrict__ cmat, float *__restrict__ xminmat)
+{
+    constexpr int REC = kFilterRecHalfs;
+    constexpr int KB = NTB * 16;           // diagonals held in registers (>= 2r+1)
+    const float INF = __builtin_inff();
+    extern __shared__ __attribute__((aligned(16))) _Float16 ldsSrc[];   // [2][srcSlots][48]
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col = lane & 31;
+    const int half = lane >> 5;
+    const int twoR = 2 * radius;
+
+    // lane's A-operand position inside a tile: source (arow>>2)&1, local frame (arow&3)+4(arow>>3)
+    const int arow = lane & 31;
+    const int a_h = (arow >> 2) & 1;
+    const int a_local = (arow & 3) + 4 * (arow >> 3);
+    const _Float16 *const aLane = ldsSrc + ((size_t)a_h * srcSlots + a_local) * REC + half * 24;
+
+    int curSp = -1;
+    const int t0 = blockIdx.x * tasksPerBlock;
+    const int t1 = min(t0 + tasksPerBlock, nTasks);
+    for (int task = t0; task < t1; ++task) {
+        const int sp = task / nTgtBlocks;              // source pair (tasks are sp-major)
+        const int tg = (task % nTgtBlocks) * WB + wave;
+        if (sp != curSp) {                             // workgroup-uniform
+            __syncthreads();                           // everyone is done with the previous pair
+            const uint4 *g = reinterpret_cast<const uint4 *>(srcRec + (size_t)(2 * sp) * srcSlots * REC);
+            uint4 *l = reinterpret_cast<uint4 *>(ldsSrc);
+            const int n16 = 2 * srcSlots * REC * 2 / 16;
+            for (int i = threadIdx.x; i < n16; i += 64 * WB)
+                l[i] = g[i];
+            __syncthreads();
+            curSp = sp;
+        }
+
+        const int fa = srcLen[2 * sp + half];
+        const int fb_m1 = tgtLen[32 * tg + col] - 1;
+        int nCols = fb_m1 + 1;
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1)
+            nCols = max(nCols, __shfl_xor(nCols, o));
+        nCols = __builtin_amdgcn_readfirstlane(nCols);
+
+        // column -1: everything +inf except the virtual D(-1,-1) = 0 on diagonal k = r
+        float L[KB + 1];
+#pragma unroll
+        for (int k = 0; k <= KB; ++k)
+            L[k] = (k == radius) ? 0.0f : INF;
+        float res = INF, xmin = INF;
+        const int kstar = fa - 1 - fb_m1 + radius;     // diagonal of the end cell (fa-1, fb-1)
+
+        const _Float16 *bbase = tgtRec + ((size_t)(32 * tg + col) * tgtFramesPad) * REC + half * 24;
+        half8 B0[kFilterKM], B1[kFilterKM];
+#pragma unroll
+        for (int m = 0; m < kFilterKM; ++m)
+            B0[m] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (nCols > 0)
+            load_rec(bbase, B0);
+        // software pipeline as in dtw_filter_kernel.hpp: the MFMA chain of the NEXT tile (next
+        // column's first tile after the last one) is in flight while this tile's cells run
+        f32x16 acc;
+        {
+            half8 A[kFilterKM];
+            load_rec(aLane, A);                        // column 0, tile 0
+            acc = mfma_tile<kFilterKM>(A, B0);
+        }
+
+        for (int j0 = 0; j0 < nCols; j0 += 2) {
+#pragma unroll
+            for (int par = 0; par < 2; ++par) {
+                const int j = j0 + par;
+                if (j < nCols) {                       // wave-uniform
+                    const int jn = min(j + 1, nCols - 1);
+                    if (par == 0)
+                        load_rec(bbase + (size_t)jn * REC, B1);
+                    else
+                        load_rec(bbase + (size_t)jn * REC, B0);
+                    // tile T of column j needs source frames j - r + 16T + local = slots j + 16T + local
+                    const _Float16 *aCol = aLane + (size_t)j * REC;
+                    float up = INF;
+#pragma unroll
+                    for (int T = 0; T < NTB; ++T) {
+                        f32x16 accn;
+                        {
+                            half8 A[kFilterKM];
+                            if (T + 1 < NTB) {
+                                load_rec(aCol + (size_t)(T + 1) * 16 * REC, A);
+                                accn = (par == 0) ? mfma_tile<kFilterKM>(A, B0) : mfma_tile<kFilterKM>(A, B1);
+                            } else {
+                                load_rec(aCol + REC, A);   // column j+1, tile 0 (slots stay inside the window)
+                                accn = (par == 0) ? mfma_tile<kFilterKM>(A, B1) : mfma_tile<kFilterKM>(A, B0);
+                            }
+                        }
+#pragma unroll
+                        for (int r = 0; r < 16; r += 2)
+                            xmin = __builtin_fminf(__builtin_fminf(xmin, acc[r]), acc[r + 1]);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int k = T * 16 + r;
+                            const float x = acc[r];
+                            float c = SQ ? __builtin_fabsf(x) : __builtin_amdgcn_sqrtf(__builtin_fabsf(x));
+                            if (T == NTB - 1)
+                                c = (k <= twoR) ? c : INF;       // diagonals beyond the band (wave-uniform)
+                            const float m3 = __builtin_fminf(__builtin_fminf(up, L[k]), L[k + 1]);
+                            const float cur = c + m3;
+                            L[k] = cur;
+                            up = cur;
+                        }
+                        acc = accn;
+                        // keep the scheduler from hoisting every tile's LDS reads and MFMA chains to
+                        // the top of the column (5 accumulators + 15 operand quads live = spills)
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (__any(j == fb_m1)) {           // the end cell of some lane's pair is in this column
+                        const bool mine = (j == fb_m1);
+#pragma unroll
+                        for (int k = 0; k < KB; ++k)
+                            res = (mine && k == kstar) ? L[k] : res;
+                    }
+                }
+            }
+        }
+        const size_t o = (size_t)(2 * sp + half) * mPad + 32 * tg + col;
+        cmat[o] = res * outScale;
+        xminmat[o] = xmin * outScaleSq;
+    }
+}
+
+}  // namespace ssym

@@ -13,18 +13,20 @@
 // costs and indices always come from the exact f64 kernel.
 #include "ssym_internal.hpp"
 #include "dtw_filter_kernel.hpp"
+#include "dtw_band_kernel.hpp"
 
 #include <algorithm>
 #include <cmath>
 
 namespace ssym {
 
-// One thread per (segment, record slot).  Targets: frame f -> slot f.  Sources: END-ALIGNED, frame f
-// of nf -> slot frames_pad - nf + f; the slots above (and all slots of padding segments) get
-// |a|^2 = +inf so that their DP rows stay at +inf.
+// One thread per (segment, record slot).  Frame f of a segment with nf frames goes to slot
+// lead + f (lead = -1: END-ALIGNED, slot frames_pad - nf + f, the unbanded kernel's source layout).
+// Source slots that hold no frame (and all slots of padding segments) get |a|^2 = +inf so that
+// their DP cells stay at +inf; empty target slots are all-zero records.
 __global__ void build_filter_records_kernel(const double *__restrict__ raw, const uint64_t *__restrict__ off,
                                             uint32_t n, uint32_t dim, uint32_t frames_pad, int is_source,
-                                            int pieces, double scale, _Float16 *__restrict__ rec)
+                                            int lead, int pieces, double scale, _Float16 *__restrict__ rec)
 {
     const uint32_t s = blockIdx.y;                              // < n_pad
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
@@ -35,20 +37,11 @@ __global__ void build_filter_records_kernel(const double *__restrict__ raw, cons
     for (int i = 0; i < kFilterRecHalfs; ++i)
         out[i] = (_Float16)0.0f;
     const uint32_t nf = s < n ? (uint32_t)(off[s + 1] - off[s]) : 0u;
-    bool real = false;
-    uint32_t f = 0;
-    if (is_source) {
-        if (slot >= frames_pad - nf) {
-            real = true;
-            f = slot - (frames_pad - nf);
-        } else {
-            out[filter_slot_offset((is_source ? 0 : 3) + (pieces == 2 ? 3 : 1) * (int)dim)] =
-                (_Float16)__builtin_inff();                               // pad row: |a|^2 = +inf
-        }
-    } else if (slot < nf) {
-        real = true;
-        f = slot;
-    }
+    const uint32_t first = lead < 0 ? frames_pad - nf : (uint32_t)lead;
+    const bool real = slot >= first && slot < first + nf;
+    const uint32_t f = slot - first;
+    if (!real && is_source)
+        out[filter_slot_offset((pieces == 2 ? 3 : 1) * (int)dim)] = (_Float16)__builtin_inff();   // |a|^2 = +inf
     if (real) {
         const double *p = raw + (off[s] + f) * dim;
         double nrm = 0.0;
@@ -85,14 +78,30 @@ __global__ void build_filter_records_kernel(const double *__restrict__ raw, cons
         dst[i] = out[i];
 }
 
+// banded layout: slot s of a source holds frame s - r; tile T of column j reads slots j + 16T .. +15
+static uint32_t band_slots(int radius, const SegmentSet &src, const SegmentSet &tgt)
+{
+    const uint32_t kb = (uint32_t)(2 * radius + 1 + 15) / 16 * 16;
+    return std::max<uint32_t>(radius + src.max_frames, std::max<uint32_t>(tgt.max_frames, 1) + kb) + 1;
+}
+static size_t band_lds_bytes(int radius, const SegmentSet &src, const SegmentSet &tgt)
+{
+    return (size_t)2 * band_slots(radius, src, tgt) * kFilterRecHalfs * sizeof(_Float16);
+}
+
 bool filter_supported(const ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt)
 {
-    if (ctx->band >= 0)
-        return false;   // banded shapes run on the exact kernel (DESIGN.md "limits")
     if (src.dim != tgt.dim || (int)src.dim > kFilterMaxDim1)
         return false;
-    if (filter_shape((int)src.max_frames).nt == 0)
-        return false;   // more than 512 source frames
+    if (ctx->band >= 0) {
+        // banded kernel: 2r+1 diagonals in registers (<= 6 tiles) and the source pair in LDS
+        if (2 * ctx->band + 1 > 6 * 16)
+            return false;
+        if (band_lds_bytes(ctx->band, src, tgt) > 160 * 1024)
+            return false;
+    } else if (filter_shape((int)src.max_frames).nt == 0) {
+        return false;   // more than 4096 source frames
+    }
     if (!std::isfinite(src.max_abs) || !std::isfinite(tgt.max_abs))
         return false;   // inf / NaN features: exact kernel keeps IEEE semantics
     return src.n > 0 && tgt.n > 0;
@@ -110,10 +119,11 @@ static double common_scale(const SegmentSet &src, const SegmentSet &tgt)
     return std::ldexp(1.0, e);
 }
 
-static int32_t ensure_records(ssym_ctx *ctx, const SegmentSet &set, double scale)
+static int32_t ensure_records(ssym_ctx *ctx, const SegmentSet &set, double scale, uint32_t slots, int lead)
 {
-    const size_t bytes = (size_t)set.n_pad * set.frames_pad * kFilterRecHalfs * sizeof(_Float16);
-    if (set.rec && set.rec_scale == scale && set.rec_bytes == bytes)
+    const size_t bytes = (size_t)set.n_pad * slots * kFilterRecHalfs * sizeof(_Float16);
+    if (set.rec && set.rec_scale == scale && set.rec_bytes == bytes && set.rec_slots == slots &&
+        set.rec_lead == lead)
         return SSYM_OK;
     if (set.rec && set.rec_bytes != bytes) {
         SSYM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -123,13 +133,15 @@ static int32_t ensure_records(ssym_ctx *ctx, const SegmentSet &set, double scale
     if (!set.rec)
         SSYM_HIP_CHECK(ctx, hipMalloc(&set.rec, bytes));
     set.rec_bytes = bytes;
-    dim3 grid((set.frames_pad + 63) / 64, set.n_pad);
-    build_filter_records_kernel<<<grid, 64, 0, ctx->stream>>>(set.raw, set.off, set.n, set.dim,
-                                                              set.frames_pad, set.is_source ? 1 : 0,
+    dim3 grid((slots + 63) / 64, set.n_pad);
+    build_filter_records_kernel<<<grid, 64, 0, ctx->stream>>>(set.raw, set.off, set.n, set.dim, slots,
+                                                              set.is_source ? 1 : 0, lead,
                                                               filter_pieces((int)set.dim), scale,
                                                               (_Float16 *)set.rec);
     SSYM_HIP_CHECK(ctx, hipGetLastError());
     set.rec_scale = scale;
+    set.rec_slots = slots;
+    set.rec_lead = lead;
     return SSYM_OK;
 }
 
@@ -146,19 +158,75 @@ static void launch_one(hipStream_t st, const SegmentSet &src, const SegmentSet &
         (int)tgt.frames_pad, (int)tgt.n_pad, nSrcBlocks, nTasks, outScale, outScaleSq, handoff, cmat, xminmat);
 }
 
+template <int NTB, bool SQ>
+static int32_t launch_band(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, uint32_t slots,
+                           size_t lds, float outScale, float outScaleSq, float *cmat, float *xminmat)
+{
+    constexpr int WB = NTB <= 3 ? 8 : 4;
+    constexpr int OCC = NTB <= 3 ? 2 : 1;
+    const int nTgtBlocks = (int)tgt.n_pad / (32 * WB);
+    const int nTasks = ((int)src.n_pad / 2) * nTgtBlocks;
+    const int grid = std::max(1, std::min(ctx->num_cus, nTasks));
+    const int tasksPerBlock = (nTasks + grid - 1) / grid;
+    auto kern = dtw_band_kernel<NTB, WB, OCC, SQ>;
+    if (lds > 64 * 1024)
+        SSYM_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    kern<<<dim3(grid), 64 * WB, lds, ctx->stream>>>(
+        (const _Float16 *)src.rec, (const _Float16 *)tgt.rec, src.len, tgt.len, (int)slots, ctx->band,
+        (int)tgt.frames_pad, (int)tgt.n_pad, nTgtBlocks, nTasks, tasksPerBlock, outScale, outScaleSq, cmat,
+        xminmat);
+    SSYM_HIP_CHECK(ctx, hipGetLastError());
+    return SSYM_OK;
+}
+
+static int32_t launch_dtw_filter_banded(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, float *cmat,
+                                        float *xminmat)
+{
+    if (tgt.n_pad % kBandTgtQuantum != 0 || src.n_pad % 2 != 0) {
+        ctx->err = "dtw band filter: segment set not padded for the banded kernel";
+        return SSYM_E_UNSUPPORTED;
+    }
+    const uint32_t slots = band_slots(ctx->band, src, tgt);
+    const size_t lds = band_lds_bytes(ctx->band, src, tgt);
+    const double scale = common_scale(src, tgt);
+    int32_t rc = ensure_records(ctx, src, scale, slots, ctx->band);
+    if (rc != SSYM_OK)
+        return rc;
+    rc = ensure_records(ctx, tgt, scale, tgt.frames_pad, 0);
+    if (rc != SSYM_OK)
+        return rc;
+    const bool sq = ctx->squared != 0;
+    const float outScaleSq = (float)(1.0 / (scale * scale));
+    const float outScale = sq ? outScaleSq : (float)(1.0 / scale);
+    const int ntb = (2 * ctx->band + 1 + 15) / 16;
+#define SSYM_BCASE(N_)                                                                                  \
+    case N_:                                                                                            \
+        return sq ? launch_band<N_, true>(ctx, src, tgt, slots, lds, outScale, outScaleSq, cmat, xminmat)  \
+                  : launch_band<N_, false>(ctx, src, tgt, slots, lds, outScale, outScaleSq, cmat, xminmat);
+    switch (ntb) {
+        SSYM_BCASE(1) SSYM_BCASE(2) SSYM_BCASE(3) SSYM_BCASE(4) SSYM_BCASE(5) SSYM_BCASE(6)
+    default:
+        ctx->err = "dtw band filter: band radius too large";
+        return SSYM_E_UNSUPPORTED;
+    }
+#undef SSYM_BCASE
+}
+
 int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, float *cmat,
                           float *xminmat)
 {
+    if (ctx->band >= 0)
+        return launch_dtw_filter_banded(ctx, src, tgt, cmat, xminmat);
     const FilterShape shape = filter_shape((int)src.max_frames);
     if (shape.nt == 0 || (int)src.frames_pad != shape.rows() || src.n_pad % 8 != 0 || tgt.n_pad % 32 != 0) {
         ctx->err = "dtw filter: segment set not padded for the filter kernel";
         return SSYM_E_UNSUPPORTED;
     }
     const double scale = common_scale(src, tgt);
-    int32_t rc = ensure_records(ctx, src, scale);
+    int32_t rc = ensure_records(ctx, src, scale, src.frames_pad, -1);
     if (rc != SSYM_OK)
         return rc;
-    rc = ensure_records(ctx, tgt, scale);
+    rc = ensure_records(ctx, tgt, scale, tgt.frames_pad, 0);
     if (rc != SSYM_OK)
         return rc;
     // persistent grid: 2 workgroups of 4 waves per CU (2 waves per SIMD), a multiple of 8 so that

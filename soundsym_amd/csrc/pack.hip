@@ -124,7 +124,9 @@ static int32_t build_derived(ssym_ctx *ctx, SegmentSet &set)
         segment_norm_kernel<<<(n + 63) / 64, 64, 0, st>>>(set.raw, set.off, n, dim, set.norm);
         SSYM_HIP_CHECK(ctx, hipGetLastError());
     } else {
-        set.n_pad = (n + 31) / 32 * 32;       // sources: 8 per workgroup; targets: 32 per group
+        // sources: 8 per workgroup; targets: groups of 32, 8 groups per workgroup in the banded kernel
+        const uint32_t quantum = (!set.is_source && ctx->band >= 0) ? 256u : 32u;
+        set.n_pad = (n + quantum - 1) / quantum * quantum;
         uint32_t mf = std::max<uint32_t>(set.max_frames, 1);
         FilterShape shape = filter_shape((int)mf);
         set.frames_pad = set.is_source ? (shape.nt ? (uint32_t)shape.rows() : mf) : mf;

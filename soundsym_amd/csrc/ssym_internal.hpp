@@ -58,6 +58,8 @@ struct SegmentSet {
     mutable void *rec = nullptr;    // [n_pad][frames_pad][48] _Float16
     mutable double rec_scale = 0.0;
     mutable size_t rec_bytes = 0;
+    mutable uint32_t rec_slots = 0;   // record slots per segment in `rec`
+    mutable int rec_lead = 0;         // slot of frame 0 (-1: end-aligned)
     size_t raw_capacity_vals = 0;
 };
 

@@ -75,3 +75,20 @@ def test_refcos_4096x4096x128x12(oracle):
     idx2, val2 = e.match(d, q)
     assert np.array_equal(idx, idx2) and np.array_equal(val, val2)
     e.close()
+
+
+def test_config5_shape_banded_512x512x256x40():
+    # BASELINE configs[4] shape (256 frames x 40 dims, Sakoe-Chiba r = 32) at 512 x 512 segments:
+    # planted neighbours recovered, run-to-run identical
+    e = Engine(metric="dtw", dtype="f32", band=32)
+    g = synth.make_grid(512, 512, 256, 40, 0x5EED0005)
+    sf, so = g.flat("sources")
+    tf, to = g.flat("targets")
+    d, q = e.dictionary(sf, so, 40), e.queries(tf, to, 40)
+    idx, cost = e.match(d, q)
+    tm = e.timings()
+    assert tm["used_filter"] == 1
+    assert np.array_equal(idx, g.planted)
+    idx2, cost2 = e.match(d, q)
+    assert np.array_equal(idx, idx2) and np.array_equal(cost, cost2)
+    e.close()

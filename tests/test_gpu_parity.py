@@ -304,9 +304,50 @@ def test_dtw_wide_frames_use_single_piece_records(oracle, dim, f):
     e.close()
 
 
-def test_dtw_bands_and_very_wide_frames_use_the_exact_kernel(oracle):
-    # Sakoe-Chiba bands and more than 42 values per frame are outside the MFMA filter: exact f64
-    # kernel on every pair, including its own 64-row chunking (150 frames = 3 chunks)
+@pytest.mark.parametrize("n,m,f,dim,band", [(24, 40, 30, 13, 3), (16, 33, 64, 13, 8), (10, 12, 100, 40, 32),
+                                              (12, 9, 48, 12, 0), (8, 8, 70, 20, 40)])
+def test_dtw_banded_filter_vs_oracle(oracle, n, m, f, dim, band):
+    # Sakoe-Chiba band on the MFMA path: diagonal-coordinate kernel, source pair in LDS
+    e = Engine(metric="dtw", dtype="f32", band=band)
+    g = synth.make_grid(n, m, f, dim, 0x5EED0380 + band)
+    sf, so = g.flat("sources")
+    tf, to = g.flat("targets")
+    d, q = e.dictionary(sf, so, dim), e.queries(tf, to, dim)
+    idx, cost = e.match(d, q)
+    assert e.timings()["used_filter"] == 1
+    want_idx, want_cost, mat = oracle.dtw_match_all(sf.astype(np.float64), so, tf.astype(np.float64), to, dim,
+                                                    band=band, want_matrix=True, nthreads=8)
+    assert np.array_equal(idx, want_idx) and np.allclose(cost, want_cost, rtol=EXACT_RTOL, atol=0)
+    filt = e.pair_matrix(d, q, exact=False)
+    bound = _filter_bound(list(g.sources), list(g.targets), f, f, dim)
+    finite = np.isfinite(mat)
+    assert np.array_equal(np.isfinite(filt), finite)
+    assert (np.abs(filt[finite] - mat[finite]) <= bound + 1e-5 * mat[finite]).all()
+    e.close()
+
+
+def test_dtw_banded_ragged_lengths(oracle):
+    # unequal lengths: the end cell (fa-1, fb-1) is outside the band when |fa - fb| > r -> +inf
+    src, tgt = synth.make_ragged(40, 70, 1, 45, 13, 0x5EED0390)
+    tgt[5] = src[11].copy()
+    sf, so = pack_segments(src, 13, np.float32)
+    tf, to = pack_segments(tgt, 13, np.float32)
+    for band in (2, 10):
+        e = Engine(metric="dtw", dtype="f32", band=band)
+        idx, cost = e.match(e.dictionary(sf, so, 13), e.queries(tf, to, 13))
+        assert e.timings()["used_filter"] == 1
+        want_idx, want_cost = oracle.dtw_match_all(sf.astype(np.float64), so, tf.astype(np.float64), to, 13,
+                                                   band=band, nthreads=8)
+        assert np.array_equal(idx, want_idx)
+        assert np.array_equal(np.isinf(cost), np.isinf(want_cost))
+        fin = np.isfinite(want_cost)
+        assert np.allclose(cost[fin], want_cost[fin], rtol=EXACT_RTOL, atol=0)
+        e.close()
+
+
+def test_dtw_very_wide_bands_and_frames_use_the_exact_kernel(oracle):
+    # more than 42 values per frame, or a band wider than 6 tiles of diagonals, are outside the MFMA
+    # filter: exact f64 kernel on every pair, including its own 64-row chunking (150 frames = 3 chunks)
     g = synth.make_grid(5, 4, 20, 50, 0x5EED0323)
     sf, so = g.flat("sources")
     tf, to = g.flat("targets")
@@ -316,13 +357,13 @@ def test_dtw_bands_and_very_wide_frames_use_the_exact_kernel(oracle):
     want_idx, want_cost = oracle.dtw_match_all(sf.astype(np.float64), so, tf.astype(np.float64), to, 50)
     assert np.array_equal(idx, want_idx) and np.allclose(cost, want_cost, rtol=EXACT_RTOL, atol=0)
     ew.close()
-    g = synth.make_grid(6, 5, 40, 40, 0x5EED0321)
+    g = synth.make_grid(6, 5, 120, 13, 0x5EED0321)
     sf, so = g.flat("sources")
     tf, to = g.flat("targets")
-    eb = Engine(metric="dtw", dtype="f32", band=8)
-    idx, cost = eb.match(eb.dictionary(sf, so, 40), eb.queries(tf, to, 40))
+    eb = Engine(metric="dtw", dtype="f32", band=60)
+    idx, cost = eb.match(eb.dictionary(sf, so, 13), eb.queries(tf, to, 13))
     assert eb.timings()["used_filter"] == 0
-    want_idx, want_cost = oracle.dtw_match_all(sf.astype(np.float64), so, tf.astype(np.float64), to, 40, band=8)
+    want_idx, want_cost = oracle.dtw_match_all(sf.astype(np.float64), so, tf.astype(np.float64), to, 13, band=60)
     assert np.array_equal(idx, want_idx) and np.allclose(cost, want_cost, rtol=EXACT_RTOL, atol=0)
     eb.close()
     e = Engine(metric="dtw", dtype="f32")
