@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--src-per-gpu", type=int, default=SRC_PER_GPU)
     ap.add_argument("--targets", type=int, default=N_TGT)
     ap.add_argument("--frames", type=int, default=FRAMES)
+    ap.add_argument("--dim", type=int, default=DIM)
+    ap.add_argument("--band", type=int, default=-1, help="Sakoe-Chiba radius (configs[4]: 32), -1 = none")
     args = ap.parse_args()
 
     import torch
@@ -118,15 +120,16 @@ def main():
     m = args.targets
 
     # synthetic workload (seeded; every rank builds the same grid and keeps its source shard)
-    grid = synth.make_grid(n_src_total, m, args.frames, DIM, SEED)
+    DIM_ = args.dim
+    grid = synth.make_grid(n_src_total, m, args.frames, DIM_, SEED)
     lo, hi = sharding.shard_range(n_src_total, n_gpus, rank)
-    eng = Engine(metric="dtw", dtype="f32", device=local_rank)
+    eng = Engine(metric="dtw", dtype="f32", device=local_rank, band=args.band)
     src_dev = torch.from_numpy(np.ascontiguousarray(grid.sources[lo:hi]).reshape(-1)).cuda()
     tgt_dev = torch.from_numpy(np.ascontiguousarray(grid.targets).reshape(-1)).cuda()
     so = np.arange(hi - lo + 1, dtype=np.uint64) * args.frames
     to = np.arange(m + 1, dtype=np.uint64) * args.frames
-    d = eng.dictionary(src_dev, so, DIM)
-    q = eng.queries(tgt_dev, to, DIM)
+    d = eng.dictionary(src_dev, so, DIM_)
+    q = eng.queries(tgt_dev, to, DIM_)
     out_idx = torch.empty(m, dtype=torch.int32, device="cuda")
     out_cost = torch.empty(m, dtype=torch.float64, device="cuda")
 
@@ -174,13 +177,15 @@ def main():
         k_ms = float(np.mean(main_ms))
         k_s = k_ms * 1e-3
         pairs_launch = (hi - lo) * m
-        f, dd = args.frames, DIM
+        f, dd = args.frames, DIM_
+        r = args.band
+        cells_pair = float(f) * f if r < 0 else float(f * (2 * r + 1) - r * (r + 1))
         stream_gbps = pairs_launch * 2 * f * dd * 4 / k_s / 1e9
-        flops_tf = pairs_launch * 2.0 * f * f * dd / k_s / 1e12
-        cells_per_s = pairs_launch * float(f) * f / k_s
+        flops_tf = pairs_launch * 2.0 * cells_pair * dd / k_s / 1e12
+        cells_per_s = pairs_launch * cells_pair / k_s
         traffic = None
         prof = sorted(glob.glob(os.path.join(ROOT, "profiles", "*bench_1gpu.json")))
-        if prof and n_gpus == 1 and (hi - lo, m, f) == (SRC_PER_GPU, N_TGT, FRAMES):
+        if prof and n_gpus == 1 and (hi - lo, m, f, dd, r) == (SRC_PER_GPU, N_TGT, FRAMES, DIM, -1):
             traffic = json.load(open(prof[-1])).get("hbm_traffic_bytes_per_launch")
         # VALU floor measured on MI355X (profiles/): v_sqrt_f32 8 + v_min3_f32 4 + v_add_f32 4
         # cycles per wave-instruction = 16 cycles per 64 cells per SIMD, 1024 SIMDs
@@ -200,7 +205,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{n_src_total}x{m} segments, {f} frames x {dd} dims, f32, "
-                            f"dtw (L2 local cost, full matrix), planted neighbours, seed 0x{SEED:X}",
+                            f"dtw (L2 local cost, {'full matrix' if r < 0 else f'Sakoe-Chiba r={r}'}), "
+                            f"planted neighbours, seed 0x{SEED:X}",
                 "sources_per_gpu": hi - lo,
                 "parallelism": f"source-shard x{n_gpus}" if n_gpus > 1 else "single GPU",
                 "indices_equal_planted": planted_ok,
@@ -208,7 +214,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "dtw_filter_kernel",
+                "kernel": "dtw_filter_kernel" if r < 0 else "dtw_band_kernel",
                 "model": "per-pair operand-streaming bytes 2*F*d*4 (SURVEY.md 8(d)); the kernel keeps "
                          "operands on chip, so measured HBM traffic is far below this and the "
                          "limiter is VALU issue, see 'valu' and DESIGN.md",
@@ -218,7 +224,7 @@ def main():
                 "frac": stream_gbps / PEAK_HBM_GBPS,
                 "traffic": traffic,
                 "kernel_ms": k_ms,
-                "mfma": {"achieved": flops_tf, "unit": "TFLOP/s", "algorithmic_flops_per_pair": 2 * f * f * dd,
+                "mfma": {"achieved": flops_tf, "unit": "TFLOP/s", "algorithmic_flops_per_pair": 2 * cells_pair * dd,
                          "peak_f32_mfma": PEAK_F32_MFMA_TFLOPS, "frac_of_f32_mfma_peak": flops_tf / PEAK_F32_MFMA_TFLOPS,
                          "note": "cost block runs on the f16 matrix pipe (3 x 32x32x16 per 32x32 tile, "
                                  "two-piece operand split); algorithmic flops, not issued flops"},
