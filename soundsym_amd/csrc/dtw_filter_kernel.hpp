@@ -56,7 +56,10 @@ constexpr int kFilterMaxDim1 = 42;       // one f16 piece per value:  42 product
 // reads its 8 K-values at f16 offset h*24 + m*8, i.e. logical K slot 16*m + 8*h + j.
 __host__ __device__ constexpr int filter_slot_offset(int k) { return ((k >> 3) & 1) * 24 + (k >> 4) * 8 + (k & 7); }
 
-constexpr int kFilterSlide = 4;   // columns per slide-back of the DP column array
+#ifndef SSYM_FILTER_SLIDE
+#define SSYM_FILTER_SLIDE 4
+#endif
+constexpr int kFilterSlide = SSYM_FILTER_SLIDE;   // columns per slide-back of the DP column array (4 or 8)
 
 template <int KM>
 __device__ __forceinline__ f32x16 mfma_tile(const half8 (&a)[KM], const half8 (&b)[KM])
@@ -241,15 +244,19 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, 2) void dtw_filter_kerne
                         prevTop = up;
                         if (haveTop)
                             topN = hand[(size_t)jn * 64];           // next column's top boundary
-                        float bottom;
-                        if (u == 0)
-                            bottom = dp_column<NT, SL - 0, SQ>(A, B0, B1, acc, up, diag, L, xmin);
-                        else if (u == 1)
-                            bottom = dp_column<NT, SL - 1, SQ>(A, B1, B0, acc, up, diag, L, xmin);
-                        else if (u == 2)
-                            bottom = dp_column<NT, SL - 2, SQ>(A, B0, B1, acc, up, diag, L, xmin);
-                        else
-                            bottom = dp_column<NT, SL - 3, SQ>(A, B1, B0, acc, up, diag, L, xmin);
+                        float bottom = 0.0f;
+                        switch (u) {   // u is a constant after unrolling: one case survives
+                        case 0: bottom = dp_column<NT, SL - 0, SQ>(A, B0, B1, acc, up, diag, L, xmin); break;
+                        case 1: bottom = dp_column<NT, SL - 1, SQ>(A, B1, B0, acc, up, diag, L, xmin); break;
+                        case 2: bottom = dp_column<NT, SL - 2, SQ>(A, B0, B1, acc, up, diag, L, xmin); break;
+                        case 3: bottom = dp_column<NT, SL - 3, SQ>(A, B1, B0, acc, up, diag, L, xmin); break;
+#if SSYM_FILTER_SLIDE == 8
+                        case 4: bottom = dp_column<NT, SL - 4, SQ>(A, B0, B1, acc, up, diag, L, xmin); break;
+                        case 5: bottom = dp_column<NT, SL - 5, SQ>(A, B1, B0, acc, up, diag, L, xmin); break;
+                        case 6: bottom = dp_column<NT, SL - 6, SQ>(A, B0, B1, acc, up, diag, L, xmin); break;
+                        case 7: bottom = dp_column<NT, SL - 7, SQ>(A, B1, B0, acc, up, diag, L, xmin); break;
+#endif
+                        }
                         if (!lastPass)
                             hand[(size_t)j * 64] = bottom;          // top boundary of the next pass
                         else
