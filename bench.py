@@ -223,6 +223,9 @@ def main():
                 "unit": "GB/s",
                 "frac": stream_gbps / PEAK_HBM_GBPS,
                 "traffic": traffic,
+                "traffic_note": "bytes per launch at the L2-fabric boundary (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, "
+                                "profiles/r01_bench_1gpu.md): the per-wave hand-off rows written and read once",
+                "algorithmic_bytes_per_launch": pairs_launch * 2 * f * dd * 4,
                 "kernel_ms": k_ms,
                 "mfma": {"achieved": flops_tf, "unit": "TFLOP/s", "algorithmic_flops_per_pair": 2 * cells_pair * dd,
                          "peak_f32_mfma": PEAK_F32_MFMA_TFLOPS, "frac_of_f32_mfma_peak": flops_tf / PEAK_F32_MFMA_TFLOPS,

@@ -69,6 +69,9 @@ __device__ __forceinline__ void dtw_key_interval(const MarginParams &mp, double 
         cell = E + 4.1 * mp.in_round * (na + nb);
     else
         cell = (xmin > 4.0 * E ? E / (2.0 * sqrt(xmin - E)) : sqrt(E)) + 1.001 * mp.in_round * (sqrt(na) + sqrt(nb));
+    // f16 pieces below 2^-14 are subnormal: their absolute rounding 2^-25 (scaled units) per value,
+    // over at most 42 values of both frames
+    cell += 9.5367431640625e-07 * sqrt(mp.inv_scale2);
     const double L = (double)(fa + fb - 1);
     const double err = 1.02 * L * cell + (L + 6.0) * u * cst + 1e-300;
     const double lo = fmax(cst - err, 0.0), hi = cst + err;
