@@ -148,7 +148,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    main_ms, total_ms, refined = [], [], 0
+    main_ms, total_ms, refined, last_tm = [], [], 0, {}
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -157,6 +157,7 @@ def main():
         main_ms.append(tm["main_ms"])
         total_ms.append(tm["total_ms"])
         refined = tm["n_refined"]
+        last_tm = tm
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -211,6 +212,7 @@ def main():
                 "parallelism": f"source-shard x{n_gpus}" if n_gpus > 1 else "single GPU",
                 "indices_equal_planted": planted_ok,
                 "pairs_refined_f64": int(refined),
+                "phase_ms": {k: round(float(v), 3) for k, v in last_tm.items() if k.endswith("_ms")},
             },
             "roofline": {
                 "bound": "hbm",

@@ -36,10 +36,14 @@ __global__ __launch_bounds__(64) void dtw_exact_kernel(
     double *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    // LDS frame rows are padded to an ODD number of doubles: lane l reads frame (tau - l), i.e. a
+    // stride of `ld` doubles between lanes, and ds_read_b64 is conflict-free iff ld is odd
+    // (ld = 40 would be a 16-way conflict)
+    const uint32_t ld = LDS_FRAMES ? (dim | 1u) : dim;
     double *bound0 = smem;                  // [fbCap]
     double *bound1 = smem + fbCap;          // [fbCap]
-    double *ldsA = smem + 2 * (size_t)fbCap;        // [64][dim]      (LDS_FRAMES only)
-    double *ldsB = ldsA + 64 * (size_t)dim;          // [fbCap][dim]   (LDS_FRAMES only)
+    double *ldsA = smem + 2 * (size_t)fbCap;        // [64][ld]      (LDS_FRAMES only)
+    double *ldsB = ldsA + 64 * (size_t)ld;           // [fbCap][ld]   (LDS_FRAMES only)
 
     const double INF = __builtin_inf();
     const int lane = threadIdx.x;
@@ -75,7 +79,7 @@ __global__ __launch_bounds__(64) void dtw_exact_kernel(
         const double *bsrc = b0;
         if (LDS_FRAMES) {
             for (int i = lane; i < Fb * (int)dim; i += 64)
-                ldsB[i] = b0[i];
+                ldsB[(size_t)(i / (int)dim) * ld + (i % (int)dim)] = b0[i];
             bsrc = ldsB;
         }
         double result = INF;
@@ -88,17 +92,26 @@ __global__ __launch_bounds__(64) void dtw_exact_kernel(
             if (LDS_FRAMES) {
                 __syncthreads();   // previous chunk's A rows no longer read
                 for (int i = lane; i < rowsHere * (int)dim; i += 64)
-                    ldsA[i] = a0[(size_t)c0 * dim + i];
-                arow = ldsA + (size_t)(rowValid ? lane : 0) * dim;
+                    ldsA[(size_t)(i / (int)dim) * ld + (i % (int)dim)] = a0[(size_t)c0 * dim + i];
+                arow = ldsA + (size_t)(rowValid ? lane : 0) * ld;
             }
-            __syncthreads();       // staged frames + previous chunk's boundary row visible
             const double *boundPrev = (chunk & 1) ? bound0 : bound1;
             double *boundCur = (chunk & 1) ? bound1 : bound0;
+            // columns this chunk can reach: all of them, or the band around its rows; the boundary
+            // row it leaves behind is +inf wherever it does not compute
+            int jlo = 0, jhi = Fb - 1;
+            if (band >= 0) {
+                jlo = max(0, c0 - band);
+                jhi = min(Fb - 1, c0 + rowsHere - 1 + band);
+            }
+            for (int j = lane; j < Fb; j += 64)
+                boundCur[j] = INF;
+            __syncthreads();       // staged frames, cleared boundary, previous chunk's boundary row visible
 
             double mine = INF;      // D(r, j-1)
             double diagReg = INF;   // D(r-1, j-1)
-            const int nSteps = rowsHere + Fb - 1;
-            for (int tau = 0; tau < nSteps; ++tau) {
+            const int tauEnd = jhi + rowsHere;     // exclusive: lane l works on column tau - l
+            for (int tau = jlo; tau < tauEnd; ++tau) {
                 const int j = tau - lane;
                 double fromAbove = shfl_up1(mine);        // D(r-1, j) for lanes >= 1
                 double diagv = diagReg;
@@ -116,10 +129,24 @@ __global__ __launch_bounds__(64) void dtw_exact_kernel(
                     double cur = INF;
                     const int dij = r - j;
                     if (band < 0 || (dij <= band && -dij <= band)) {
-                        const double *bj = bsrc + (size_t)j * dim;
+                        const double *bj = bsrc + (size_t)j * ld;
+                        // sum_k (a_k - b_k)^2 with k ascending (the oracle's order); the loads and the
+                        // sub / mul of a block of eight are independent, only the adds are a chain
                         double acc = 0.0;
-                        for (uint32_t e = 0; e < dim; ++e) {
-                            double df = __dsub_rn(arow[e], bj[e]);
+                        uint32_t e = 0;
+                        for (; e + 8 <= dim; e += 8) {
+                            double sq[8];
+#pragma unroll
+                            for (int v = 0; v < 8; ++v) {
+                                const double df = __dsub_rn(arow[e + v], bj[e + v]);
+                                sq[v] = __dmul_rn(df, df);
+                            }
+#pragma unroll
+                            for (int v = 0; v < 8; ++v)
+                                acc = __dadd_rn(acc, sq[v]);
+                        }
+                        for (; e < dim; ++e) {
+                            const double df = __dsub_rn(arow[e], bj[e]);
                             acc = __dadd_rn(acc, __dmul_rn(df, df));
                         }
                         const double c = squared ? acc : sqrt(acc);
@@ -153,7 +180,7 @@ int32_t launch_dtw_exact(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet 
     const uint32_t dim = src.dim;
     const uint32_t fbCap = std::max<uint32_t>(tgt.max_frames, 1);
     const size_t boundBytes = 2 * (size_t)fbCap * sizeof(double);
-    const size_t frameBytes = (64 * (size_t)dim + (size_t)fbCap * dim) * sizeof(double);
+    const size_t frameBytes = (64 * (size_t)(dim | 1u) + (size_t)fbCap * (dim | 1u)) * sizeof(double);
     if (boundBytes > 120 * 1024) {
         ctx->err = "dtw exact: target segment too long (boundary row does not fit LDS)";
         return SSYM_E_UNSUPPORTED;

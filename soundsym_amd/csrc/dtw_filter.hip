@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 namespace ssym {
 
@@ -158,12 +159,10 @@ static void launch_one(hipStream_t st, const SegmentSet &src, const SegmentSet &
         (int)tgt.frames_pad, (int)tgt.n_pad, nSrcBlocks, nTasks, outScale, outScaleSq, handoff, cmat, xminmat);
 }
 
-template <int NTB, bool SQ>
-static int32_t launch_band(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, uint32_t slots,
-                           size_t lds, float outScale, float outScaleSq, float *cmat, float *xminmat)
+template <int NTB, int WB, int OCC, bool SQ>
+static int32_t launch_band_cfg(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, uint32_t slots,
+                               size_t lds, float outScale, float outScaleSq, float *cmat, float *xminmat)
 {
-    constexpr int WB = NTB <= 3 ? 8 : 4;
-    constexpr int OCC = NTB <= 3 ? 2 : 1;
     const int nTgtBlocks = (int)tgt.n_pad / (32 * WB);
     const int nTasks = ((int)src.n_pad / 2) * nTgtBlocks;
     const int grid = std::max(1, std::min(ctx->num_cus, nTasks));
@@ -177,6 +176,19 @@ static int32_t launch_band(ssym_ctx *ctx, const SegmentSet &src, const SegmentSe
         xminmat);
     SSYM_HIP_CHECK(ctx, hipGetLastError());
     return SSYM_OK;
+}
+
+// Up to 3 tiles of diagonals fit two waves per SIMD (8-wave workgroups); wider bands run one wave
+// per SIMD (4-wave workgroups) with the whole register file.  SSYM_BAND_OCC2=1 forces the
+// two-wave variant for tuning experiments.
+template <int NTB, bool SQ>
+static int32_t launch_band(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, uint32_t slots,
+                           size_t lds, float outScale, float outScaleSq, float *cmat, float *xminmat)
+{
+    static const bool forceOcc2 = getenv("SSYM_BAND_OCC2") != nullptr;
+    if (NTB <= 3 || forceOcc2)
+        return launch_band_cfg<NTB, 8, 2, SQ>(ctx, src, tgt, slots, lds, outScale, outScaleSq, cmat, xminmat);
+    return launch_band_cfg<NTB, 4, 1, SQ>(ctx, src, tgt, slots, lds, outScale, outScaleSq, cmat, xminmat);
 }
 
 static int32_t launch_dtw_filter_banded(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, float *cmat,
