@@ -178,15 +178,16 @@ static int32_t launch_band_cfg(ssym_ctx *ctx, const SegmentSet &src, const Segme
     return SSYM_OK;
 }
 
-// Up to 3 tiles of diagonals fit two waves per SIMD (8-wave workgroups); wider bands run one wave
-// per SIMD (4-wave workgroups) with the whole register file.  SSYM_BAND_OCC2=1 forces the
-// two-wave variant for tuning experiments.
+// Up to 5 tiles of diagonals (r <= 39) run two waves per SIMD (8-wave workgroups); at 4 and 5 tiles
+// that costs a few register spills but measured 10 % faster than one wave per SIMD at r = 32.
+// 6 tiles run one wave per SIMD (4-wave workgroups) with the whole register file.
+// SSYM_BAND_OCC1=1 forces the one-wave variant for tuning experiments.
 template <int NTB, bool SQ>
 static int32_t launch_band(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, uint32_t slots,
                            size_t lds, float outScale, float outScaleSq, float *cmat, float *xminmat)
 {
-    static const bool forceOcc2 = getenv("SSYM_BAND_OCC2") != nullptr;
-    if (NTB <= 3 || forceOcc2)
+    static const bool forceOcc1 = getenv("SSYM_BAND_OCC1") != nullptr;
+    if (NTB <= 5 && !forceOcc1)
         return launch_band_cfg<NTB, 8, 2, SQ>(ctx, src, tgt, slots, lds, outScale, outScaleSq, cmat, xminmat);
     return launch_band_cfg<NTB, 4, 1, SQ>(ctx, src, tgt, slots, lds, outScale, outScaleSq, cmat, xminmat);
 }
