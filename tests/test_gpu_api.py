@@ -109,3 +109,61 @@ def test_reconstruction_tail_on_the_gpu(oracle):
     out, q = e.reconstruct(h, [0], [0, big.size + 2], want_pcm32=True)
     assert np.array_equal(q[:big.size], oracle.pcm32(big)) and q[big.size:].tolist() == [0, 0]
     assert np.array_equal(out[:big.size][~np.isnan(big)], big[~np.isnan(big)])
+
+
+def test_reconstruction_example_end_to_end(tmp_path, oracle):
+    """examples/reconstruction.py on synthetic WAVs: read -> segment -> features -> match (GPU) ->
+    length fit + concatenation + 32-bit conversion (GPU) -> WAV, checked against the oracle."""
+    import importlib.util
+    import os
+    from oracle.oracle import pack_segments
+    from soundsym_amd import io as sio
+    from soundsym_amd.features import frame_features
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("reconstruction", os.path.join(here, "examples", "reconstruction.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rate = 22050
+    t = np.arange(rate * 3) / rate
+    src = 0.4 * np.sin(2 * np.pi * (200 + 300 * t) * t) + 0.1 * np.sin(2 * np.pi * 1700 * t)
+    tgt = 0.3 * np.sin(2 * np.pi * (900 - 150 * t[:rate * 2]) * t[:rate * 2])
+    ps, pt, po = str(tmp_path / "s.wav"), str(tmp_path / "t.wav"), str(tmp_path / "o.wav")
+    sio.write_wav32(ps, src, rate)
+    sio.write_wav32(pt, tgt, rate)
+    labels = str(tmp_path / "l.txt")
+    open(labels, "w").write("0.10\t0.45\ta\n0.45\t0.60\tb\n0.60\t1.40\tc\n1.40\t1.95\td\n")
+    for extra in ([], ["--labels", labels], ["--metric", "dtw"]):
+        got = mod.main(["-s", ps, "-t", pt, "-o", po] + extra)
+        back, r = sio.read_wav(po)
+        assert r == rate and back.size == got.size
+        assert np.array_equal(back, sio.pcm32(got).astype(np.float64) / 2147483647.0)
+        # oracle for the same segmentation and features
+        s_smp, _ = sio.read_wav(ps)
+        t_smp, _ = sio.read_wav(pt)
+        seg = 16 * HOP
+        slens = mod.chunk_lengths(s_smp.size, seg)
+        sfe = frame_features(s_smp, rate)
+        ssm, sft, pos, fpos = [], [], 0, 0
+        for L in slens:
+            nf = L // HOP
+            ssm.append(s_smp[pos:pos + L]); sft.append(sfe[fpos:fpos + nf * NCOEFFS]); pos += L; fpos += nf * NCOEFFS
+        if "--labels" in extra:
+            tsm = []
+            for a, b, _ in sio.audacity_labels_to_timestamps(labels):
+                tsm.append(t_smp[int(round(a * rate)):int(round(b * rate)) + 1])
+            tft = [frame_features(x, rate) for x in tsm]
+        else:
+            tfe = frame_features(t_smp, rate)
+            tsm, tft, pos, fpos = [], [], 0, 0
+            for L in mod.chunk_lengths(t_smp.size, seg):
+                nf = L // HOP
+                tsm.append(t_smp[pos:pos + L]); tft.append(tfe[fpos:fpos + nf * NCOEFFS]); pos += L; fpos += nf * NCOEFFS
+        flat, off = pack_segments(sft, NCOEFFS)
+        tflat, toff = pack_segments(tft, NCOEFFS)
+        if "dtw" in extra:
+            idx, _ = oracle.dtw_match_all(flat, off, tflat, toff, NCOEFFS)
+        else:
+            idx, _ = oracle.refcos_match_all(flat, off, tflat, toff, NCOEFFS)
+        soff = np.concatenate([[0], np.cumsum([x.size for x in ssm])]).astype(np.uint64)
+        ooff = np.concatenate([[0], np.cumsum([x.size for x in tsm])]).astype(np.uint64)
+        assert np.array_equal(got, oracle.reconstruct(np.concatenate(ssm), soff, idx, ooff))

@@ -1,0 +1,50 @@
+"""WAV / label I/O conventions of the reference (host side), and the label fixture its tests hold."""
+import os
+import struct
+
+import numpy as np
+
+from soundsym_amd import io as sio
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _write_int_wav(path, ints, bits, rate=44100):
+    if bits == 16:
+        body = np.asarray(ints, dtype="<i2").tobytes()
+    else:  # 24
+        v = np.asarray(ints, dtype=np.int64) & 0xFFFFFF
+        body = np.stack([v & 255, (v >> 8) & 255, (v >> 16) & 255], axis=1).astype(np.uint8).tobytes()
+    hdr = b"RIFF" + struct.pack("<I", 36 + len(body)) + b"WAVE" + b"fmt " + struct.pack(
+        "<IHHIIHH", 16, 1, 1, rate, rate * bits // 8, bits // 8, bits) + b"data" + struct.pack("<I", len(body))
+    open(path, "wb").write(hdr + body)
+
+
+def test_audacity_labels_to_timestamps_reference_fixture():
+    # the reference's own test (src/sound.rs:546-554) on its own data file
+    ts = sio.audacity_labels_to_timestamps(os.path.join(GOLD, "vowel.txt"))
+    assert abs(ts[0][0] - 0.7065779155923718) < 1e-10
+    assert abs(ts[26][1] - 5.59353222977394) < 1e-10
+    assert ts[44][2] == "ning"
+    assert len(ts) == 55
+
+
+def test_read_wav_divisor_matches_hound_convention(tmp_path):
+    # src/sound.rs:118-120: sample / (i32::MAX >> (32 - bits))
+    p16, p24 = str(tmp_path / "a16.wav"), str(tmp_path / "a24.wav")
+    _write_int_wav(p16, [0, 32767, -32768, 12345], 16)
+    _write_int_wav(p24, [0, 8388607, -8388608, -5], 24)
+    s16, r = sio.read_wav(p16)
+    assert r == 44100.0 and np.array_equal(s16, np.array([0, 32767, -32768, 12345]) / 32767.0)
+    s24, _ = sio.read_wav(p24)
+    assert np.array_equal(s24, np.array([0, 8388607, -8388608, -5]) / 8388607.0)
+
+
+def test_write_wav32_roundtrip_and_conversion(tmp_path, oracle):
+    x = np.array([0.0, 0.5, -0.5, 1.0, 1.5, -1.5, 1e-10, -0.123456789])
+    assert np.array_equal(sio.pcm32(x), oracle.pcm32(x))           # src/sound.rs:139
+    p = str(tmp_path / "o.wav")
+    sio.write_wav32(p, x, 22050.0)
+    back, rate = sio.read_wav(p)
+    assert rate == 22050.0
+    assert np.array_equal(back, sio.pcm32(x).astype(np.float64) / 2147483647.0)
