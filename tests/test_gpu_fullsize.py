@@ -92,3 +92,32 @@ def test_config5_shape_banded_512x512x256x40():
     idx2, cost2 = e.match(d, q)
     assert np.array_equal(idx, idx2) and np.array_equal(cost, cost2)
     e.close()
+
+
+def test_config4_16384x4096_source_sharded_on_one_gpu(dtw):
+    """BASELINE configs[3]: 16384 x 4096 segments, 128 frames x 13 dims, source axis split in 8
+    shards.  The 8 ranks' work is run one after the other on this GPU (same calls a rank makes:
+    match with index_base, then the gathered [8, M] candidates through the HIP merge kernel);
+    the planted neighbours are known from the generator alone."""
+    import torch
+    from soundsym_amd import sharding
+    g = synth.make_grid(16384, 4096, 128, 13, 0x5EED0004)
+    tf, to = g.flat("targets")
+    q = dtw.queries(torch.from_numpy(tf).cuda(), to, 13)
+    costs = torch.empty((8, 4096), dtype=torch.float64, device="cuda")
+    idxs = torch.empty((8, 4096), dtype=torch.int32, device="cuda")
+    refined = 0
+    for rank in range(8):
+        lo, hi = sharding.shard_range(16384, 8, rank)
+        sf = np.ascontiguousarray(g.sources[lo:hi]).reshape(-1)
+        so = np.arange(hi - lo + 1, dtype=np.uint64) * 128
+        d = dtw.dictionary(torch.from_numpy(sf).cuda(), so, 13)
+        dtw.match(d, q, index_base=lo, out_idx=idxs[rank], out_cost=costs[rank])
+        refined += dtw.timings()["n_refined"]
+        d.close()
+    out_idx, out_cost = sharding.merge_shards(dtw, costs, idxs)
+    assert np.array_equal(out_idx.cpu().numpy().astype(np.int64), g.planted)
+    # a rank that does not hold a target's neighbour must not re-score many pairs
+    assert refined <= 8 * 4096 * 3, refined
+    c = out_cost.cpu().numpy()
+    assert np.isfinite(c).all() and (c > 0).all()

@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Latency of ssym_match_one (the reference's one-query-at-a-time call pattern)."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from soundsym_amd import Engine, synth
+from soundsym_amd.engine import pack_segments
+
+src, tgt = synth.make_ragged(1024, 64, 5, 40, 12, 0x5EED0700)
+for metric, dtype in (("refcos", "f64"), ("dtw", "f64")):
+    e = Engine(metric=metric, dtype=dtype)
+    sf, so = pack_segments([s.astype(np.float64) * 0.05 for s in src], 12)
+    d = e.dictionary(sf, so, 12)
+    qs = [t.astype(np.float64).reshape(-1) * 0.05 for t in tgt]
+    e.match_one(d, qs[0], 1.0)
+    t0 = time.perf_counter()
+    for q in qs:
+        e.match_one(d, q, 1.0 if metric == "refcos" else 0.0)
+    dt = (time.perf_counter() - t0) / len(qs)
+    print(f"{metric}: match_one on a 1024-entry dictionary: {dt * 1e6:.0f} us per call; timings {e.timings()['total_ms']:.3f} ms device")
+    e.close()
