@@ -1,0 +1,85 @@
+"""Seeded random differential tests: small ragged problems of every shape class against the oracle.
+
+Covers what the hand-written cases may miss: empty segments anywhere, 1-frame segments, lengths
+straddling tile / pass / chunk boundaries (16, 48, 64, 128), dims 1..42 (both record layouts), bands
+from 0 to beyond the filter's reach, squared local cost, f32 and f64 inputs, per-target distances.
+"""
+import numpy as np
+import pytest
+
+from soundsym_amd import Engine, synth
+from soundsym_amd.engine import pack_segments
+
+pytestmark = pytest.mark.gpu
+
+
+def _ragged(st, n, lo, hi, dim, scale):
+    lens = lo + st.integers(n, hi - lo + 1)
+    return [(st.normal(int(f) * dim).reshape(int(f), dim) * synth.sigma(dim) * scale) for f in lens]
+
+
+@pytest.mark.parametrize("case", range(120))
+def test_dtw_random_shapes(oracle, case):
+    st = synth.Stream(0x5EED1000 + case)
+    dim = int([1, 2, 5, 12, 13, 14, 20, 40, 42][st.integers(1, 9)[0]])
+    hi = int([3, 17, 33, 50, 66, 130, 150][st.integers(1, 7)[0]])
+    lo = int(st.integers(1, 2)[0])                      # 0 or 1: empty segments allowed
+    n, m = int(2 + st.integers(1, 30)[0]), int(1 + st.integers(1, 40)[0])
+    band = int([-1, -1, -1, 0, 1, 5, 20, 47, 60][st.integers(1, 9)[0]])
+    squared = bool(st.integers(1, 4)[0] == 0)
+    dtype = ["f32", "f64"][int(st.integers(1, 2)[0])]
+    scale = float([1e-3, 1.0, 300.0][st.integers(1, 3)[0]])
+    src = _ragged(st, n, lo, hi, dim, scale)
+    tgt = _ragged(st, m, lo, hi, dim, scale)
+    if m > 2 and n > 3 and src[3].shape[0] > 0:
+        tgt[1] = src[3].copy()                           # an exact match
+        tgt[2] = src[3][: max(1, src[3].shape[0] - 1)].copy()
+    if n > 6:
+        src[6] = src[2].copy()                           # duplicates: first index wins
+    npdt = np.float32 if dtype == "f32" else np.float64
+    sf, so = pack_segments(src, dim, npdt)
+    tf, to = pack_segments(tgt, dim, npdt)
+    use_dist = bool(st.integers(1, 3)[0] == 0)
+    e = Engine(metric="dtw", dtype=dtype, band=band, squared=squared)
+    d, q = e.dictionary(sf, so, dim), e.queries(tf, to, dim)
+    want_idx, want_cost, mat = oracle.dtw_match_all(sf.astype(np.float64), so, tf.astype(np.float64), to, dim,
+                                                    band=band, squared=squared, want_matrix=True, nthreads=4)
+    if use_dist:
+        fin = np.where(np.isfinite(mat), mat, np.nan)
+        with np.errstate(all="ignore"):
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                dist = np.nan_to_num(np.nanmedian(fin, axis=0), nan=1.0)
+        key = np.abs(mat - dist[None, :])
+        key = np.where(np.isnan(key), np.inf, key)
+        want_idx = np.where(np.isfinite(key).any(axis=0), key.argmin(axis=0), 0)
+        want_cost = np.where(np.isfinite(key).any(axis=0), mat[want_idx, np.arange(m)], np.inf)
+        idx, cost = e.match(d, q, distance=dist)
+    else:
+        idx, cost = e.match(d, q)
+    info = dict(case=case, dim=dim, hi=hi, n=n, m=m, band=band, squared=squared, dtype=dtype, scale=scale,
+                dist=use_dist, filter=e.timings()["used_filter"])
+    assert np.array_equal(idx, want_idx), info
+    assert np.array_equal(np.isinf(cost), np.isinf(want_cost)), info
+    fin = np.isfinite(want_cost)
+    assert np.allclose(cost[fin], want_cost[fin], rtol=1e-12, atol=0), info
+    e.close()
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_refcos_random_shapes(oracle, case):
+    st = synth.Stream(0x5EED2000 + case)
+    dim = int([1, 3, 12, 13, 40][st.integers(1, 5)[0]])
+    hi = int([2, 9, 40, 100][st.integers(1, 4)[0]])
+    n, m = int(1 + st.integers(1, 70)[0]), int(1 + st.integers(1, 70)[0])
+    src = _ragged(st, n, 0, hi, dim, 0.05)
+    tgt = _ragged(st, m, 0, hi, dim, 0.05)
+    sf, so = pack_segments(src, dim)
+    tf, to = pack_segments(tgt, dim)
+    dist = None if case % 2 == 0 else np.abs(st.normal(m)) * 0.01
+    e = Engine(metric="refcos", dtype="f64")
+    idx, val = e.match(e.dictionary(sf, so, dim), e.queries(tf, to, dim), distance=dist)
+    want_idx, want_val = oracle.refcos_match_all(sf, so, tf, to, dim, dist)
+    assert np.array_equal(idx, want_idx) and np.array_equal(val, want_val), (case, dim, hi, n, m)
+    e.close()
