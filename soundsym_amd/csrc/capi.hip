@@ -95,7 +95,8 @@ int32_t ssym_ctx_destroy(ssym_ctx *ctx)
         return SSYM_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    DeviceBuf *bufs[] = {&ctx->handoff, &ctx->cmat, &ctx->tmin, &ctx->cand, &ctx->cand_cost, &ctx->best,
+    DeviceBuf *bufs[] = {&ctx->handoff, &ctx->cmat, &ctx->tmin, &ctx->cand, &ctx->cand2, &ctx->cand_xmin,
+                         &ctx->cand_cost, &ctx->best,
                          &ctx->dist, &ctx->part, &ctx->out_idx, &ctx->out_cost};
     for (DeviceBuf *b : bufs)
         if (b->ptr)
@@ -351,34 +352,44 @@ int32_t ssym_match_queries(ssym_ctx *ctx, const ssym_dict *dict, const ssym_quer
         const bool useFilter = !(flags & SSYM_DTW_FORCE_EXACT) && filter_supported(ctx, src, tgt);
         tm.used_filter = useFilter ? 1 : 0;
         if (useFilter) {
-            const size_t matElems = (size_t)src.n_pad * tgt.n_pad;
-            rc = ensure(ctx, ctx->cmat, sizeof(float) * 2 * matElems);
+            rc = ensure(ctx, ctx->cmat, sizeof(float) * (size_t)src.n_pad * tgt.n_pad);
             if (rc != SSYM_OK)
                 return rc;
             float *cmat = (float *)ctx->cmat.ptr;
-            float *xminmat = cmat + matElems;
             SSYM_HIP_CHECK(ctx, hipEventRecord(ev[0], st));
-            rc = launch_dtw_filter(ctx, src, tgt, cmat, xminmat);
+            rc = launch_dtw_filter(ctx, src, tgt, cmat);
             if (rc != SSYM_OK)
                 return rc;
             SSYM_HIP_CHECK(ctx, hipEventRecord(ev[1], st));
             tm.main_launches = 1;
-            // candidate capacity: a few per target is the normal case; on overflow redo the
-            // selection with room for every pair (exactness never depends on the capacity)
-            uint64_t cap = std::max<uint64_t>(4ull * M, 4096);
+            // list 1 (worst-case margin) is usually tens of pairs per target at most; on overflow
+            // the selection is redone with room for every pair (exactness never depends on it)
+            uint64_t cap = std::max<uint64_t>(64ull * M, 65536);
             cap = std::min<uint64_t>(cap, (uint64_t)N * M);
             float sel_ms = 0.f, ref_ms = 0.f, red_ms = 0.f;
             for (int attempt = 0; attempt < 2; ++attempt) {
                 SSYM_HIP_CHECK(ctx, hipEventRecord(ev[2], st));
-                rc = launch_dtw_select(ctx, src, tgt, cmat, xminmat, distDev, (uint32_t)cap);
+                rc = launch_dtw_select(ctx, src, tgt, cmat, distDev, (uint32_t)cap);          // stage 1
+                if (rc != SSYM_OK)
+                    return rc;
+                uint32_t *hdr1 = (uint32_t *)ctx->cand.ptr;
+                rc = ensure(ctx, ctx->cand_xmin, sizeof(float) * cap);
+                if (rc != SSYM_OK)
+                    return rc;
+                rc = launch_certify(ctx, src, tgt, hdr1, (const uint2 *)(hdr1 + 2), (uint32_t)cap,
+                                    (float *)ctx->cand_xmin.ptr);                               // certificates
+                if (rc != SSYM_OK)
+                    return rc;
+                rc = launch_dtw_select2(ctx, src, tgt, cmat, (const float *)ctx->cand_xmin.ptr, distDev,
+                                        (uint32_t)cap);                                         // stage 2
                 if (rc != SSYM_OK)
                     return rc;
                 SSYM_HIP_CHECK(ctx, hipEventRecord(ev[3], st));
                 rc = ensure(ctx, ctx->cand_cost, sizeof(double) * cap);
                 if (rc != SSYM_OK)
                     return rc;
-                uint32_t *hdr = (uint32_t *)ctx->cand.ptr;
-                rc = launch_dtw_exact(ctx, src, tgt, (const uint2 *)(hdr + 2), hdr, (uint32_t)cap,
+                uint32_t *hdr2 = (uint32_t *)ctx->cand2.ptr;
+                rc = launch_dtw_exact(ctx, src, tgt, (const uint2 *)(hdr2 + 2), hdr2, (uint32_t)cap,
                                       (double *)ctx->cand_cost.ptr);
                 if (rc != SSYM_OK)
                     return rc;
@@ -387,14 +398,15 @@ int32_t ssym_match_queries(ssym_ctx *ctx, const ssym_dict *dict, const ssym_quer
                 if (rc != SSYM_OK)
                     return rc;
                 SSYM_HIP_CHECK(ctx, hipEventRecord(ev[5], st));
-                uint32_t h[2] = {0, 0};
-                SSYM_HIP_CHECK(ctx, hipMemcpyAsync(h, hdr, sizeof(h), hipMemcpyDeviceToHost, st));
+                uint32_t h1[2] = {0, 0}, h2[2] = {0, 0};
+                SSYM_HIP_CHECK(ctx, hipMemcpyAsync(h1, hdr1, sizeof(h1), hipMemcpyDeviceToHost, st));
+                SSYM_HIP_CHECK(ctx, hipMemcpyAsync(h2, hdr2, sizeof(h2), hipMemcpyDeviceToHost, st));
                 SSYM_HIP_CHECK(ctx, hipStreamSynchronize(st));
                 sel_ms += ev_ms(ev[2], ev[3]);
                 ref_ms += ev_ms(ev[3], ev[4]);
                 red_ms += ev_ms(ev[4], ev[5]);
-                tm.n_refined = std::min<uint64_t>(h[0], cap);
-                if (!h[1])
+                tm.n_refined = h2[0];
+                if (!h1[1])
                     break;
                 if (attempt == 1 || cap == (uint64_t)N * M) {
                     ctx->err = "dtw: candidate list overflow";
@@ -519,11 +531,10 @@ int32_t ssym_pair_matrix(ssym_ctx *ctx, const ssym_dict *dict, const ssym_querie
             ctx->err = "dtw filter does not cover this shape (band / frames / dim); ask for exact = 1";
             return SSYM_E_UNSUPPORTED;
         }
-        const size_t matElems = (size_t)src.n_pad * tgt.n_pad;
-        rc = ensure(ctx, ctx->cmat, sizeof(float) * 2 * matElems);
+        rc = ensure(ctx, ctx->cmat, sizeof(float) * (size_t)src.n_pad * tgt.n_pad);
         if (rc != SSYM_OK)
             return rc;
-        rc = launch_dtw_filter(ctx, src, tgt, (float *)ctx->cmat.ptr, (float *)ctx->cmat.ptr + matElems);
+        rc = launch_dtw_filter(ctx, src, tgt, (float *)ctx->cmat.ptr);
         if (rc == SSYM_OK) {
             dim3 grid((M + 255) / 256, N);
             f32_to_f64_matrix_kernel<<<grid, 256, 0, st>>>((const float *)ctx->cmat.ptr, N, M, tgt.n_pad, mat);

@@ -1,0 +1,74 @@
+// certify.hip -- per-pair error certificates for the dtw filter, computed only where they matter.
+//
+// The filter's error on a pair is small unless some cell of the pair is nearly zero (the square
+// root amplifies the cancellation error of the expanded form there).  Knowing
+//     m(s,t) = min over all cells (i,j) of x~(i,j),   x~ = the f16-split MFMA value of |a_i - b_j|^2,
+// bounds every cell's error by E / (2 sqrt(m - 2E)) (select.hip).  Tracking m inside the filter
+// kernel costs half a v_min3_f32 per cell on all N x M pairs (measured +8 %); instead the first,
+// worst-case-margin selection leaves a short list of pairs per target and this kernel computes m for
+// those only: one wave per listed pair, plain 32 x 32 tiles (32 source frames x 32 target frames of
+// ONE pair), three chained v_mfma_f32_32x32x16_f16 on the same operand records the filter uses,
+// v_min3_f32 over the accumulators, one wave reduction at the end.
+#include "ssym_internal.hpp"
+#include "dtw_filter_kernel.hpp"
+
+namespace ssym {
+
+__global__ __launch_bounds__(64) void certify_kernel(const _Float16 *__restrict__ srcRec,
+                                                     const _Float16 *__restrict__ tgtRec,
+                                                     const int *__restrict__ srcLen, const int *__restrict__ tgtLen,
+                                                     int srcSlots, int srcLead, int tgtSlots,
+                                                     const uint32_t *__restrict__ candHdr,
+                                                     const uint2 *__restrict__ pairs, uint32_t cap, float outScaleSq,
+                                                     float *__restrict__ xmin)
+{
+    constexpr int REC = kFilterRecHalfs;
+    const float INF = __builtin_inff();
+    const int lane = threadIdx.x;
+    const int rc = lane & 31, kh = lane >> 5;
+    const uint32_t n = min(candHdr[0], cap);
+    for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) {
+        const uint2 p = pairs[k];
+        const int fa = srcLen[p.x], fb = tgtLen[p.y];
+        float m = INF;
+        if (fa > 0 && fb > 0) {
+            // frame f of the source sits in slot first + f (end-aligned when srcLead < 0)
+            const int first = srcLead < 0 ? srcSlots - fa : srcLead;
+            const _Float16 *sBase = srcRec + ((size_t)p.x * srcSlots + first) * REC + kh * 24;
+            const _Float16 *tBase = tgtRec + ((size_t)p.y * tgtSlots) * REC + kh * 24;
+            for (int i0 = 0; i0 < fa; i0 += 32) {
+                half8 A[kFilterKM];
+                load_rec(sBase + (size_t)min(i0 + rc, fa - 1) * REC, A);      // rows past the end repeat the last frame
+                for (int j0 = 0; j0 < fb; j0 += 32) {
+                    half8 B[kFilterKM];
+                    load_rec(tBase + (size_t)min(j0 + rc, fb - 1) * REC, B);
+                    const f32x16 acc = mfma_tile<kFilterKM>(A, B);
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2)
+                        m = __builtin_fminf(__builtin_fminf(m, acc[r]), acc[r + 1]);
+                }
+            }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1)
+                m = __builtin_fminf(m, __shfl_xor(m, o));
+        }
+        if (lane == 0)
+            xmin[k] = m * outScaleSq;
+    }
+}
+
+int32_t launch_certify(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, const uint32_t *candHdr,
+                       const uint2 *pairs, uint32_t cap, float *xmin)
+{
+    if (cap == 0)
+        return SSYM_OK;
+    const double s = src.rec_scale > 0.0 ? src.rec_scale : 1.0;
+    const unsigned grid = (unsigned)std::min<uint64_t>(cap, (uint64_t)ctx->num_cus * 64);
+    certify_kernel<<<grid, 64, 0, ctx->stream>>>((const _Float16 *)src.rec, (const _Float16 *)tgt.rec, src.len,
+                                                  tgt.len, (int)src.rec_slots, src.rec_lead, (int)tgt.rec_slots,
+                                                  candHdr, pairs, cap, (float)(1.0 / (s * s)), xmin);
+    SSYM_HIP_CHECK(ctx, hipGetLastError());
+    return SSYM_OK;
+}
+
+}  // namespace ssym

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(64 * WB, OCC) void dtw_band_kernel(
     const _Float16 *__restrict__ srcRec, const _Float16 *__restrict__ tgtRec,
     const int *__restrict__ srcLen, const int *__restrict__ tgtLen, int srcSlots, int radius,
     int tgtFramesPad, int mPad, int nTgtBlocks, int nTasks, int tasksPerBlock, float outScale,
-    float outScaleSq, float *__restrict__ cmat, float *__restrict__ xminmat)
+    float *__restrict__ cmat)
 {
     constexpr int REC = kFilterRecHalfs;
     constexpr int KB = NTB * 16;           // diagonals held in registers (>= 2r+1)
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(64 * WB, OCC) void dtw_band_kernel(
 #pragma unroll
         for (int k = 0; k <= KB; ++k)
             L[k] = (k == radius) ? 0.0f : INF;
-        float res = INF, xmin = INF;
+        float res = INF;
         const int kstar = fa - 1 - fb_m1 + radius;     // diagonal of the end cell (fa-1, fb-1)
 
         const _Float16 *bbase = tgtRec + ((size_t)(32 * tg + col) * tgtFramesPad) * REC + half * 24;
@@ -122,9 +122,6 @@ __global__ __launch_bounds__(64 * WB, OCC) void dtw_band_kernel(
                             }
                         }
 #pragma unroll
-                        for (int r = 0; r < 16; r += 2)
-                            xmin = __builtin_fminf(__builtin_fminf(xmin, acc[r]), acc[r + 1]);
-#pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int k = T * 16 + r;
                             const float x = acc[r];
@@ -150,9 +147,7 @@ __global__ __launch_bounds__(64 * WB, OCC) void dtw_band_kernel(
                 }
             }
         }
-        const size_t o = (size_t)(2 * sp + half) * mPad + 32 * tg + col;
-        cmat[o] = res * outScale;
-        xminmat[o] = xmin * outScaleSq;
+        cmat[(size_t)(2 * sp + half) * mPad + 32 * tg + col] = res * outScale;
     }
 }
 

@@ -148,20 +148,19 @@ static int32_t ensure_records(ssym_ctx *ctx, const SegmentSet &set, double scale
 
 template <int NT, bool SQ>
 static void launch_one(hipStream_t st, const SegmentSet &src, const SegmentSet &tgt, int nPasses,
-                       int gridBlocks, float outScale, float outScaleSq, float *handoff, float *cmat,
-                       float *xminmat)
+                       int gridBlocks, float outScale, float *handoff, float *cmat)
 {
     const int nSrcBlocks = (int)src.n_pad / (2 * kFilterWavesPerBlock);
     const int nTgtGroups = (int)tgt.n_pad / 32;
     const int nTasks = nSrcBlocks * nTgtGroups;
     dtw_filter_kernel<NT, SQ><<<dim3(std::min(gridBlocks, (nTasks + 7) / 8 * 8)), 64 * kFilterWavesPerBlock, 0, st>>>(
         (const _Float16 *)src.rec, (const _Float16 *)tgt.rec, src.len, tgt.len, (int)src.frames_pad, nPasses,
-        (int)tgt.frames_pad, (int)tgt.n_pad, nSrcBlocks, nTasks, outScale, outScaleSq, handoff, cmat, xminmat);
+        (int)tgt.frames_pad, (int)tgt.n_pad, nSrcBlocks, nTasks, outScale, handoff, cmat);
 }
 
 template <int NTB, int WB, int OCC, bool SQ>
 static int32_t launch_band_cfg(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, uint32_t slots,
-                               size_t lds, float outScale, float outScaleSq, float *cmat, float *xminmat)
+                               size_t lds, float outScale, float *cmat)
 {
     const int nTgtBlocks = (int)tgt.n_pad / (32 * WB);
     const int nTasks = ((int)src.n_pad / 2) * nTgtBlocks;
@@ -172,8 +171,7 @@ static int32_t launch_band_cfg(ssym_ctx *ctx, const SegmentSet &src, const Segme
         SSYM_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     kern<<<dim3(grid), 64 * WB, lds, ctx->stream>>>(
         (const _Float16 *)src.rec, (const _Float16 *)tgt.rec, src.len, tgt.len, (int)slots, ctx->band,
-        (int)tgt.frames_pad, (int)tgt.n_pad, nTgtBlocks, nTasks, tasksPerBlock, outScale, outScaleSq, cmat,
-        xminmat);
+        (int)tgt.frames_pad, (int)tgt.n_pad, nTgtBlocks, nTasks, tasksPerBlock, outScale, cmat);
     SSYM_HIP_CHECK(ctx, hipGetLastError());
     return SSYM_OK;
 }
@@ -184,16 +182,15 @@ static int32_t launch_band_cfg(ssym_ctx *ctx, const SegmentSet &src, const Segme
 // SSYM_BAND_OCC1=1 forces the one-wave variant for tuning experiments.
 template <int NTB, bool SQ>
 static int32_t launch_band(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, uint32_t slots,
-                           size_t lds, float outScale, float outScaleSq, float *cmat, float *xminmat)
+                           size_t lds, float outScale, float *cmat)
 {
     static const bool forceOcc1 = getenv("SSYM_BAND_OCC1") != nullptr;
     if (NTB <= 5 && !forceOcc1)
-        return launch_band_cfg<NTB, 8, 2, SQ>(ctx, src, tgt, slots, lds, outScale, outScaleSq, cmat, xminmat);
-    return launch_band_cfg<NTB, 4, 1, SQ>(ctx, src, tgt, slots, lds, outScale, outScaleSq, cmat, xminmat);
+        return launch_band_cfg<NTB, 8, 2, SQ>(ctx, src, tgt, slots, lds, outScale, cmat);
+    return launch_band_cfg<NTB, 4, 1, SQ>(ctx, src, tgt, slots, lds, outScale, cmat);
 }
 
-static int32_t launch_dtw_filter_banded(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, float *cmat,
-                                        float *xminmat)
+static int32_t launch_dtw_filter_banded(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, float *cmat)
 {
     if (tgt.n_pad % kBandTgtQuantum != 0 || src.n_pad % 2 != 0) {
         ctx->err = "dtw band filter: segment set not padded for the banded kernel";
@@ -209,13 +206,12 @@ static int32_t launch_dtw_filter_banded(ssym_ctx *ctx, const SegmentSet &src, co
     if (rc != SSYM_OK)
         return rc;
     const bool sq = ctx->squared != 0;
-    const float outScaleSq = (float)(1.0 / (scale * scale));
-    const float outScale = sq ? outScaleSq : (float)(1.0 / scale);
+    const float outScale = (float)(sq ? 1.0 / (scale * scale) : 1.0 / scale);
     const int ntb = (2 * ctx->band + 1 + 15) / 16;
 #define SSYM_BCASE(N_)                                                                                  \
     case N_:                                                                                            \
-        return sq ? launch_band<N_, true>(ctx, src, tgt, slots, lds, outScale, outScaleSq, cmat, xminmat)  \
-                  : launch_band<N_, false>(ctx, src, tgt, slots, lds, outScale, outScaleSq, cmat, xminmat);
+        return sq ? launch_band<N_, true>(ctx, src, tgt, slots, lds, outScale, cmat)   \
+                  : launch_band<N_, false>(ctx, src, tgt, slots, lds, outScale, cmat);
     switch (ntb) {
         SSYM_BCASE(1) SSYM_BCASE(2) SSYM_BCASE(3) SSYM_BCASE(4) SSYM_BCASE(5) SSYM_BCASE(6)
     default:
@@ -225,11 +221,10 @@ static int32_t launch_dtw_filter_banded(ssym_ctx *ctx, const SegmentSet &src, co
 #undef SSYM_BCASE
 }
 
-int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, float *cmat,
-                          float *xminmat)
+int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, float *cmat)
 {
     if (ctx->band >= 0)
-        return launch_dtw_filter_banded(ctx, src, tgt, cmat, xminmat);
+        return launch_dtw_filter_banded(ctx, src, tgt, cmat);
     const FilterShape shape = filter_shape((int)src.max_frames);
     if (shape.nt == 0 || (int)src.frames_pad != shape.rows() || src.n_pad % 8 != 0 || tgt.n_pad % 32 != 0) {
         ctx->err = "dtw filter: segment set not padded for the filter kernel";
@@ -250,13 +245,12 @@ int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
         return rc;
     hipStream_t st = ctx->stream;
     const bool sq = ctx->squared != 0;
-    const float outScaleSq = (float)(1.0 / (scale * scale));
-    const float outScale = sq ? outScaleSq : (float)(1.0 / scale);
+    const float outScale = (float)(sq ? 1.0 / (scale * scale) : 1.0 / scale);
     float *hand = (float *)ctx->handoff.ptr;
 #define SSYM_CASE(NT_)                                                                          \
     case NT_:                                                                                   \
-        if (sq) launch_one<NT_, true>(st, src, tgt, shape.rb, gridBlocks, outScale, outScaleSq, hand, cmat, xminmat);  \
-        else launch_one<NT_, false>(st, src, tgt, shape.rb, gridBlocks, outScale, outScaleSq, hand, cmat, xminmat);    \
+        if (sq) launch_one<NT_, true>(st, src, tgt, shape.rb, gridBlocks, outScale, hand, cmat);  \
+        else launch_one<NT_, false>(st, src, tgt, shape.rb, gridBlocks, outScale, hand, cmat);    \
         break;
     switch (shape.nt) {
         SSYM_CASE(1) SSYM_CASE(2) SSYM_CASE(3) SSYM_CASE(4)

@@ -19,11 +19,11 @@
 //     lane (col = lane&31, half = lane>>5) is cell (row r, column j) of the pair
 //     (source 2*sp+half, target 32*tg+col);
 //   * DP: min-of-three recurrence, lane-local, 3 VALU instructions per cell (v_sqrt_f32 |x|,
-//     v_min3_f32, v_add_f32) plus half a v_min3_f32 that tracks the pair's smallest cell.  The
-//     column lives in ONE register array that slides down by one register per column (the new
-//     D(i,j) overwrites the just-consumed D(i-1,j-1)) and is moved back every 4 columns; an
-//     earlier version where the previous column is read from one register array and the new
-//     column written to the other (ping-pong, no register moves);
+//     v_min3_f32, v_add_f32); the previous column is read from one register array and the new
+//     column written to the other (ping-pong over a 2-column unroll, no register moves).  The
+//     per-pair error certificate (smallest cell) is NOT tracked here: certify.hip computes it
+//     afterwards for the few pairs that survive a first, worst-case-margin selection, which is
+//     8 % cheaper than half a v_min3 per cell on all N x M pairs;
 //   * a wave keeps 16*NT rows of the column in registers; longer sources are processed in row-block
 //     PASSES by the same wave: pass p sweeps all columns for rows [p*16*NT, (p+1)*16*NT) and leaves
 //     the bottom row of its block, D(last row, j), in a per-wave hand-off row in global memory
@@ -56,11 +56,6 @@ constexpr int kFilterMaxDim1 = 42;       // one f16 piece per value:  42 product
 // reads its 8 K-values at f16 offset h*24 + m*8, i.e. logical K slot 16*m + 8*h + j.
 __host__ __device__ constexpr int filter_slot_offset(int k) { return ((k >> 3) & 1) * 24 + (k >> 4) * 8 + (k & 7); }
 
-#ifndef SSYM_FILTER_SLIDE
-#define SSYM_FILTER_SLIDE 4
-#endif
-constexpr int kFilterSlide = SSYM_FILTER_SLIDE;   // columns per slide-back of the DP column array (4 or 8)
-
 template <int KM>
 __device__ __forceinline__ f32x16 mfma_tile(const half8 (&a)[KM], const half8 (&b)[KM])
 {
@@ -88,13 +83,11 @@ __device__ __forceinline__ void load_rec(const _Float16 *__restrict__ p, half8 (
 }
 
 // One column of one row block: NT tiles, software-pipelined (the next tile's MFMA chain is in
-// flight while this tile's 16 cells run on the VALU).
-// Column array: before the column, D(i, j-1) sits in L[OFF + i]; the new D(i, j) is written to
-// L[OFF - 1 + i], the register that held D(i-1, j-1), which row i has just consumed as its diagonal.
-template <int NT, int OFF, bool SQ>
+// flight while this tile's 16 cells run on the VALU).  Lr = D(., j-1), Lw = D(., j).
+template <int NT, bool SQ>
 __device__ __forceinline__ float dp_column(const half8 (&A)[NT][kFilterKM], const half8 (&Bc)[kFilterKM],
-                                           const half8 (&Bn)[kFilterKM], f32x16 &acc, float up, float diagTop,
-                                           float (&L)[NT * 16 + kFilterSlide], float &xmin)
+                                           const half8 (&Bn)[kFilterKM], f32x16 &acc, float up, float diag,
+                                           const float (&Lr)[NT * 16], float (&Lw)[NT * 16])
 {
 #pragma unroll
     for (int T = 0; T < NT; ++T) {
@@ -106,24 +99,17 @@ __device__ __forceinline__ float dp_column(const half8 (&A)[NT][kFilterKM], cons
 #if SSYM_FILTER_MODE == 1
         asm volatile("" ::"v"(acc[0]), "v"(acc[15]));
         up = acc[3];
-        L[OFF - 1 + T * 16] = L[OFF + T * 16];
+        Lw[T * 16] = Lr[T * 16];
 #else
-        // smallest |a-b|^2 seen by this pair (one v_min3 per two cells): select.hip turns it into
-        // a per-pair bound on the filter's error, so that only genuine near-ties are re-scored
-#ifndef SSYM_FILTER_NOTRACK   // tools only: measure what the tracking costs
-#pragma unroll
-        for (int r = 0; r < 16; r += 2)
-            xmin = __builtin_fminf(__builtin_fminf(xmin, acc[r]), acc[r + 1]);
-#endif
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int idx = T * 16 + r;
             const float x = acc[r];
             const float c = SQ ? __builtin_fabsf(x) : __builtin_amdgcn_sqrtf(__builtin_fabsf(x));
-            const float dg = (idx == 0) ? diagTop : L[OFF + idx - 1];
-            const float m = __builtin_fminf(__builtin_fminf(up, dg), L[OFF + idx]);
+            const float m = __builtin_fminf(__builtin_fminf(up, diag), Lr[idx]);
+            diag = Lr[idx];
             const float cur = c + m;
-            L[OFF - 1 + idx] = cur;
+            Lw[idx] = cur;
             up = cur;
         }
 #endif
@@ -140,8 +126,8 @@ template <int NT, bool SQ>
 __global__ __launch_bounds__(64 * kFilterWavesPerBlock, 2) void dtw_filter_kernel(
     const _Float16 *__restrict__ srcRec, const _Float16 *__restrict__ tgtRec,
     const int *__restrict__ srcLen, const int *__restrict__ tgtLen, int srcRows, int nPasses,
-    int tgtFramesPad, int mPad, int nSrcBlocks, int nTasks, float outScale, float outScaleSq,
-    float *__restrict__ handoff, float *__restrict__ cmat, float *__restrict__ xminmat)
+    int tgtFramesPad, int mPad, int nSrcBlocks, int nTasks, float outScale,
+    float *__restrict__ handoff, float *__restrict__ cmat)
 {
     constexpr int REC = kFilterRecHalfs;
     constexpr int BR = NT * 16;            // rows per pass
@@ -181,7 +167,6 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, 2) void dtw_filter_kerne
         const int firstPass = min(max(r0min - 1, 0) / BR, nPasses - 1);
 
         float res = INF;
-        float xmin = INF;              // min over the pair's cells of the accumulator (scaled |a-b|^2)
         const _Float16 *bbase = tgtRec + ((size_t)(32 * tg + col) * tgtFramesPad) * REC + half * 24;
 
         for (int pass = firstPass; pass < nPasses; ++pass) {
@@ -201,12 +186,13 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, 2) void dtw_filter_kerne
                     load_rec(abase + (size_t)T * kFilterRowsPerTile * REC, A[T]);
             }
 
-            // D(., -1) at L[SL + i]: +inf, except the virtual D(r0-1, -1) = 0 that starts the recurrence
-            constexpr int SL = kFilterSlide;
-            float L[BR + SL];
+            // D(., -1): +inf, except the virtual D(r0-1, -1) = 0 that starts the recurrence
+            float L0[BR], L1[BR];
 #pragma unroll
-            for (int i = 0; i < BR + SL; ++i)
-                L[i] = (i >= SL && rowBase + (i - SL) == r0 - 1) ? 0.0f : INF;
+            for (int i = 0; i < BR; ++i) {
+                L0[i] = (rowBase + i == r0 - 1) ? 0.0f : INF;
+                L1[i] = L0[i];
+            }
             const float diagCol0 = (rowBase == r0) ? 0.0f : INF;   // D(rowBase-1, -1)
             float prevTop = INF;                                    // D(rowBase-1, j-1)
 
@@ -223,19 +209,13 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, 2) void dtw_filter_kerne
             }
             f32x16 acc = mfma_tile<kFilterKM>(A[0], B0);
 
-            for (int j0 = 0; j0 < nCols; j0 += SL) {
-                if (j0 > 0) {
-                    // slide the column back up: D(i, j0-1) from L[i] to L[SL + i]
+            for (int j0 = 0; j0 < nCols; j0 += 2) {
 #pragma unroll
-                    for (int i = BR - 1; i >= 0; --i)
-                        L[SL + i] = L[i];
-                }
-#pragma unroll
-                for (int u = 0; u < SL; ++u) {
-                    const int j = j0 + u;
+                for (int par = 0; par < 2; ++par) {
+                    const int j = j0 + par;
                     if (j < nCols) {                                // wave-uniform
                         const int jn = min(j + 1, nCols - 1);
-                        if ((u & 1) == 0)
+                        if (par == 0)
                             load_rec(bbase + (size_t)jn * REC, B1);
                         else
                             load_rec(bbase + (size_t)jn * REC, B0);
@@ -244,19 +224,11 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, 2) void dtw_filter_kerne
                         prevTop = up;
                         if (haveTop)
                             topN = hand[(size_t)jn * 64];           // next column's top boundary
-                        float bottom = 0.0f;
-                        switch (u) {   // u is a constant after unrolling: one case survives
-                        case 0: bottom = dp_column<NT, SL - 0, SQ>(A, B0, B1, acc, up, diag, L, xmin); break;
-                        case 1: bottom = dp_column<NT, SL - 1, SQ>(A, B1, B0, acc, up, diag, L, xmin); break;
-                        case 2: bottom = dp_column<NT, SL - 2, SQ>(A, B0, B1, acc, up, diag, L, xmin); break;
-                        case 3: bottom = dp_column<NT, SL - 3, SQ>(A, B1, B0, acc, up, diag, L, xmin); break;
-#if SSYM_FILTER_SLIDE == 8
-                        case 4: bottom = dp_column<NT, SL - 4, SQ>(A, B0, B1, acc, up, diag, L, xmin); break;
-                        case 5: bottom = dp_column<NT, SL - 5, SQ>(A, B1, B0, acc, up, diag, L, xmin); break;
-                        case 6: bottom = dp_column<NT, SL - 6, SQ>(A, B0, B1, acc, up, diag, L, xmin); break;
-                        case 7: bottom = dp_column<NT, SL - 7, SQ>(A, B1, B0, acc, up, diag, L, xmin); break;
-#endif
-                        }
+                        float bottom;
+                        if (par == 0)
+                            bottom = dp_column<NT, SQ>(A, B0, B1, acc, up, diag, L0, L1);
+                        else
+                            bottom = dp_column<NT, SQ>(A, B1, B0, acc, up, diag, L1, L0);
                         if (!lastPass)
                             hand[(size_t)j * 64] = bottom;          // top boundary of the next pass
                         else
@@ -265,9 +237,7 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, 2) void dtw_filter_kerne
                 }
             }
         }
-        const size_t o = (size_t)(2 * sp + half) * mPad + 32 * tg + col;
-        cmat[o] = res * outScale;
-        xminmat[o] = xmin * outScaleSq;
+        cmat[(size_t)(2 * sp + half) * mPad + 32 * tg + col] = res * outScale;
     }
 }
 

@@ -27,11 +27,13 @@ namespace ssym {
 //      48 roundings (counted twice in case the matrix pipe truncates): 2 * 48 u * 2(|a|^2+|b|^2);
 //      together  |x~ - x| <= 204 u (|a|^2 + |b|^2) + 2^-12   -- the code uses
 //          E = 256 u (max|a|^2 of the source + max|b|^2 of the target) + 2^-12 / s^2   (unscaled).
-//  local cost c~ = v_sqrt_f32(|x~|):  |c~ - c| = |x~ - x| / (c~ + c).  The kernel reports, per pair,
-//      m = the smallest accumulator value over all of the pair's cells, so every cell has
-//      x~ >= m and x >= m - E:
-//          m > 4E :  |c~ - c| <= E / (2 sqrt(m - E))          (no cell is near zero)
+//  local cost c~ = v_sqrt_f32(|x~|):  |c~ - c| = |x~ - x| / (c~ + c).  certify.hip reports, for
+//      the pairs that matter, m = the smallest value of the same MFMA expression over all of the
+//      pair's cells (recomputed, so within E of x like the filter's own value): every cell has
+//      x >= m - E and x~ >= m - 2E:
+//          m > 6E :  |c~ - c| <= E / (2 sqrt(m - 2E))         (no cell is near zero)
 //          else   :  |c~ - c| <= sqrt(E)                      (|sqrt(y) - sqrt(x)| <= sqrt|y - x|)
+//      (m = 0 stands for "no certificate": the first, worst-case selection over all N x M pairs)
 //      squared-L2 mode: |c~ - c| <= E.   The norms in the records are those of the REPRESENTED
 //      frames, so x is the squared distance of the rounded frames; rounding to the f16 piece(s)
 //      moves every frame by <= rho |frame| (rho = 2^-22 with two pieces, 2^-11 with one, dims 14..42)
@@ -40,9 +42,11 @@ namespace ssym {
 //      within 1 ulp, and DTW is monotone and 1-Lipschitz in the cell costs along the optimal path
 //      of either side, so for EVERY pair
 //          |C~ - C| <= err := L * cell + (L + 6) u * C~ .
-//  Selection (rigorous): C lies in [C~ - err, C~ + err], hence key = |C - delta| lies in
+//  Selection (rigorous), two stages: C lies in [C~ - err, C~ + err], hence key = |C - delta| lies in
 //      [key_lo, key_hi]; the exact first minimum over s is attained by some s with
-//      key_lo(s) <= min_s' key_hi(s'), and only those pairs are re-scored exactly.
+//      key_lo(s) <= min_s' key_hi(s').  Stage 1 applies this to all N x M pairs with the worst-case
+//      err (m = 0) and keeps list 1; certify.hip computes m for list 1; stage 2 applies it again
+//      inside list 1 with the per-pair err and keeps list 2, which is re-scored exactly.
 // ---------------------------------------------------------------------------------------------
 struct MarginParams {
     double inv_scale2;  // 1 / s^2
@@ -68,7 +72,7 @@ __device__ __forceinline__ void dtw_key_interval(const MarginParams &mp, double 
     if (mp.squared)
         cell = E + 4.1 * mp.in_round * (na + nb);
     else
-        cell = (xmin > 4.0 * E ? E / (2.0 * sqrt(xmin - E)) : sqrt(E)) + 1.001 * mp.in_round * (sqrt(na) + sqrt(nb));
+        cell = (xmin > 6.0 * E ? E / (2.0 * sqrt(xmin - 2.0 * E)) : sqrt(E)) + 1.001 * mp.in_round * (sqrt(na) + sqrt(nb));
     // f16 pieces below 2^-14 are subnormal: their absolute rounding 2^-25 (scaled units) per value,
     // over at most 42 values of both frames
     cell += 9.5367431640625e-07 * sqrt(mp.inv_scale2);
@@ -97,7 +101,7 @@ constexpr int kSelChunk = 64;   // sources scanned per thread
 
 // ub[t] = min_s key_hi(s,t) as order-preserving u64 bits
 __global__ __launch_bounds__(256) void dtw_colmin_kernel(
-    const float *__restrict__ cmat, const float *__restrict__ xminmat, uint32_t nSrc, uint32_t nTgt,
+    const float *__restrict__ cmat, uint32_t nSrc, uint32_t nTgt,
     uint32_t mPad, const double *__restrict__ dist, const int *__restrict__ srcLen,
     const float *__restrict__ srcMaxSq, const int *__restrict__ tgtLen, const float *__restrict__ tgtMaxSq,
     MarginParams mp, unsigned long long *__restrict__ ub)
@@ -114,8 +118,7 @@ __global__ __launch_bounds__(256) void dtw_colmin_kernel(
     for (uint32_t s = s0; s < s1; ++s) {
         const size_t o = (size_t)s * mPad + t;
         double klo, khi;
-        dtw_key_interval(mp, (double)cmat[o], (double)xminmat[o], (double)srcMaxSq[s], nb, srcLen[s], fb, delta,
-                         klo, khi);
+        dtw_key_interval(mp, (double)cmat[o], 0.0, (double)srcMaxSq[s], nb, srcLen[s], fb, delta, klo, khi);
         if (khi < best)
             best = khi;
     }
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(256) void dtw_colmin_kernel(
 
 // cand layout: [0] = count, [1] = overflow flag, pairs start at cand + 2 (as uint2)
 __global__ __launch_bounds__(256) void dtw_select_kernel(
-    const float *__restrict__ cmat, const float *__restrict__ xminmat, uint32_t nSrc, uint32_t nTgt,
+    const float *__restrict__ cmat, uint32_t nSrc, uint32_t nTgt,
     uint32_t mPad, const double *__restrict__ dist, const int *__restrict__ srcLen,
     const float *__restrict__ srcMaxSq, const int *__restrict__ tgtLen, const float *__restrict__ tgtMaxSq,
     MarginParams mp, const unsigned long long *__restrict__ ub, uint32_t cap,
@@ -145,8 +148,7 @@ __global__ __launch_bounds__(256) void dtw_select_kernel(
     for (uint32_t s = s0; s < s1; ++s) {
         const size_t o = (size_t)s * mPad + t;
         double klo, khi;
-        dtw_key_interval(mp, (double)cmat[o], (double)xminmat[o], (double)srcMaxSq[s], nb, srcLen[s], fb, delta,
-                         klo, khi);
+        dtw_key_interval(mp, (double)cmat[o], 0.0, (double)srcMaxSq[s], nb, srcLen[s], fb, delta, klo, khi);
         if (klo <= thr) {
             const uint32_t slot = atomicAdd(&candHdr[0], 1u);
             if (slot < cap)
@@ -154,6 +156,44 @@ __global__ __launch_bounds__(256) void dtw_select_kernel(
             else
                 candHdr[1] = 1u;
         }
+    }
+}
+
+// ---- stage 2: inside list 1, with the per-pair certificate --------------------------------------
+__global__ void dtw_stage2_ub_kernel(const uint32_t *__restrict__ hdr1, const uint2 *__restrict__ pairs1,
+                                     const float *__restrict__ xmin, uint32_t cap, const float *__restrict__ cmat,
+                                     uint32_t mPad, const double *__restrict__ dist, const int *__restrict__ srcLen,
+                                     const float *__restrict__ srcMaxSq, const int *__restrict__ tgtLen,
+                                     const float *__restrict__ tgtMaxSq, MarginParams mp,
+                                     unsigned long long *__restrict__ ub)
+{
+    const uint32_t n = min(hdr1[0], cap);
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const uint2 p = pairs1[k];
+        double klo, khi;
+        dtw_key_interval(mp, (double)cmat[(size_t)p.x * mPad + p.y], (double)xmin[k], (double)srcMaxSq[p.x],
+                         (double)tgtMaxSq[p.y], srcLen[p.x], tgtLen[p.y], dist ? dist[p.y] : 0.0, klo, khi);
+        if (khi < __builtin_inf())
+            atomicMin(&ub[p.y], (unsigned long long)__double_as_longlong(khi));
+    }
+}
+
+__global__ void dtw_stage2_keep_kernel(const uint32_t *__restrict__ hdr1, const uint2 *__restrict__ pairs1,
+                                       const float *__restrict__ xmin, uint32_t cap, const float *__restrict__ cmat,
+                                       uint32_t mPad, const double *__restrict__ dist, const int *__restrict__ srcLen,
+                                       const float *__restrict__ srcMaxSq, const int *__restrict__ tgtLen,
+                                       const float *__restrict__ tgtMaxSq, MarginParams mp,
+                                       const unsigned long long *__restrict__ ub, uint32_t *__restrict__ hdr2,
+                                       uint2 *__restrict__ pairs2)
+{
+    const uint32_t n = min(hdr1[0], cap);
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const uint2 p = pairs1[k];
+        double klo, khi;
+        dtw_key_interval(mp, (double)cmat[(size_t)p.x * mPad + p.y], (double)xmin[k], (double)srcMaxSq[p.x],
+                         (double)tgtMaxSq[p.y], srcLen[p.x], tgtLen[p.y], dist ? dist[p.y] : 0.0, klo, khi);
+        if (klo <= __longlong_as_double((long long)ub[p.y]))
+            pairs2[atomicAdd(&hdr2[0], 1u)] = p;     // list 2 has list 1's capacity: cannot overflow
     }
 }
 
@@ -304,14 +344,44 @@ __global__ void merge_shards_kernel(uint32_t nShards, uint32_t nTgt, const doubl
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-int32_t launch_dtw_select(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt,
-                          const float *cmat, const float *xminmat, const double *dist_dev, uint32_t cap)
+static MarginParams margin_params(const ssym_ctx *ctx, const SegmentSet &src)
 {
-    hipStream_t st = ctx->stream;
     MarginParams mp;
     mp.inv_scale2 = src.rec_scale > 0.0 ? 1.0 / (src.rec_scale * src.rec_scale) : 1.0;
     mp.in_round = filter_pieces((int)src.dim) == 2 ? 2.384185791015625e-07 : 4.8828125e-04;
     mp.squared = ctx->squared;
+    return mp;
+}
+
+int32_t launch_dtw_select2(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, const float *cmat,
+                           const float *xmin, const double *dist_dev, uint32_t cap)
+{
+    hipStream_t st = ctx->stream;
+    const MarginParams mp = margin_params(ctx, src);
+    int32_t rc = ensure(ctx, ctx->cand2, sizeof(uint32_t) * 2 + sizeof(uint2) * (size_t)cap);
+    if (rc != SSYM_OK)
+        return rc;
+    unsigned long long *ub = (unsigned long long *)ctx->tmin.ptr;
+    const uint32_t *hdr1 = (const uint32_t *)ctx->cand.ptr;
+    const uint2 *pairs1 = (const uint2 *)(hdr1 + 2);
+    uint32_t *hdr2 = (uint32_t *)ctx->cand2.ptr;
+    uint2 *pairs2 = (uint2 *)(hdr2 + 2);
+    fill_u64_kernel<<<(tgt.n + 255) / 256, 256, 0, st>>>(ub, 0x7ff0000000000000ull, tgt.n);
+    SSYM_HIP_CHECK(ctx, hipMemsetAsync(hdr2, 0, sizeof(uint32_t) * 2, st));
+    const unsigned blocks = std::max(1u, std::min((cap + 255) / 256, 2048u));
+    dtw_stage2_ub_kernel<<<blocks, 256, 0, st>>>(hdr1, pairs1, xmin, cap, cmat, tgt.n_pad, dist_dev, src.len,
+                                                 src.max_sqnorm, tgt.len, tgt.max_sqnorm, mp, ub);
+    dtw_stage2_keep_kernel<<<blocks, 256, 0, st>>>(hdr1, pairs1, xmin, cap, cmat, tgt.n_pad, dist_dev, src.len,
+                                                   src.max_sqnorm, tgt.len, tgt.max_sqnorm, mp, ub, hdr2, pairs2);
+    SSYM_HIP_CHECK(ctx, hipGetLastError());
+    return SSYM_OK;
+}
+
+int32_t launch_dtw_select(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt,
+                          const float *cmat, const double *dist_dev, uint32_t cap)
+{
+    hipStream_t st = ctx->stream;
+    const MarginParams mp = margin_params(ctx, src);
     int32_t rc = ensure(ctx, ctx->tmin, sizeof(unsigned long long) * tgt.n);
     if (rc != SSYM_OK)
         return rc;
@@ -325,9 +395,9 @@ int32_t launch_dtw_select(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
     fill_u64_kernel<<<(tgt.n + 255) / 256, 256, 0, st>>>(ub, infBits, tgt.n);
     SSYM_HIP_CHECK(ctx, hipMemsetAsync(hdr, 0, sizeof(uint32_t) * 2, st));
     dim3 grid((tgt.n + 255) / 256, (src.n + kSelChunk - 1) / kSelChunk);
-    dtw_colmin_kernel<<<grid, 256, 0, st>>>(cmat, xminmat, src.n, tgt.n, tgt.n_pad, dist_dev, src.len,
+    dtw_colmin_kernel<<<grid, 256, 0, st>>>(cmat, src.n, tgt.n, tgt.n_pad, dist_dev, src.len,
                                             src.max_sqnorm, tgt.len, tgt.max_sqnorm, mp, ub);
-    dtw_select_kernel<<<grid, 256, 0, st>>>(cmat, xminmat, src.n, tgt.n, tgt.n_pad, dist_dev, src.len,
+    dtw_select_kernel<<<grid, 256, 0, st>>>(cmat, src.n, tgt.n, tgt.n_pad, dist_dev, src.len,
                                             src.max_sqnorm, tgt.len, tgt.max_sqnorm, mp, ub, cap, hdr, pairs);
     SSYM_HIP_CHECK(ctx, hipGetLastError());
     return SSYM_OK;
@@ -344,7 +414,7 @@ int32_t launch_dtw_final(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet 
         return rc;
     unsigned long long *bestKey = (unsigned long long *)ctx->best.ptr;
     uint32_t *bestIdx = (uint32_t *)(bestKey + tgt.n);
-    const uint32_t *hdr = (const uint32_t *)ctx->cand.ptr;
+    const uint32_t *hdr = (const uint32_t *)ctx->cand2.ptr;     // list 2: the exactly re-scored pairs
     const uint2 *pairs = (const uint2 *)(hdr + 2);
     const double *costs = (const double *)ctx->cand_cost.ptr;
     fill_u64_kernel<<<(tgt.n + 255) / 256, 256, 0, st>>>(bestKey, 0x7ff0000000000000ull, tgt.n);

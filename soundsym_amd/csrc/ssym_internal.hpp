@@ -80,7 +80,9 @@ struct ssym_ctx {
     ssym::DeviceBuf handoff;    // dtw filter: per-wave row hand-off between row-block passes
     ssym::DeviceBuf cmat;       // dtw filter costs f32 [n_pad][m_pad]  /  refcos sims f64
     ssym::DeviceBuf tmin;       // per-target min key bits
-    ssym::DeviceBuf cand;       // candidate pairs (uint2) + counter + overflow flag
+    ssym::DeviceBuf cand;       // candidate pairs (uint2) + counter + overflow flag (list 1)
+    ssym::DeviceBuf cand2;      // list 2: pairs that survive the per-pair certificates
+    ssym::DeviceBuf cand_xmin;  // certificate (smallest cell) per list-1 pair
     ssym::DeviceBuf cand_cost;  // exact f64 cost per candidate
     ssym::DeviceBuf best;       // per-target best bits / idx
     ssym::DeviceBuf dist;       // per-target distance (f64)
@@ -120,7 +122,11 @@ void free_segments(SegmentSet &set);
 // dtw_filter.hip
 bool filter_supported(const ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt);
 int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt,
-                          float *cmat /*[src.n_pad][tgt.n_pad]*/, float *xminmat /*same shape*/);
+                          float *cmat /*[src.n_pad][tgt.n_pad]*/);
+
+// certify.hip: smallest cell of every listed pair (per-pair error certificate)
+int32_t launch_certify(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, const uint32_t *candHdr,
+                       const uint2 *pairs, uint32_t cap, float *xmin);
 
 // dtw_exact.hip
 // pairs == nullptr: every (s,t) pair, out[s*n_tgt + t]; else out[k] for pairs[k] with k < *count
@@ -134,8 +140,12 @@ struct SelectParams {
     uint32_t cap;           // candidate capacity
     float cell_err_scale;   // see select.hip
 };
+// stage 1: worst-case margin over the whole filter matrix -> ctx->cand (list 1)
 int32_t launch_dtw_select(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt,
-                          const float *cmat, const float *xminmat, const double *dist_dev, uint32_t cap);
+                          const float *cmat, const double *dist_dev, uint32_t cap);
+// stage 2: per-pair intervals from the certificates of list 1 -> ctx->cand2 (list 2, same capacity)
+int32_t launch_dtw_select2(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, const float *cmat,
+                           const float *xmin, const double *dist_dev, uint32_t cap);
 int32_t launch_dtw_final(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt,
                          const double *dist_dev, uint32_t cap, uint32_t index_base,
                          uint32_t *out_idx_dev, double *out_cost_dev);

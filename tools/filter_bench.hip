@@ -41,7 +41,7 @@ int run(int N, int M, int F, int reps, int blocksPerCU)
     const int nTasks = nSrcBlocks * (M / 32);
     auto launch = [&]() {
         dtw_filter_kernel<NT, SSYM_TOOL_SQ><<<grid, 64 * kFilterWavesPerBlock>>>(ds, dt, dls, dlt, rows, nPasses, F, M, nSrcBlocks,
-                                                                         nTasks, 1.0f, 1.0f, dh, dc, dc2);
+                                                                         nTasks, 1.0f, dh, dc);
     };
     for (int w = 0; w < 2; ++w) launch();
     CK(hipDeviceSynchronize());
