@@ -362,9 +362,11 @@ int32_t ssym_match_queries(ssym_ctx *ctx, const ssym_dict *dict, const ssym_quer
                 return rc;
             SSYM_HIP_CHECK(ctx, hipEventRecord(ev[1], st));
             tm.main_launches = 1;
-            // list 1 (worst-case margin) is usually tens of pairs per target at most; on overflow
-            // the selection is redone with room for every pair (exactness never depends on it)
-            uint64_t cap = std::max<uint64_t>(64ull * M, 65536);
+            // list 1 (worst-case margin) is a few pairs per target when near-duplicates exist and
+            // ~10^2 when they do not; on overflow stage 1 reports the size it wanted, the later
+            // stages see the flag and do nothing, and the selection is redone with that room
+            // (exactness never depends on the capacity)
+            uint64_t cap = std::max<uint64_t>(256ull * M, 65536);
             cap = std::min<uint64_t>(cap, (uint64_t)N * M);
             float sel_ms = 0.f, ref_ms = 0.f, red_ms = 0.f;
             for (int attempt = 0; attempt < 2; ++attempt) {
@@ -412,8 +414,8 @@ int32_t ssym_match_queries(ssym_ctx *ctx, const ssym_dict *dict, const ssym_quer
                     ctx->err = "dtw: candidate list overflow";
                     return SSYM_E_NOMEM;
                 }
-                cap = (uint64_t)N * M;
-                if (cap > 0xffffffffull) {
+                cap = h1[0];
+                if (cap >= 0xffffffffull) {
                     ctx->err = "dtw: too many near-tied candidates for one batch";
                     return SSYM_E_UNSUPPORTED;
                 }

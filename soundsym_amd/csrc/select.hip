@@ -126,36 +126,104 @@ __global__ __launch_bounds__(256) void dtw_colmin_kernel(
         atomicMin(&ub[t], (unsigned long long)__double_as_longlong(best));
 }
 
-// cand layout: [0] = count, [1] = overflow flag, pairs start at cand + 2 (as uint2)
-__global__ __launch_bounds__(256) void dtw_select_kernel(
+// Stage-1 list, grouped by target (certify.hip keeps a target's records in registers across its
+// run of sources), built without a contended counter in three passes:
+//   mark:    one thread per (target, 64-source chunk) -> u64 hit mask, per-target count += popcount
+//   scan:    segment start per target = exclusive sum of the counts; hdr[0] = total, hdr[1] = total > cap
+//   scatter: every thread with hits claims popcount slots inside its target's segment
+// cand layout: [0] = count (the number wanted, even past cap), [1] = overflow flag, pairs from cand + 2
+__global__ __launch_bounds__(256) void dtw_mark_kernel(
     const float *__restrict__ cmat, uint32_t nSrc, uint32_t nTgt,
     uint32_t mPad, const double *__restrict__ dist, const int *__restrict__ srcLen,
     const float *__restrict__ srcMaxSq, const int *__restrict__ tgtLen, const float *__restrict__ tgtMaxSq,
-    MarginParams mp, const unsigned long long *__restrict__ ub, uint32_t cap,
-    uint32_t *__restrict__ candHdr, uint2 *__restrict__ candPairs)
+    MarginParams mp, const unsigned long long *__restrict__ ub, unsigned long long *__restrict__ mask,
+    uint32_t *__restrict__ cnt)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nTgt)
         return;
+    unsigned long long hits = 0;
     const double thr = __longlong_as_double((long long)ub[t]);
-    if (!(thr < __builtin_inf()))
-        return;   // no finite cost for this target: the fold keeps (0, +inf)
-    const double delta = dist ? dist[t] : 0.0;
-    const double nb = (double)tgtMaxSq[t];
-    const int fb = tgtLen[t];
-    const uint32_t s0 = blockIdx.y * kSelChunk;
-    const uint32_t s1 = min(s0 + kSelChunk, nSrc);
-    for (uint32_t s = s0; s < s1; ++s) {
-        const size_t o = (size_t)s * mPad + t;
-        double klo, khi;
-        dtw_key_interval(mp, (double)cmat[o], 0.0, (double)srcMaxSq[s], nb, srcLen[s], fb, delta, klo, khi);
-        if (klo <= thr) {
-            const uint32_t slot = atomicAdd(&candHdr[0], 1u);
-            if (slot < cap)
-                candPairs[slot] = make_uint2(s, t);
-            else
-                candHdr[1] = 1u;
+    if (thr < __builtin_inf()) {     // else no finite cost for this target: the fold keeps (0, +inf)
+        const double delta = dist ? dist[t] : 0.0;
+        const double nb = (double)tgtMaxSq[t];
+        const int fb = tgtLen[t];
+        const uint32_t s0 = blockIdx.y * kSelChunk;
+        const uint32_t s1 = min(s0 + kSelChunk, nSrc);
+        for (uint32_t s = s0; s < s1; ++s) {
+            const size_t o = (size_t)s * mPad + t;
+            double klo, khi;
+            dtw_key_interval(mp, (double)cmat[o], 0.0, (double)srcMaxSq[s], nb, srcLen[s], fb, delta, klo, khi);
+            if (klo <= thr)
+                hits |= 1ull << (s - s0);
         }
+    }
+    mask[(size_t)blockIdx.y * nTgt + t] = hits;
+    if (hits)
+        atomicAdd(&cnt[t], (uint32_t)__popcll(hits));
+}
+
+// one block: cnt[t] -> exclusive prefix (in place), total into hdr[0], overflow flag into hdr[1]
+__global__ __launch_bounds__(1024) void dtw_scan_kernel(uint32_t *__restrict__ cnt, uint32_t nTgt, uint32_t cap,
+                                                        uint32_t *__restrict__ hdr)
+{
+    __shared__ uint32_t waveSum[16];
+    __shared__ unsigned long long carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0)
+        carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nTgt; base += 1024) {
+        const uint32_t t = base + threadIdx.x;
+        const uint32_t v = t < nTgt ? cnt[t] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o);
+            if (lane >= o)
+                incl += up;
+        }
+        if (lane == 63)
+            waveSum[wave] = incl;
+        __syncthreads();
+        uint32_t before = 0, all = 0;
+        for (int w = 0; w < 16; ++w) {
+            if (w < wave)
+                before += waveSum[w];
+            all += waveSum[w];
+        }
+        const unsigned long long c = carry;
+        if (t < nTgt)      // starts past 2^32 - 1 only arise together with the overflow flag
+            cnt[t] = (uint32_t)min(c + before + incl - v, 0xffffffffull);
+        __syncthreads();
+        if (threadIdx.x == 0)
+            carry = c + all;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        hdr[0] = (uint32_t)min(carry, 0xffffffffull);
+        hdr[1] = carry > cap ? 1u : 0u;
+    }
+}
+
+__global__ __launch_bounds__(256) void dtw_scatter_kernel(const unsigned long long *__restrict__ mask,
+                                                          uint32_t nTgt, const uint32_t *__restrict__ start,
+                                                          uint32_t *__restrict__ fill,
+                                                          const uint32_t *__restrict__ hdr,
+                                                          uint2 *__restrict__ candPairs)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nTgt || hdr[1])
+        return;
+    unsigned long long hits = mask[(size_t)blockIdx.y * nTgt + t];
+    if (!hits)
+        return;
+    uint32_t slot = start[t] + atomicAdd(&fill[t], (uint32_t)__popcll(hits));
+    const uint32_t s0 = blockIdx.y * kSelChunk;
+    while (hits) {
+        const int b = __ffsll((long long)hits) - 1;
+        hits &= hits - 1;
+        candPairs[slot++] = make_uint2(s0 + b, t);
     }
 }
 
@@ -167,7 +235,7 @@ __global__ void dtw_stage2_ub_kernel(const uint32_t *__restrict__ hdr1, const ui
                                      const float *__restrict__ tgtMaxSq, MarginParams mp,
                                      unsigned long long *__restrict__ ub)
 {
-    const uint32_t n = min(hdr1[0], cap);
+    const uint32_t n = hdr1[1] ? 0u : min(hdr1[0], cap);     // overflowed list 1: the host redoes stage 1
     for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
         const uint2 p = pairs1[k];
         double klo, khi;
@@ -186,7 +254,7 @@ __global__ void dtw_stage2_keep_kernel(const uint32_t *__restrict__ hdr1, const 
                                        const unsigned long long *__restrict__ ub, uint32_t *__restrict__ hdr2,
                                        uint2 *__restrict__ pairs2)
 {
-    const uint32_t n = min(hdr1[0], cap);
+    const uint32_t n = hdr1[1] ? 0u : min(hdr1[0], cap);     // overflowed list 1: the host redoes stage 1
     for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
         const uint2 p = pairs1[k];
         double klo, khi;
@@ -392,13 +460,24 @@ int32_t launch_dtw_select(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
     uint32_t *hdr = (uint32_t *)ctx->cand.ptr;
     uint2 *pairs = (uint2 *)(hdr + 2);
     const unsigned long long infBits = 0x7ff0000000000000ull;
+    const uint32_t nChunks = (src.n + kSelChunk - 1) / kSelChunk;
+    rc = ensure(ctx, ctx->selmask, sizeof(unsigned long long) * (size_t)nChunks * tgt.n);
+    if (rc != SSYM_OK)
+        return rc;
+    rc = ensure(ctx, ctx->selcnt, sizeof(uint32_t) * 2 * (size_t)tgt.n);
+    if (rc != SSYM_OK)
+        return rc;
+    unsigned long long *mask = (unsigned long long *)ctx->selmask.ptr;
+    uint32_t *cnt = (uint32_t *)ctx->selcnt.ptr, *fill = cnt + tgt.n;
     fill_u64_kernel<<<(tgt.n + 255) / 256, 256, 0, st>>>(ub, infBits, tgt.n);
-    SSYM_HIP_CHECK(ctx, hipMemsetAsync(hdr, 0, sizeof(uint32_t) * 2, st));
-    dim3 grid((tgt.n + 255) / 256, (src.n + kSelChunk - 1) / kSelChunk);
+    SSYM_HIP_CHECK(ctx, hipMemsetAsync(cnt, 0, sizeof(uint32_t) * 2 * (size_t)tgt.n, st));
+    dim3 grid((tgt.n + 255) / 256, nChunks);
     dtw_colmin_kernel<<<grid, 256, 0, st>>>(cmat, src.n, tgt.n, tgt.n_pad, dist_dev, src.len,
                                             src.max_sqnorm, tgt.len, tgt.max_sqnorm, mp, ub);
-    dtw_select_kernel<<<grid, 256, 0, st>>>(cmat, src.n, tgt.n, tgt.n_pad, dist_dev, src.len,
-                                            src.max_sqnorm, tgt.len, tgt.max_sqnorm, mp, ub, cap, hdr, pairs);
+    dtw_mark_kernel<<<grid, 256, 0, st>>>(cmat, src.n, tgt.n, tgt.n_pad, dist_dev, src.len,
+                                          src.max_sqnorm, tgt.len, tgt.max_sqnorm, mp, ub, mask, cnt);
+    dtw_scan_kernel<<<1, 1024, 0, st>>>(cnt, tgt.n, cap, hdr);
+    dtw_scatter_kernel<<<grid, 256, 0, st>>>(mask, tgt.n, cnt, fill, hdr, pairs);
     SSYM_HIP_CHECK(ctx, hipGetLastError());
     return SSYM_OK;
 }

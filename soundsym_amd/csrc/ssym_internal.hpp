@@ -81,6 +81,8 @@ struct ssym_ctx {
     ssym::DeviceBuf cmat;       // dtw filter costs f32 [n_pad][m_pad]  /  refcos sims f64
     ssym::DeviceBuf tmin;       // per-target min key bits
     ssym::DeviceBuf cand;       // candidate pairs (uint2) + counter + overflow flag (list 1)
+    ssym::DeviceBuf selmask;    // stage-1 hit masks, one u64 per (64-source chunk, target)
+    ssym::DeviceBuf selcnt;     // stage-1 per-target counts / segment starts / fill cursors
     ssym::DeviceBuf cand2;      // list 2: pairs that survive the per-pair certificates
     ssym::DeviceBuf cand_xmin;  // certificate (smallest cell) per list-1 pair
     ssym::DeviceBuf cand_cost;  // exact f64 cost per candidate
