@@ -468,17 +468,19 @@ def test_dtw_dictionary_append_and_device_create(oracle):
     e.close()
 
 
-def test_dtw_candidate_overflow_falls_back_to_full_capacity(dtw, oracle):
-    # every source identical: every pair is an exact tie, so the candidate list overflows its first
-    # capacity (4 per target) and the selection is redone with room for every pair; first index wins
-    one = synth.make_grid(1, 1, 24, 13, 0x5EED0395).sources[0]
-    src = np.repeat(one[None], 80, axis=0)
-    tgt = synth.make_grid(70, 1, 24, 13, 0x5EED0396).sources
-    so = np.arange(81, dtype=np.uint64) * 24
-    to = np.arange(71, dtype=np.uint64) * 24
+def test_dtw_candidate_overflow_is_redone_with_the_reported_size(dtw, oracle):
+    # every source identical: every pair is an exact tie, so list 1 wants all 600 x 200 pairs, more
+    # than its first capacity (max(256 per target, 65536)); stage 1 reports the size, the later stages
+    # skip, and the selection is redone with that room; the first index wins every tie
+    n, m, f = 600, 200, 8
+    one = synth.make_grid(1, 1, f, 13, 0x5EED0395).sources[0]
+    src = np.repeat(one[None], n, axis=0)
+    tgt = synth.make_grid(m, 1, f, 13, 0x5EED0396).sources
+    so = np.arange(n + 1, dtype=np.uint64) * f
+    to = np.arange(m + 1, dtype=np.uint64) * f
     idx, cost = dtw.match(dtw.dictionary(src.reshape(-1), so, 13), dtw.queries(tgt.reshape(-1), to, 13))
     tm = dtw.timings()
-    assert tm["n_refined"] == 80 * 70 and (idx == 0).all()
+    assert tm["n_refined"] == n * m and (idx == 0).all()
     want_idx, want_cost = oracle.dtw_match_all(src.reshape(-1).astype(np.float64), so,
                                                tgt.reshape(-1).astype(np.float64), to, 13)
     assert np.array_equal(idx, want_idx) and np.allclose(cost, want_cost, rtol=EXACT_RTOL, atol=0)
