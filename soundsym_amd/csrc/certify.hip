@@ -40,13 +40,13 @@ __global__ __launch_bounds__(64) void certify_kernel(const _Float16 *__restrict_
             // frame f of the source sits in slot first + f (end-aligned when srcLead < 0)
             const int first = srcLead < 0 ? srcSlots - fa : srcLead;
             const _Float16 *sBase = srcRec + ((size_t)p.x * srcSlots + first) * REC + kh * 24;
-            const _Float16 *tBase = tgtRec + ((size_t)p.y * tgtSlots) * REC + kh * 24;
+            const _Float16 *tBase = tgtRec + tgt_rec_offset(p.y, tgtSlots, 0, 0, kh);
             for (int i0 = 0; i0 < fa; i0 += 32) {
                 half8 A[kFilterKM];
                 load_rec(sBase + (size_t)min(i0 + rc, fa - 1) * REC, A);      // rows past the end repeat the last frame
                 for (int j0 = 0; j0 < fb; j0 += 32) {
                     half8 B[kFilterKM];
-                    load_rec(tBase + (size_t)min(j0 + rc, fb - 1) * REC, B);
+                    load_tgt_rec(tBase, min(j0 + rc, fb - 1), B);
                     const f32x16 acc = mfma_tile<kFilterKM>(A, B);
 #pragma unroll
                     for (int r = 0; r < 16; r += 2)
@@ -88,10 +88,10 @@ __global__ __launch_bounds__(64) void certify_run_kernel(const _Float16 *__restr
             if (p.y != cachedT) {
                 cachedT = p.y;
                 fb = tgtLen[p.y];
-                const _Float16 *tBase = tgtRec + ((size_t)p.y * tgtSlots) * REC + kh * 24;
+                const _Float16 *tBase = tgtRec + tgt_rec_offset(p.y, tgtSlots, 0, 0, kh);
 #pragma unroll
                 for (int q = 0; q < NB; ++q)      // columns past the end repeat the last frame
-                    load_rec(tBase + (size_t)max(min(q * 32 + rc, fb - 1), 0) * REC, B[q]);
+                    load_tgt_rec(tBase, max(min(q * 32 + rc, fb - 1), 0), B[q]);
             }
             const int fa = srcLen[p.x];
             float m = INF;

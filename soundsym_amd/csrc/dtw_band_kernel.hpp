@@ -79,13 +79,13 @@ __global__ __launch_bounds__(64 * WB, OCC) void dtw_band_kernel(
         float res = INF;
         const int kstar = fa - 1 - fb_m1 + radius;     // diagonal of the end cell (fa-1, fb-1)
 
-        const _Float16 *bbase = tgtRec + ((size_t)(32 * tg + col) * tgtFramesPad) * REC + half * 24;
+        const _Float16 *bbase = tgtRec + tgt_rec_offset(32 * tg + col, tgtFramesPad, 0, 0, half);
         half8 B0[kFilterKM], B1[kFilterKM];
 #pragma unroll
         for (int m = 0; m < kFilterKM; ++m)
             B0[m] = half8{0, 0, 0, 0, 0, 0, 0, 0};
         if (nCols > 0)
-            load_rec(bbase, B0);
+            load_tgt_rec(bbase, 0, B0);
         // software pipeline as in dtw_filter_kernel.hpp: the MFMA chain of the NEXT tile (next
         // column's first tile after the last one) is in flight while this tile's cells run
         f32x16 acc;
@@ -102,9 +102,9 @@ __global__ __launch_bounds__(64 * WB, OCC) void dtw_band_kernel(
                 if (j < nCols) {                       // wave-uniform
                     const int jn = min(j + 1, nCols - 1);
                     if (par == 0)
-                        load_rec(bbase + (size_t)jn * REC, B1);
+                        load_tgt_rec(bbase, jn, B1);
                     else
-                        load_rec(bbase + (size_t)jn * REC, B0);
+                        load_tgt_rec(bbase, jn, B0);
                     // tile T of column j needs source frames j - r + 16T + local = slots j + 16T + local
                     const _Float16 *aCol = aLane + (size_t)j * REC;
                     float up = INF;

@@ -73,10 +73,23 @@ __global__ void build_filter_records_kernel(const double *__restrict__ raw, cons
         out[filter_slot_offset(other + 1)] = (_Float16)1.0f;
         out[filter_slot_offset(other + 2)] = (_Float16)1.0f;
     }
-    _Float16 *dst = rec + ((size_t)s * frames_pad + slot) * kFilterRecHalfs;
+    if (is_source) {
+        _Float16 *dst = rec + ((size_t)s * frames_pad + slot) * kFilterRecHalfs;
 #pragma unroll
-    for (int i = 0; i < kFilterRecHalfs; ++i)
-        dst[i] = out[i];
+        for (int i = 0; i < kFilterRecHalfs; ++i)
+            dst[i] = out[i];
+    } else {
+        // group-major target layout (dtw_filter_kernel.hpp, tgt_rec_offset); n_pad is a multiple of 32
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int m = 0; m < kFilterKM; ++m) {
+                _Float16 *dst = rec + tgt_rec_offset(s, frames_pad, slot, m, h);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    dst[i] = out[h * 24 + m * 8 + i];
+            }
+    }
 }
 
 // banded layout: slot s of a source holds frame s - r; tile T of column j reads slots j + 16T .. +15

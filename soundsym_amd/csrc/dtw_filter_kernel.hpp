@@ -31,9 +31,16 @@
 //     persistent); pass p+1 reads it back as its top boundary.  Waves never synchronise with each
 //     other -- a first version that pipelined row blocks across waves with one workgroup barrier
 //     per column spent half of its wave-cycles waiting (profiles/);
+//   * target records (group-major, 1 KB per MFMA operand plane per column) and the hand-off row
+//     reach the wave through a per-wave LDS ring filled by global_load_lds DMA three columns
+//     ahead of use: loads in flight hold no registers (the kernel sits at the 256-VGPR limit of two
+//     waves per SIMD) and s_waitcnt vmcnt(6) at the top of a column never waits for a young load;
 //   * measured on MI355X (rocprofv3 PMC): plain VALU instructions occupy the SIMD for 4 cycles,
 //     v_sqrt_f32 for 8, whatever the occupancy -- 16 cycles per cell is the floor of this
-//     recurrence, and the kernel is VALU-bound, not MFMA- or HBM-bound.
+//     recurrence, and the kernel is VALU-bound, not MFMA- or HBM-bound.  Ablations (tools/
+//     filter_bench.hip, -DSSYM_ABL_NOSTAGE / -DSSYM_ABL_NOHAND): the kernel runs 21.1 cycles per
+//     cell at 2.07 GHz; without any per-column memory traffic 19.3 cycles at 2.22 GHz -- the chip
+//     is power-limited, so moving data costs clock as well as cycles.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -82,6 +89,24 @@ __device__ __forceinline__ void load_rec(const _Float16 *__restrict__ p, half8 (
         dst[m] = *reinterpret_cast<const half8 *>(p + 8 * m);
 }
 
+// TARGET records are stored group-major so that a wave's column load is contiguous: for target
+// group g = t / 32 and frame slot j, the 16 bytes that lane (h, c = t & 31) feeds to MFMA m sit at
+//     f16 offset ((g * slots + j) * 3 + m) * 512 + (h * 32 + c) * 8,
+// i.e. one global_load_dwordx4 of the wave covers 1 KB = 8 whole cache lines (with per-target
+// records every lane touched a line of its own and the texture path, not the VALU, set the pace).
+constexpr int kTgtFrameHalfs = kFilterKM * 512;      // f16 values per (target group, frame slot)
+__host__ __device__ constexpr size_t tgt_rec_offset(uint32_t t, uint32_t slots, uint32_t j, int m, int h)
+{
+    return (((size_t)(t >> 5) * slots + j) * kFilterKM + m) * 512 + (size_t)(h * 32 + (t & 31u)) * 8;
+}
+// p = the lane's base for its target and K half (tgt_rec_offset(t, slots, 0, 0, h)); j = frame slot
+__device__ __forceinline__ void load_tgt_rec(const _Float16 *__restrict__ p, int j, half8 (&dst)[kFilterKM])
+{
+#pragma unroll
+    for (int m = 0; m < kFilterKM; ++m)
+        dst[m] = *reinterpret_cast<const half8 *>(p + (size_t)j * kTgtFrameHalfs + m * 512);
+}
+
 // One column of one row block: NT tiles, software-pipelined (the next tile's MFMA chain is in
 // flight while this tile's 16 cells run on the VALU).  Lr = D(., j-1), Lw = D(., j).
 template <int NT, bool SQ>
@@ -119,6 +144,11 @@ __device__ __forceinline__ float dp_column(const half8 (&A)[NT][kFilterKM], cons
 }
 
 constexpr int kFilterWavesPerBlock = 4;
+constexpr int kFilterRing = 4;                                  // target columns staged in LDS per wave
+constexpr int kFilterSlotBytes = kFilterKM * 1024 + 256;        // 64 lanes x (3 x 16 B operands + 1 float)
+// s_waitcnt immediates (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14])
+constexpr int kWaitVm6 = 0x0F76;                                // vmcnt(6), nothing else
+constexpr int kWaitVm9 = 0x0F79;                                // vmcnt(9)
 
 // Persistent kernel: workgroup b works on tasks b, b + gridDim.x, ...; a task is (target group of
 // 32, block of 8 sources); each of the 4 waves owns one source pair of the block = 64 pairs.
@@ -137,8 +167,11 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, 2) void dtw_filter_kerne
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int col = lane & 31;         // output column: target 32*tg + col
     const int half = lane >> 5;        // operand role: K half; output role: source 2*sp + half
-    // this wave's hand-off row: [tgtFramesPad][64] floats
-    float *const hand = handoff + ((size_t)blockIdx.x * kFilterWavesPerBlock + wave) * (size_t)tgtFramesPad * 64 + lane;
+    // this wave's hand-off row, [tgtFramesPad][64] floats (wave-uniform base + lane offset)
+    char *const handRow = reinterpret_cast<char *>(handoff + ((size_t)blockIdx.x * kFilterWavesPerBlock + wave) * (size_t)tgtFramesPad * 64);
+    const uint32_t laneOff16 = lane * 16, laneOff4 = lane * 4;
+    __shared__ __attribute__((aligned(16))) char ring[kFilterWavesPerBlock][kFilterRing * kFilterSlotBytes];
+    char *const myRing = ring[wave];
 
     for (unsigned task = blockIdx.x; task < (unsigned)nTasks; task += gridDim.x) {
         // XCD-aware task order: workgroups b, b+8, ... share an XCD and gridDim.x is a multiple of
@@ -167,12 +200,47 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, 2) void dtw_filter_kerne
         const int firstPass = min(max(r0min - 1, 0) / BR, nPasses - 1);
 
         float res = INF;
-        const _Float16 *bbase = tgtRec + ((size_t)(32 * tg + col) * tgtFramesPad) * REC + half * 24;
+        const char *const tgtGroup = reinterpret_cast<const char *>(tgtRec) + (size_t)tg * tgtFramesPad * (kTgtFrameHalfs * 2);
 
-        for (int pass = firstPass; pass < nPasses; ++pass) {
+        for (int pass = nCols > 0 ? firstPass : nPasses; pass < nPasses; ++pass) {
             const int rowBase = pass * BR;
+#ifdef SSYM_ABL_NOHAND
+            const bool haveTop = false;
+#else
             const bool haveTop = pass > firstPass;      // wave-uniform
+#endif
             const bool lastPass = pass == nPasses - 1;
+
+            // Target records (and the hand-off row above this row block) travel global -> LDS by
+            // DMA, kFilterRing - 1 columns ahead of their use, and LDS -> registers one column
+            // ahead: no registers are held by loads in flight.  Virtual column c (clamped to the
+            // last real column) lives in ring slot c % kFilterRing.
+            auto stage = [&](int c) {
+                const int cc = min(c, nCols - 1);
+                char *slot = myRing + (c & (kFilterRing - 1)) * kFilterSlotBytes;
+                // one LDS base (M0) per column; the instruction offset moves the global and the LDS
+                // address together, which the group-major record layout is made for
+                const char *gb = tgtGroup + (size_t)cc * (kTgtFrameHalfs * 2);       // wave-uniform
+                static_assert(kFilterKM == 3, "three operand planes per column");
+                const __attribute__((address_space(1))) void *gp =
+                    (const __attribute__((address_space(1))) void *)(gb + laneOff16);
+                __attribute__((address_space(3))) void *lp = (__attribute__((address_space(3))) void *)slot;
+                __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(gp, lp, 16, 1024, 0);
+                __builtin_amdgcn_global_load_lds(gp, lp, 16, 2048, 0);
+                if (haveTop)
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void *)(handRow + (ptrdiff_t)cc * 256 - kFilterKM * 1024 + laneOff4),
+                        (__attribute__((address_space(3))) void *)slot, 4, kFilterKM * 1024, 0);
+            };
+            auto fetch = [&](int c, half8 (&B)[kFilterKM], float &top) {
+                const char *slot = myRing + (c & (kFilterRing - 1)) * kFilterSlotBytes;
+#pragma unroll
+                for (int m = 0; m < kFilterKM; ++m)
+                    B[m] = *reinterpret_cast<const half8 *>(slot + m * 1024 + lane * 16);
+                // read unconditionally (no branch, no wait at a block end); unused when !haveTop
+                top = *reinterpret_cast<const float *>(slot + kFilterKM * 1024 + lane * 4);
+            };
 
             // A operands of this pass: the pad rows above a source carry |a|^2 = +inf
             half8 A[NT][kFilterKM];
@@ -186,6 +254,11 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, 2) void dtw_filter_kerne
                     load_rec(abase + (size_t)T * kFilterRowsPerTile * REC, A[T]);
             }
 
+            asm volatile("" ::: "memory");      // A loads are issued (program order) before the staging DMAs
+#pragma unroll
+            for (int c = 0; c < kFilterRing; ++c)
+                stage(c);
+
             // D(., -1): +inf, except the virtual D(r0-1, -1) = 0 that starts the recurrence
             float L0[BR], L1[BR];
 #pragma unroll
@@ -198,15 +271,12 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, 2) void dtw_filter_kerne
 
             // B operands of the current and the next column swap roles every column (no copies)
             half8 B0[kFilterKM], B1[kFilterKM];
-#pragma unroll
-            for (int m = 0; m < kFilterKM; ++m)
-                B0[m] = half8{0, 0, 0, 0, 0, 0, 0, 0};
-            float topN = INF;                                       // D(rowBase-1, j) prefetched
-            if (nCols > 0) {
-                load_rec(bbase, B0);
-                if (haveTop)
-                    topN = hand[0];
-            }
+            float topN = INF;                                       // D(rowBase-1, j) for the coming column
+            // everything issued so far except the last kFilterRing - 1 column groups has landed
+            // (a group is 3 or 4 DMAs; the A loads are older): column 0 is in its slot
+            __builtin_amdgcn_s_waitcnt(kWaitVm9);
+            asm volatile("" ::: "memory");
+            fetch(0, B0, topN);
             f32x16 acc = mfma_tile<kFilterKM>(A[0], B0);
 
             for (int j0 = 0; j0 < nCols; j0 += 2) {
@@ -214,23 +284,32 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, 2) void dtw_filter_kerne
                 for (int par = 0; par < 2; ++par) {
                     const int j = j0 + par;
                     if (j < nCols) {                                // wave-uniform
-                        const int jn = min(j + 1, nCols - 1);
-                        if (par == 0)
-                            load_rec(bbase + (size_t)jn * REC, B1);
-                        else
-                            load_rec(bbase + (size_t)jn * REC, B0);
                         const float up = haveTop ? topN : INF;
                         const float diag = (j == 0) ? diagCol0 : prevTop;
                         prevTop = up;
-                        if (haveTop)
-                            topN = hand[(size_t)jn * 64];           // next column's top boundary
+                        // column j+1 was staged kFilterRing - 1 columns ago; at least the two
+                        // groups after it (>= 6 DMAs) are younger, so vmcnt(6) covers it
+                        __builtin_amdgcn_s_waitcnt(kWaitVm6);
+                        asm volatile("" ::: "memory");
+                        if (par == 0)
+                            fetch(j + 1, B1, topN);
+                        else
+                            fetch(j + 1, B0, topN);
+#ifndef SSYM_ABL_NOSTAGE
+                        stage(j + kFilterRing);                     // into the slot column j just left
+#endif
                         float bottom;
                         if (par == 0)
                             bottom = dp_column<NT, SQ>(A, B0, B1, acc, up, diag, L0, L1);
                         else
                             bottom = dp_column<NT, SQ>(A, B1, B0, acc, up, diag, L1, L0);
+#ifndef SSYM_ABL_NOHAND
                         if (!lastPass)
-                            hand[(size_t)j * 64] = bottom;          // top boundary of the next pass
+                            *reinterpret_cast<float *>(handRow + (size_t)j * 256 + laneOff4) = bottom;   // top boundary of the next pass
+#else
+                        if (!lastPass)
+                            res = (j == fb_m1 - 1) ? bottom : res;
+#endif
                         else
                             res = (j == fb_m1) ? bottom : res;      // D(fa-1, fb-1)
                     }
