@@ -154,6 +154,21 @@ SSYM_API int32_t ssym_match_queries(ssym_ctx *ctx, const ssym_dict *dict, const 
                            const double *distance, uint32_t index_base, uint32_t *out_idx,
                            double *out_cost, uint32_t flags);
 
+/* The k best dictionary entries per target ("top-k candidates"; the
+ * reference itself only ever takes the first: at_distance, src/sound.rs:351-370).  Same inputs as
+ * ssym_match_queries; entry r of target t is at [t * k + r].  Entries are ordered by
+ * (|value - distance|, index) ascending, value = cosine_sim in refcos, DTW cost in dtw -- so entry 0
+ * is ssym_match_queries' answer whenever anything beats the fold start (key < 2.0 in refcos,
+ * finite cost in dtw; NaN keys never enter, as in src/sound.rs:362).  When fewer than k entries
+ * qualify the rest of the row is SSYM_NO_MATCH with cost NaN.  out_cost as in ssym_match_queries
+ * (refcos: the key |sim - distance|; dtw: the cost).  1 <= k <= SSYM_TOPK_MAX.  dtw results are
+ * those of an exact f64 evaluation of every pair, as for k = 1. */
+#define SSYM_TOPK_MAX 64u
+#define SSYM_NO_MATCH 0xffffffffu
+SSYM_API int32_t ssym_match_topk(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queries *q,
+                        const double *distance, uint32_t k, uint32_t index_base, uint32_t *out_idx,
+                        double *out_cost, uint32_t flags);
+
 /* Convenience: pack host targets, match, release.  Same contract as ssym_match_queries with
  * host outputs. */
 SSYM_API int32_t ssym_match_batch(ssym_ctx *ctx, const ssym_dict *dict, const void *tgt_feats,

@@ -67,6 +67,12 @@ class Oracle:
                                                    ctypes.c_uint32, ctypes.c_uint32, _f64p,
                                                    _i64p, _f64p]
         L.ssym_oracle_length_fit.restype = None
+        L.ssym_oracle_refcos_matrix.argtypes = [_f64p, _u64p, ctypes.c_uint32, _f64p, _u64p, ctypes.c_uint32,
+                                                ctypes.c_uint32, _f64p]
+        L.ssym_oracle_refcos_matrix.restype = None
+        L.ssym_oracle_topk.argtypes = [_f64p, ctypes.c_uint32, ctypes.c_uint32, _f64p, ctypes.c_double,
+                                       ctypes.c_double, ctypes.c_uint32, _i64p, _f64p]
+        L.ssym_oracle_topk.restype = ctypes.c_int
         L.ssym_oracle_length_fit.argtypes = [_f64p, ctypes.c_uint64, ctypes.c_uint64, _f64p]
         L.ssym_oracle_reconstruct.restype = None
         L.ssym_oracle_reconstruct.argtypes = [_f64p, _u64p, _i64p, _u64p, ctypes.c_uint32, _f64p]
@@ -126,6 +132,36 @@ class Oracle:
         if rc != 0:
             raise ValueError("empty dictionary (the reference panics here, src/sound.rs:369)")
         return idx, val
+
+    def refcos_matrix(self, src_flat, src_off, tgt_flat, tgt_off, dim) -> np.ndarray:
+        """cosine_sim of every (source, target) pair, [n_src][n_tgt]."""
+        src_flat = np.ascontiguousarray(src_flat, dtype=np.float64)
+        tgt_flat = np.ascontiguousarray(tgt_flat, dtype=np.float64)
+        src_off = np.ascontiguousarray(src_off, dtype=np.uint64)
+        tgt_off = np.ascontiguousarray(tgt_off, dtype=np.uint64)
+        n, m = src_off.size - 1, tgt_off.size - 1
+        out = np.zeros((n, m), dtype=np.float64)
+        self.lib.ssym_oracle_refcos_matrix(_ptr(src_flat, _f64p), _ptr(src_off, _u64p), n, _ptr(tgt_flat, _f64p),
+                                           _ptr(tgt_off, _u64p), m, dim, _ptr(out, _f64p))
+        return out
+
+    def topk(self, values, k: int, distance=None, default_distance: float = 1.0, fold_start: float = 2.0):
+        """k best sources per target from a [n_src][n_tgt] value matrix: (idx [m][k] (-1 = none),
+        key [m][k] (NaN = none)), ordered by (|value - distance|, index); keys must be < fold_start."""
+        values = np.ascontiguousarray(values, dtype=np.float64)
+        n, m = values.shape
+        idx = np.zeros((m, k), dtype=np.int64)
+        key = np.zeros((m, k), dtype=np.float64)
+        dist = None
+        if distance is not None:
+            dist = np.ascontiguousarray(distance, dtype=np.float64)
+            assert dist.size == m
+        rc = self.lib.ssym_oracle_topk(_ptr(values, _f64p), n, m, _ptr(dist, _f64p) if dist is not None else None,
+                                       float(default_distance), float(fold_start), k, _ptr(idx, _i64p),
+                                       _ptr(key, _f64p))
+        if rc != 0:
+            raise MemoryError
+        return idx, key
 
     def length_fit(self, matched, n_target: int) -> np.ndarray:
         matched = np.ascontiguousarray(matched, dtype=np.float64)

@@ -276,6 +276,61 @@ SSYM_ORACLE_API int ssym_oracle_dtw_match_all(const double *src, const uint64_t 
     return 0;
 }
 
+/* Every cosine_sim(source s, target t) (src/sound.rs:22-33), out[s * n_tgt + t]. */
+SSYM_ORACLE_API void ssym_oracle_refcos_matrix(const double *src, const uint64_t *src_off,
+                                               uint32_t n_src, const double *tgt,
+                                               const uint64_t *tgt_off, uint32_t n_tgt,
+                                               uint32_t dim, double *out)
+{
+    for (uint32_t s = 0; s < n_src; ++s)
+        for (uint32_t t = 0; t < n_tgt; ++t)
+            out[(size_t)s * n_tgt + t] =
+                ssym_oracle_cosine_sim(src + src_off[s] * dim, (size_t)(src_off[s + 1] - src_off[s]) * dim,
+                                       tgt + tgt_off[t] * dim, (size_t)(tgt_off[t + 1] - tgt_off[t]) * dim);
+}
+
+/* Top-k candidates per target (the reference only takes the first,
+ * src/sound.rs:351-370): the entries a repeated at_distance would return if each winner were
+ * removed from the dictionary -- i.e. the sources ordered by (|value - distance|, index), keeping
+ * those whose key is below the fold start (strict '<', so NaN keys never enter, :362).
+ * Restated as a plain sort, independently of the GPU's round formulation.
+ * values[s * n_tgt + t]; out_idx / out_key are [n_tgt][k]; missing entries: index -1, key NaN. */
+typedef struct { double key; int64_t idx; } ssym_oracle_cand;
+static int ssym_oracle_cand_cmp(const void *a, const void *b)
+{
+    const ssym_oracle_cand *x = (const ssym_oracle_cand *)a, *y = (const ssym_oracle_cand *)b;
+    if (x->key < y->key) return -1;
+    if (x->key > y->key) return 1;
+    return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0);
+}
+SSYM_ORACLE_API int ssym_oracle_topk(const double *values, uint32_t n_src, uint32_t n_tgt,
+                                     const double *distance, double default_distance,
+                                     double fold_start, uint32_t k, int64_t *out_idx, double *out_key)
+{
+    ssym_oracle_cand *c = (ssym_oracle_cand *)malloc(sizeof(ssym_oracle_cand) * (n_src ? n_src : 1));
+    if (!c)
+        return -1;
+    for (uint32_t t = 0; t < n_tgt; ++t) {
+        const double d = distance ? distance[t] : default_distance;
+        uint32_t n = 0;
+        for (uint32_t s = 0; s < n_src; ++s) {
+            const double key = fabs(values[(size_t)s * n_tgt + t] - d);
+            if (key < fold_start) {
+                c[n].key = key;
+                c[n].idx = (int64_t)s;
+                ++n;
+            }
+        }
+        qsort(c, n, sizeof(ssym_oracle_cand), ssym_oracle_cand_cmp);
+        for (uint32_t r = 0; r < k; ++r) {
+            out_idx[(size_t)t * k + r] = r < n ? c[r].idx : -1;
+            out_key[(size_t)t * k + r] = r < n ? c[r].key : NAN;
+        }
+    }
+    free(c);
+    return 0;
+}
+
 SSYM_ORACLE_API int ssym_oracle_max_threads(void)
 {
 #ifdef _OPENMP

@@ -35,10 +35,15 @@ ABI_SYMBOLS = [
     "ssym_abi_version", "ssym_ctx_create", "ssym_ctx_destroy", "ssym_last_error",
     "ssym_ctx_synchronize", "ssym_get_timings", "ssym_dict_create", "ssym_dict_create_device",
     "ssym_dict_append", "ssym_dict_size", "ssym_dict_destroy", "ssym_queries_create",
-    "ssym_queries_create_device", "ssym_queries_destroy", "ssym_match_queries", "ssym_match_batch",
+    "ssym_queries_create_device", "ssym_queries_destroy", "ssym_match_queries", "ssym_match_topk",
+    "ssym_match_batch",
     "ssym_match_one", "ssym_pair_matrix", "ssym_merge_shards", "ssym_samples_create",
     "ssym_samples_destroy", "ssym_reconstruct",
 ]
+
+
+NO_MATCH = 0xFFFFFFFF      # SSYM_NO_MATCH
+TOPK_MAX = 64              # SSYM_TOPK_MAX
 
 
 class SsymError(RuntimeError):
@@ -154,6 +159,8 @@ def lib() -> ctypes.CDLL:
     L.ssym_queries_destroy.argtypes = [vp, vp]
     L.ssym_match_queries.restype = i32
     L.ssym_match_queries.argtypes = [vp, vp, vp, vp, u32, vp, vp, u32]
+    L.ssym_match_topk.restype = i32
+    L.ssym_match_topk.argtypes = [vp, vp, vp, vp, u32, u32, vp, vp, u32]
     L.ssym_match_batch.restype = i32
     L.ssym_match_batch.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp]
     L.ssym_match_one.restype = i32

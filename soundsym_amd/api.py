@@ -20,7 +20,7 @@ from typing import List, Optional, Sequence
 
 import numpy as np
 
-from ._native import EmptyDictionaryError
+from ._native import NO_MATCH, EmptyDictionaryError
 from .engine import Engine, pack_segments
 
 NCOEFFS = 12   # src/lib.rs:22
@@ -166,6 +166,18 @@ class SoundDictionary:
             raise EmptyDictionaryError(-2, "empty dictionary")
         flat, off = pack_segments([t.mfccs() for t in targets], self._dim(), self.engine.np_dtype)
         return self.engine.match_batch(self.resident(), flat, off, distances)
+
+
+    def candidates(self, targets: Sequence[Sound], k: int, distances=None) -> List[List[Sound]]:
+        """The k best dictionary sounds per target, best first: what k
+        successive at_distance calls (src/sound.rs:351) would return if each winner were removed."""
+        if not self.sounds:
+            raise EmptyDictionaryError(-2, "empty dictionary")
+        flat, off = pack_segments([t.mfccs() for t in targets], self._dim(), self.engine.np_dtype)
+        q = self.engine.queries(flat, off, self._dim())
+        idx, _ = self.engine.match_topk(self.resident(), q, k, distances)
+        q.close()
+        return [[self.sounds[int(i)] for i in row if int(i) != NO_MATCH] for row in idx]
 
 
 def length_fit(matched: np.ndarray, n_target: int) -> np.ndarray:

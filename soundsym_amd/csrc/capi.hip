@@ -281,9 +281,12 @@ static int32_t check_match_args(ssym_ctx *ctx, const ssym_dict *dict, const ssym
     return SSYM_OK;
 }
 
-int32_t ssym_match_queries(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queries *q,
-                           const double *distance, uint32_t index_base, uint32_t *out_idx,
-                           double *out_cost, uint32_t flags)
+}  // extern "C"
+
+// k_top = 1: ssym_match_queries (outputs [M]); k_top > 1: ssym_match_topk (outputs [M][k_top])
+static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queries *q,
+                          const double *distance, uint32_t index_base, uint32_t k_top, uint32_t *out_idx,
+                          double *out_cost, uint32_t flags)
 {
     int32_t rc = check_match_args(ctx, dict, q);
     if (rc != SSYM_OK)
@@ -318,10 +321,10 @@ int32_t ssym_match_queries(ssym_ctx *ctx, const ssym_dict *dict, const ssym_quer
     uint32_t *idxDev = out_idx;
     double *costDev = out_cost;
     if (!outDev) {
-        rc = ensure(ctx, ctx->out_idx, sizeof(uint32_t) * M);
+        rc = ensure(ctx, ctx->out_idx, sizeof(uint32_t) * (size_t)M * k_top);
         if (rc != SSYM_OK)
             return rc;
-        rc = ensure(ctx, ctx->out_cost, sizeof(double) * M);
+        rc = ensure(ctx, ctx->out_cost, sizeof(double) * (size_t)M * k_top);
         if (rc != SSYM_OK)
             return rc;
         idxDev = (uint32_t *)ctx->out_idx.ptr;
@@ -339,7 +342,7 @@ int32_t ssym_match_queries(ssym_ctx *ctx, const ssym_dict *dict, const ssym_quer
         if (rc != SSYM_OK)
             return rc;
         SSYM_HIP_CHECK(ctx, hipEventRecord(ev[1], st));
-        rc = launch_refcos_argmin(ctx, N, M, sims, distDev, index_base, idxDev, costDev);
+        rc = launch_refcos_argmin(ctx, N, M, sims, distDev, index_base, k_top, idxDev, costDev);
         if (rc != SSYM_OK)
             return rc;
         SSYM_HIP_CHECK(ctx, hipEventRecord(ev[2], st));
@@ -366,12 +369,12 @@ int32_t ssym_match_queries(ssym_ctx *ctx, const ssym_dict *dict, const ssym_quer
             // ~10^2 when they do not; on overflow stage 1 reports the size it wanted, the later
             // stages see the flag and do nothing, and the selection is redone with that room
             // (exactness never depends on the capacity)
-            uint64_t cap = std::max<uint64_t>(256ull * M, 65536);
+            uint64_t cap = std::max<uint64_t>((256ull + 16ull * (k_top - 1)) * M, 65536);
             cap = std::min<uint64_t>(cap, (uint64_t)N * M);
             float sel_ms = 0.f, ref_ms = 0.f, red_ms = 0.f;
             for (int attempt = 0; attempt < 2; ++attempt) {
                 SSYM_HIP_CHECK(ctx, hipEventRecord(ev[2], st));
-                rc = launch_dtw_select(ctx, src, tgt, cmat, distDev, (uint32_t)cap);          // stage 1
+                rc = launch_dtw_select(ctx, src, tgt, cmat, distDev, (uint32_t)cap, k_top);   // stage 1
                 if (rc != SSYM_OK)
                     return rc;
                 uint32_t *hdr1 = (uint32_t *)ctx->cand.ptr;
@@ -383,7 +386,7 @@ int32_t ssym_match_queries(ssym_ctx *ctx, const ssym_dict *dict, const ssym_quer
                 if (rc != SSYM_OK)
                     return rc;
                 rc = launch_dtw_select2(ctx, src, tgt, cmat, (const float *)ctx->cand_xmin.ptr, distDev,
-                                        (uint32_t)cap);                                         // stage 2
+                                        (uint32_t)cap, k_top);                                  // stage 2
                 if (rc != SSYM_OK)
                     return rc;
                 SSYM_HIP_CHECK(ctx, hipEventRecord(ev[3], st));
@@ -396,7 +399,7 @@ int32_t ssym_match_queries(ssym_ctx *ctx, const ssym_dict *dict, const ssym_quer
                 if (rc != SSYM_OK)
                     return rc;
                 SSYM_HIP_CHECK(ctx, hipEventRecord(ev[4], st));
-                rc = launch_dtw_final(ctx, src, tgt, distDev, (uint32_t)cap, index_base, idxDev, costDev);
+                rc = launch_dtw_final(ctx, src, tgt, distDev, (uint32_t)cap, index_base, k_top, idxDev, costDev);
                 if (rc != SSYM_OK)
                     return rc;
                 SSYM_HIP_CHECK(ctx, hipEventRecord(ev[5], st));
@@ -435,7 +438,7 @@ int32_t ssym_match_queries(ssym_ctx *ctx, const ssym_dict *dict, const ssym_quer
             if (rc != SSYM_OK)
                 return rc;
             SSYM_HIP_CHECK(ctx, hipEventRecord(ev[1], st));
-            rc = launch_dtw_final_allpairs(ctx, N, M, costs, distDev, index_base, idxDev, costDev);
+            rc = launch_dtw_final_allpairs(ctx, N, M, costs, distDev, index_base, k_top, idxDev, costDev);
             if (rc != SSYM_OK)
                 return rc;
             SSYM_HIP_CHECK(ctx, hipEventRecord(ev[2], st));
@@ -448,14 +451,36 @@ int32_t ssym_match_queries(ssym_ctx *ctx, const ssym_dict *dict, const ssym_quer
     }
 
     if (!outDev) {
-        SSYM_HIP_CHECK(ctx, hipMemcpyAsync(out_idx, idxDev, sizeof(uint32_t) * M, hipMemcpyDeviceToHost, st));
+        SSYM_HIP_CHECK(ctx, hipMemcpyAsync(out_idx, idxDev, sizeof(uint32_t) * (size_t)M * k_top,
+                                           hipMemcpyDeviceToHost, st));
         if (out_cost)
-            SSYM_HIP_CHECK(ctx, hipMemcpyAsync(out_cost, costDev, sizeof(double) * M,
+            SSYM_HIP_CHECK(ctx, hipMemcpyAsync(out_cost, costDev, sizeof(double) * (size_t)M * k_top,
                                                hipMemcpyDeviceToHost, st));
         SSYM_HIP_CHECK(ctx, hipStreamSynchronize(st));
     }
     ctx->timings = tm;
     return SSYM_OK;
+}
+
+extern "C" {
+
+int32_t ssym_match_queries(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queries *q,
+                           const double *distance, uint32_t index_base, uint32_t *out_idx,
+                           double *out_cost, uint32_t flags)
+{
+    return match_impl(ctx, dict, q, distance, index_base, 1, out_idx, out_cost, flags);
+}
+
+int32_t ssym_match_topk(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queries *q, const double *distance,
+                        uint32_t k, uint32_t index_base, uint32_t *out_idx, double *out_cost, uint32_t flags)
+{
+    if (!ctx)
+        return SSYM_E_INVALID;
+    if (k == 0 || k > SSYM_TOPK_MAX) {
+        ctx->err = "ssym_match_topk: k must be in 1..SSYM_TOPK_MAX";
+        return SSYM_E_INVALID;
+    }
+    return match_impl(ctx, dict, q, distance, index_base, k, out_idx, out_cost, flags);
 }
 
 int32_t ssym_match_batch(ssym_ctx *ctx, const ssym_dict *dict, const void *tgt_feats,

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void dtw_colmin_kernel(
     const float *__restrict__ cmat, uint32_t nSrc, uint32_t nTgt,
     uint32_t mPad, const double *__restrict__ dist, const int *__restrict__ srcLen,
     const float *__restrict__ srcMaxSq, const int *__restrict__ tgtLen, const float *__restrict__ tgtMaxSq,
-    MarginParams mp, unsigned long long *__restrict__ ub)
+    MarginParams mp, const unsigned long long *__restrict__ prev, unsigned long long *__restrict__ ub)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nTgt)
@@ -114,12 +114,14 @@ __global__ __launch_bounds__(256) void dtw_colmin_kernel(
     const int fb = tgtLen[t];
     const uint32_t s0 = blockIdx.y * kSelChunk;
     const uint32_t s1 = min(s0 + kSelChunk, nSrc);
+    // top-k rounds (prev != NULL): the smallest bound strictly above the previous round's
+    const double floorv = prev ? __longlong_as_double((long long)prev[t]) : -1.0;
     double best = __builtin_inf();
     for (uint32_t s = s0; s < s1; ++s) {
         const size_t o = (size_t)s * mPad + t;
         double klo, khi;
         dtw_key_interval(mp, (double)cmat[o], 0.0, (double)srcMaxSq[s], nb, srcLen[s], fb, delta, klo, khi);
-        if (khi < best)
+        if (khi < best && khi > floorv)
             best = khi;
     }
     if (best < __builtin_inf())
@@ -233,6 +235,7 @@ __global__ void dtw_stage2_ub_kernel(const uint32_t *__restrict__ hdr1, const ui
                                      uint32_t mPad, const double *__restrict__ dist, const int *__restrict__ srcLen,
                                      const float *__restrict__ srcMaxSq, const int *__restrict__ tgtLen,
                                      const float *__restrict__ tgtMaxSq, MarginParams mp,
+                                     const unsigned long long *__restrict__ prev,
                                      unsigned long long *__restrict__ ub)
 {
     const uint32_t n = hdr1[1] ? 0u : min(hdr1[0], cap);     // overflowed list 1: the host redoes stage 1
@@ -241,7 +244,8 @@ __global__ void dtw_stage2_ub_kernel(const uint32_t *__restrict__ hdr1, const ui
         double klo, khi;
         dtw_key_interval(mp, (double)cmat[(size_t)p.x * mPad + p.y], (double)xmin[k], (double)srcMaxSq[p.x],
                          (double)tgtMaxSq[p.y], srcLen[p.x], tgtLen[p.y], dist ? dist[p.y] : 0.0, klo, khi);
-        if (khi < __builtin_inf())
+        const double floorv = prev ? __longlong_as_double((long long)prev[p.y]) : -1.0;
+        if (khi < __builtin_inf() && khi > floorv)
             atomicMin(&ub[p.y], (unsigned long long)__double_as_longlong(khi));
     }
 }
@@ -265,18 +269,53 @@ __global__ void dtw_stage2_keep_kernel(const uint32_t *__restrict__ hdr1, const 
     }
 }
 
+// ---- top-k rounds (ssym_match_topk) --------------------------------------------------------------
+// The k best per target are found in k rounds of the same first-minimum machinery, each round
+// restricted to entries lexicographically above the previous round's winner (key, index).
+// For the candidate THRESHOLD a round takes the smallest upper bound strictly above the previous
+// one: after k rounds that is the k-th smallest DISTINCT upper bound, which is >= the k-th smallest
+// with multiplicity, so at least k pairs have their exact key below it and every pair of the exact
+// top k (key <= the k-th exact key <= threshold) is kept.
+constexpr unsigned long long kInfBits = 0x7ff0000000000000ull;
+constexpr unsigned long long kDblMaxBits = 0x7fefffffffffffffull;
+
+// after a threshold round: nothing above prev -> fewer than k distinct bounds -> keep every finite pair
+__global__ void topk_advance_kernel(unsigned long long *__restrict__ cur, unsigned long long *__restrict__ prev,
+                                    uint32_t n, int round, int last)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n)
+        return;
+    unsigned long long v = cur[t];
+    if (v == kInfBits && round > 0)
+        v = kDblMaxBits;
+    prev[t] = v;
+    cur[t] = last ? v : kInfBits;
+}
+
+__device__ __forceinline__ bool above_prev(double key, uint32_t s, const unsigned long long *prevKey,
+                                           const uint32_t *prevIdx, uint32_t t)
+{
+    if (!prevKey)
+        return true;
+    const double pk = __longlong_as_double((long long)prevKey[t]);
+    return key > pk || (key == pk && s > prevIdx[t]);
+}
+
 // final first-minimum over exactly re-scored candidates, three order-independent passes:
 //   A: bestKey[t] = min key      B: bestIdx[t] = min s among key == bestKey      C: outputs
 __global__ void dtw_final_key_kernel(const uint32_t *__restrict__ candHdr, const uint2 *__restrict__ pairs,
                                      const double *__restrict__ costs, uint32_t cap,
                                      const double *__restrict__ dist,
+                                     const unsigned long long *__restrict__ prevKey,
+                                     const uint32_t *__restrict__ prevIdx,
                                      unsigned long long *__restrict__ bestKey)
 {
     const uint32_t n = min(candHdr[0], cap);
     for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
         const uint2 p = pairs[k];
         const double key = fabs(costs[k] - (dist ? dist[p.y] : 0.0));
-        if (key < __builtin_inf())
+        if (key < __builtin_inf() && above_prev(key, p.x, prevKey, prevIdx, p.y))
             atomicMin(&bestKey[p.y], (unsigned long long)__double_as_longlong(key));
     }
 }
@@ -284,6 +323,8 @@ __global__ void dtw_final_key_kernel(const uint32_t *__restrict__ candHdr, const
 __global__ void dtw_final_idx_kernel(const uint32_t *__restrict__ candHdr, const uint2 *__restrict__ pairs,
                                      const double *__restrict__ costs, uint32_t cap,
                                      const double *__restrict__ dist,
+                                     const unsigned long long *__restrict__ prevKey,
+                                     const uint32_t *__restrict__ prevIdx,
                                      const unsigned long long *__restrict__ bestKey,
                                      uint32_t *__restrict__ bestIdx)
 {
@@ -291,7 +332,8 @@ __global__ void dtw_final_idx_kernel(const uint32_t *__restrict__ candHdr, const
     for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
         const uint2 p = pairs[k];
         const double key = fabs(costs[k] - (dist ? dist[p.y] : 0.0));
-        if ((unsigned long long)__double_as_longlong(key) == bestKey[p.y])
+        if ((unsigned long long)__double_as_longlong(key) == bestKey[p.y] &&
+            above_prev(key, p.x, prevKey, prevIdx, p.y))
             atomicMin(&bestIdx[p.y], p.x);
     }
 }
@@ -324,6 +366,40 @@ __global__ void dtw_final_out_kernel(const uint32_t *__restrict__ candHdr, const
     }
 }
 
+// round r of top-k: entry r of every target's list, and the (key, index) the next round must exceed
+__global__ void dtw_final_out_topk_kernel(const uint32_t *__restrict__ candHdr, const uint2 *__restrict__ pairs,
+                                          const double *__restrict__ costs, uint32_t cap,
+                                          const unsigned long long *__restrict__ bestKey,
+                                          const uint32_t *__restrict__ bestIdx, uint32_t nTgt, uint32_t kTop,
+                                          uint32_t r, uint32_t indexBase, uint32_t *__restrict__ outIdx,
+                                          double *__restrict__ outCost, unsigned long long *__restrict__ prevKey,
+                                          uint32_t *__restrict__ prevIdx)
+{
+    const uint32_t n = min(candHdr[0], cap);
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t t = tid; t < nTgt; t += stride) {
+        if (bestIdx[t] == 0xffffffffu) {
+            outIdx[(size_t)t * kTop + r] = SSYM_NO_MATCH;
+            if (outCost)
+                outCost[(size_t)t * kTop + r] = __builtin_nan("");
+            prevKey[t] = kInfBits;          // nothing is above +inf: later rounds stay empty
+            prevIdx[t] = 0xffffffffu;
+        } else {
+            prevKey[t] = bestKey[t];
+            prevIdx[t] = bestIdx[t];
+        }
+    }
+    for (uint32_t k = tid; k < n; k += stride) {
+        const uint2 p = pairs[k];
+        if (bestIdx[p.y] == p.x) {
+            outIdx[(size_t)p.y * kTop + r] = p.x + indexBase;
+            if (outCost)
+                outCost[(size_t)p.y * kTop + r] = costs[k];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Generic first-minimum over a full [nSrc][nTgt] f64 matrix (refcos similarities, or exact dtw
 // costs when the filter is bypassed).  Chunks are folded in source order with a strict '<', so
@@ -334,6 +410,8 @@ constexpr int kFoldChunk = 128;
 __global__ __launch_bounds__(128) void fold_partial_kernel(const double *__restrict__ mat, uint32_t nSrc,
                                                            uint32_t nTgt, const double *__restrict__ dist,
                                                            double defaultDist, double init,
+                                                           const double *__restrict__ prevVal,
+                                                           const uint32_t *__restrict__ prevIdx,
                                                            uint32_t *__restrict__ partIdx,
                                                            double *__restrict__ partVal)
 {
@@ -345,8 +423,13 @@ __global__ __launch_bounds__(128) void fold_partial_kernel(const double *__restr
     const uint32_t s1 = min(s0 + kFoldChunk, nSrc);
     uint32_t minIdx = 0xffffffffu;
     double minVal = init;
+    // top-k rounds (prevVal != NULL): only entries above the previous round's (value, index)
+    const double pv = prevVal ? prevVal[t] : -1.0;
+    const uint32_t pi = prevVal ? prevIdx[t] : 0u;
     for (uint32_t s = s0; s < s1; ++s) {
         const double v = fabs(mat[(size_t)s * nTgt + t] - delta);   // src/sound.rs:359
+        if (prevVal && !(v > pv || (v == pv && s > pi)))
+            continue;
         if (v < minVal) {                                           // src/sound.rs:362 (NaN never wins)
             minIdx = s;
             minVal = v;
@@ -385,6 +468,44 @@ __global__ __launch_bounds__(128) void fold_final_kernel(const uint32_t *__restr
     }
 }
 
+__global__ __launch_bounds__(128) void fold_final_topk_kernel(const uint32_t *__restrict__ partIdx,
+                                                              const double *__restrict__ partVal,
+                                                              uint32_t nChunks, uint32_t nTgt, double init,
+                                                              const double *__restrict__ gatherFrom,
+                                                              uint32_t indexBase, uint32_t kTop, uint32_t r,
+                                                              uint32_t *__restrict__ outIdx,
+                                                              double *__restrict__ outCost,
+                                                              double *__restrict__ prevVal,
+                                                              uint32_t *__restrict__ prevIdx)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nTgt)
+        return;
+    uint32_t minIdx = 0xffffffffu;
+    double minVal = init;
+    for (uint32_t c = 0; c < nChunks; ++c) {
+        const double v = partVal[(size_t)c * nTgt + t];
+        if (v < minVal) {
+            minVal = v;
+            minIdx = partIdx[(size_t)c * nTgt + t];
+        }
+    }
+    const size_t o = (size_t)t * kTop + r;
+    if (minIdx == 0xffffffffu) {            // nothing (left) below the fold start
+        outIdx[o] = SSYM_NO_MATCH;
+        if (outCost)
+            outCost[o] = __builtin_nan("");
+        prevVal[t] = __builtin_inf();
+        prevIdx[t] = 0xffffffffu;
+        return;
+    }
+    outIdx[o] = minIdx + indexBase;
+    if (outCost)
+        outCost[o] = gatherFrom ? gatherFrom[(size_t)minIdx * nTgt + t] : minVal;
+    prevVal[t] = minVal;
+    prevIdx[t] = minIdx;
+}
+
 // Source-sharded multi-GPU merge: smallest cost, lowest global index
 // on equal cost.  Shards are ordered by index, so this is the same first-minimum rule.
 __global__ void merge_shards_kernel(uint32_t nShards, uint32_t nTgt, const double *__restrict__ costs,
@@ -421,8 +542,19 @@ static MarginParams margin_params(const ssym_ctx *ctx, const SegmentSet &src)
     return mp;
 }
 
+// scratch for top-k rounds: [M] u64 previous bound / key bits, [M] u32 previous index
+static int32_t topk_scratch(ssym_ctx *ctx, uint32_t m, unsigned long long **prevKey, uint32_t **prevIdx)
+{
+    int32_t rc = ensure(ctx, ctx->topk, (sizeof(unsigned long long) + sizeof(uint32_t)) * (size_t)m);
+    if (rc != SSYM_OK)
+        return rc;
+    *prevKey = (unsigned long long *)ctx->topk.ptr;
+    *prevIdx = (uint32_t *)(*prevKey + m);
+    return SSYM_OK;
+}
+
 int32_t launch_dtw_select2(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, const float *cmat,
-                           const float *xmin, const double *dist_dev, uint32_t cap)
+                           const float *xmin, const double *dist_dev, uint32_t cap, uint32_t k_top)
 {
     hipStream_t st = ctx->stream;
     const MarginParams mp = margin_params(ctx, src);
@@ -434,11 +566,26 @@ int32_t launch_dtw_select2(ssym_ctx *ctx, const SegmentSet &src, const SegmentSe
     const uint2 *pairs1 = (const uint2 *)(hdr1 + 2);
     uint32_t *hdr2 = (uint32_t *)ctx->cand2.ptr;
     uint2 *pairs2 = (uint2 *)(hdr2 + 2);
-    fill_u64_kernel<<<(tgt.n + 255) / 256, 256, 0, st>>>(ub, 0x7ff0000000000000ull, tgt.n);
+    const unsigned tb = (tgt.n + 255) / 256;
+    fill_u64_kernel<<<tb, 256, 0, st>>>(ub, kInfBits, tgt.n);
     SSYM_HIP_CHECK(ctx, hipMemsetAsync(hdr2, 0, sizeof(uint32_t) * 2, st));
     const unsigned blocks = std::max(1u, std::min((cap + 255) / 256, 2048u));
-    dtw_stage2_ub_kernel<<<blocks, 256, 0, st>>>(hdr1, pairs1, xmin, cap, cmat, tgt.n_pad, dist_dev, src.len,
-                                                 src.max_sqnorm, tgt.len, tgt.max_sqnorm, mp, ub);
+    if (k_top <= 1) {
+        dtw_stage2_ub_kernel<<<blocks, 256, 0, st>>>(hdr1, pairs1, xmin, cap, cmat, tgt.n_pad, dist_dev, src.len,
+                                                     src.max_sqnorm, tgt.len, tgt.max_sqnorm, mp, nullptr, ub);
+    } else {
+        unsigned long long *prev;
+        uint32_t *prevIdx;
+        rc = topk_scratch(ctx, tgt.n, &prev, &prevIdx);
+        if (rc != SSYM_OK)
+            return rc;
+        for (uint32_t r = 0; r < k_top; ++r) {
+            dtw_stage2_ub_kernel<<<blocks, 256, 0, st>>>(hdr1, pairs1, xmin, cap, cmat, tgt.n_pad, dist_dev,
+                                                         src.len, src.max_sqnorm, tgt.len, tgt.max_sqnorm, mp,
+                                                         r ? prev : nullptr, ub);
+            topk_advance_kernel<<<tb, 256, 0, st>>>(ub, prev, tgt.n, (int)r, r + 1 == k_top);
+        }
+    }
     dtw_stage2_keep_kernel<<<blocks, 256, 0, st>>>(hdr1, pairs1, xmin, cap, cmat, tgt.n_pad, dist_dev, src.len,
                                                    src.max_sqnorm, tgt.len, tgt.max_sqnorm, mp, ub, hdr2, pairs2);
     SSYM_HIP_CHECK(ctx, hipGetLastError());
@@ -446,7 +593,7 @@ int32_t launch_dtw_select2(ssym_ctx *ctx, const SegmentSet &src, const SegmentSe
 }
 
 int32_t launch_dtw_select(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt,
-                          const float *cmat, const double *dist_dev, uint32_t cap)
+                          const float *cmat, const double *dist_dev, uint32_t cap, uint32_t k_top)
 {
     hipStream_t st = ctx->stream;
     const MarginParams mp = margin_params(ctx, src);
@@ -459,7 +606,7 @@ int32_t launch_dtw_select(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
     unsigned long long *ub = (unsigned long long *)ctx->tmin.ptr;
     uint32_t *hdr = (uint32_t *)ctx->cand.ptr;
     uint2 *pairs = (uint2 *)(hdr + 2);
-    const unsigned long long infBits = 0x7ff0000000000000ull;
+    const unsigned long long infBits = kInfBits;
     const uint32_t nChunks = (src.n + kSelChunk - 1) / kSelChunk;
     rc = ensure(ctx, ctx->selmask, sizeof(unsigned long long) * (size_t)nChunks * tgt.n);
     if (rc != SSYM_OK)
@@ -472,8 +619,21 @@ int32_t launch_dtw_select(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
     fill_u64_kernel<<<(tgt.n + 255) / 256, 256, 0, st>>>(ub, infBits, tgt.n);
     SSYM_HIP_CHECK(ctx, hipMemsetAsync(cnt, 0, sizeof(uint32_t) * 2 * (size_t)tgt.n, st));
     dim3 grid((tgt.n + 255) / 256, nChunks);
-    dtw_colmin_kernel<<<grid, 256, 0, st>>>(cmat, src.n, tgt.n, tgt.n_pad, dist_dev, src.len,
-                                            src.max_sqnorm, tgt.len, tgt.max_sqnorm, mp, ub);
+    if (k_top <= 1) {
+        dtw_colmin_kernel<<<grid, 256, 0, st>>>(cmat, src.n, tgt.n, tgt.n_pad, dist_dev, src.len,
+                                                src.max_sqnorm, tgt.len, tgt.max_sqnorm, mp, nullptr, ub);
+    } else {
+        unsigned long long *prev;
+        uint32_t *prevIdx;
+        rc = topk_scratch(ctx, tgt.n, &prev, &prevIdx);
+        if (rc != SSYM_OK)
+            return rc;
+        for (uint32_t r = 0; r < k_top; ++r) {
+            dtw_colmin_kernel<<<grid, 256, 0, st>>>(cmat, src.n, tgt.n, tgt.n_pad, dist_dev, src.len, src.max_sqnorm,
+                                                    tgt.len, tgt.max_sqnorm, mp, r ? prev : nullptr, ub);
+            topk_advance_kernel<<<(tgt.n + 255) / 256, 256, 0, st>>>(ub, prev, tgt.n, (int)r, r + 1 == k_top);
+        }
+    }
     dtw_mark_kernel<<<grid, 256, 0, st>>>(cmat, src.n, tgt.n, tgt.n_pad, dist_dev, src.len,
                                           src.max_sqnorm, tgt.len, tgt.max_sqnorm, mp, ub, mask, cnt);
     dtw_scan_kernel<<<1, 1024, 0, st>>>(cnt, tgt.n, cap, hdr);
@@ -483,7 +643,7 @@ int32_t launch_dtw_select(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
 }
 
 int32_t launch_dtw_final(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt,
-                         const double *dist_dev, uint32_t cap, uint32_t index_base,
+                         const double *dist_dev, uint32_t cap, uint32_t index_base, uint32_t k_top,
                          uint32_t *out_idx_dev, double *out_cost_dev)
 {
     (void)src;
@@ -496,21 +656,42 @@ int32_t launch_dtw_final(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet 
     const uint32_t *hdr = (const uint32_t *)ctx->cand2.ptr;     // list 2: the exactly re-scored pairs
     const uint2 *pairs = (const uint2 *)(hdr + 2);
     const double *costs = (const double *)ctx->cand_cost.ptr;
-    fill_u64_kernel<<<(tgt.n + 255) / 256, 256, 0, st>>>(bestKey, 0x7ff0000000000000ull, tgt.n);
-    fill_u32_kernel<<<(tgt.n + 255) / 256, 256, 0, st>>>(bestIdx, 0xffffffffu, tgt.n);
+    const unsigned tb = (tgt.n + 255) / 256;
     const unsigned blocks = std::max(1u, std::min((cap + 255) / 256, 1024u));
-    dtw_final_key_kernel<<<blocks, 256, 0, st>>>(hdr, pairs, costs, cap, dist_dev, bestKey);
-    dtw_final_idx_kernel<<<blocks, 256, 0, st>>>(hdr, pairs, costs, cap, dist_dev, bestKey, bestIdx);
-    const unsigned blocks2 = std::max(blocks, std::min((tgt.n + 255) / 256, 1024u));
-    dtw_final_out_kernel<<<blocks2, 256, 0, st>>>(hdr, pairs, costs, cap, bestIdx, tgt.n, index_base,
-                                                  out_idx_dev, out_cost_dev);
+    const unsigned blocks2 = std::max(blocks, std::min(tb, 1024u));
+    if (k_top <= 1) {
+        fill_u64_kernel<<<tb, 256, 0, st>>>(bestKey, kInfBits, tgt.n);
+        fill_u32_kernel<<<tb, 256, 0, st>>>(bestIdx, 0xffffffffu, tgt.n);
+        dtw_final_key_kernel<<<blocks, 256, 0, st>>>(hdr, pairs, costs, cap, dist_dev, nullptr, nullptr, bestKey);
+        dtw_final_idx_kernel<<<blocks, 256, 0, st>>>(hdr, pairs, costs, cap, dist_dev, nullptr, nullptr, bestKey,
+                                                     bestIdx);
+        dtw_final_out_kernel<<<blocks2, 256, 0, st>>>(hdr, pairs, costs, cap, bestIdx, tgt.n, index_base,
+                                                      out_idx_dev, out_cost_dev);
+    } else {
+        unsigned long long *prevKey;
+        uint32_t *prevIdx;
+        rc = topk_scratch(ctx, tgt.n, &prevKey, &prevIdx);
+        if (rc != SSYM_OK)
+            return rc;
+        for (uint32_t r = 0; r < k_top; ++r) {
+            fill_u64_kernel<<<tb, 256, 0, st>>>(bestKey, kInfBits, tgt.n);
+            fill_u32_kernel<<<tb, 256, 0, st>>>(bestIdx, 0xffffffffu, tgt.n);
+            dtw_final_key_kernel<<<blocks, 256, 0, st>>>(hdr, pairs, costs, cap, dist_dev, r ? prevKey : nullptr,
+                                                         prevIdx, bestKey);
+            dtw_final_idx_kernel<<<blocks, 256, 0, st>>>(hdr, pairs, costs, cap, dist_dev, r ? prevKey : nullptr,
+                                                         prevIdx, bestKey, bestIdx);
+            dtw_final_out_topk_kernel<<<blocks2, 256, 0, st>>>(hdr, pairs, costs, cap, bestKey, bestIdx, tgt.n,
+                                                               k_top, r, index_base, out_idx_dev, out_cost_dev,
+                                                               prevKey, prevIdx);
+        }
+    }
     SSYM_HIP_CHECK(ctx, hipGetLastError());
     return SSYM_OK;
 }
 
 static int32_t launch_fold(ssym_ctx *ctx, uint32_t n_src, uint32_t n_tgt, const double *mat,
                            const double *dist_dev, double default_dist, double init, bool gather,
-                           uint32_t index_base, uint32_t *out_idx_dev, double *out_cost_dev)
+                           uint32_t index_base, uint32_t k_top, uint32_t *out_idx_dev, double *out_cost_dev)
 {
     hipStream_t st = ctx->stream;
     const uint32_t nChunks = (n_src + kFoldChunk - 1) / kFoldChunk;
@@ -520,29 +701,46 @@ static int32_t launch_fold(ssym_ctx *ctx, uint32_t n_src, uint32_t n_tgt, const 
     double *partVal = (double *)ctx->part.ptr;
     uint32_t *partIdx = (uint32_t *)(partVal + (size_t)nChunks * n_tgt);
     dim3 grid((n_tgt + 127) / 128, nChunks);
-    fold_partial_kernel<<<grid, 128, 0, st>>>(mat, n_src, n_tgt, dist_dev, default_dist, init, partIdx,
-                                              partVal);
-    fold_final_kernel<<<(n_tgt + 127) / 128, 128, 0, st>>>(partIdx, partVal, nChunks, n_tgt, init,
-                                                           gather ? mat : nullptr, index_base,
-                                                           out_idx_dev, out_cost_dev);
+    if (k_top <= 1) {
+        fold_partial_kernel<<<grid, 128, 0, st>>>(mat, n_src, n_tgt, dist_dev, default_dist, init, nullptr, nullptr,
+                                                  partIdx, partVal);
+        fold_final_kernel<<<(n_tgt + 127) / 128, 128, 0, st>>>(partIdx, partVal, nChunks, n_tgt, init,
+                                                               gather ? mat : nullptr, index_base,
+                                                               out_idx_dev, out_cost_dev);
+    } else {
+        unsigned long long *prevBits;
+        uint32_t *prevIdx;
+        rc = topk_scratch(ctx, n_tgt, &prevBits, &prevIdx);
+        if (rc != SSYM_OK)
+            return rc;
+        double *prevVal = (double *)prevBits;
+        for (uint32_t r = 0; r < k_top; ++r) {
+            fold_partial_kernel<<<grid, 128, 0, st>>>(mat, n_src, n_tgt, dist_dev, default_dist, init,
+                                                      r ? prevVal : nullptr, prevIdx, partIdx, partVal);
+            fold_final_topk_kernel<<<(n_tgt + 127) / 128, 128, 0, st>>>(partIdx, partVal, nChunks, n_tgt, init,
+                                                                        gather ? mat : nullptr, index_base, k_top,
+                                                                        r, out_idx_dev, out_cost_dev, prevVal,
+                                                                        prevIdx);
+        }
+    }
     SSYM_HIP_CHECK(ctx, hipGetLastError());
     return SSYM_OK;
 }
 
 int32_t launch_dtw_final_allpairs(ssym_ctx *ctx, uint32_t n_src, uint32_t n_tgt, const double *costs,
-                                  const double *dist_dev, uint32_t index_base,
+                                  const double *dist_dev, uint32_t index_base, uint32_t k_top,
                                   uint32_t *out_idx_dev, double *out_cost_dev)
 {
-    return launch_fold(ctx, n_src, n_tgt, costs, dist_dev, 0.0, (double)INFINITY, true, index_base,
+    return launch_fold(ctx, n_src, n_tgt, costs, dist_dev, 0.0, (double)INFINITY, true, index_base, k_top,
                        out_idx_dev, out_cost_dev);
 }
 
 int32_t launch_refcos_argmin(ssym_ctx *ctx, uint32_t n_src, uint32_t n_tgt, const double *sims,
-                             const double *dist_dev, uint32_t index_base, uint32_t *out_idx_dev,
-                             double *out_cost_dev)
+                             const double *dist_dev, uint32_t index_base, uint32_t k_top,
+                             uint32_t *out_idx_dev, double *out_cost_dev)
 {
     // match_sound = at_distance(1.0, ..) (src/sound.rs:346-348); fold start 2.0 (src/sound.rs:361)
-    return launch_fold(ctx, n_src, n_tgt, sims, dist_dev, 1.0, 2.0, false, index_base, out_idx_dev,
+    return launch_fold(ctx, n_src, n_tgt, sims, dist_dev, 1.0, 2.0, false, index_base, k_top, out_idx_dev,
                        out_cost_dev);
 }
 

@@ -87,6 +87,7 @@ struct ssym_ctx {
     ssym::DeviceBuf cand_xmin;  // certificate (smallest cell) per list-1 pair
     ssym::DeviceBuf cand_cost;  // exact f64 cost per candidate
     ssym::DeviceBuf best;       // per-target best bits / idx
+    ssym::DeviceBuf topk;       // top-k rounds: previous round's key bits / index per target
     ssym::DeviceBuf dist;       // per-target distance (f64)
     ssym::DeviceBuf part;       // refcos partial argmin
     ssym::DeviceBuf out_idx, out_cost;  // staging for host outputs
@@ -136,24 +137,20 @@ int32_t launch_dtw_exact(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet 
                          const uint2 *pairs, const uint32_t *count_dev, uint32_t max_pairs,
                          double *out);
 
-// select.hip
-struct SelectParams {
-    uint32_t n_src, n_tgt, n_src_pad, n_tgt_pad;
-    uint32_t cap;           // candidate capacity
-    float cell_err_scale;   // see select.hip
-};
+// select.hip.  k_top = 1: the reference's first-minimum fold; k_top > 1: ssym_match_topk, outputs
+// [n_tgt][k_top] (rounds of the same fold, each above the previous round's (key, index))
 // stage 1: worst-case margin over the whole filter matrix -> ctx->cand (list 1)
 int32_t launch_dtw_select(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt,
-                          const float *cmat, const double *dist_dev, uint32_t cap);
+                          const float *cmat, const double *dist_dev, uint32_t cap, uint32_t k_top);
 // stage 2: per-pair intervals from the certificates of list 1 -> ctx->cand2 (list 2, same capacity)
 int32_t launch_dtw_select2(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, const float *cmat,
-                           const float *xmin, const double *dist_dev, uint32_t cap);
+                           const float *xmin, const double *dist_dev, uint32_t cap, uint32_t k_top);
 int32_t launch_dtw_final(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt,
-                         const double *dist_dev, uint32_t cap, uint32_t index_base,
+                         const double *dist_dev, uint32_t cap, uint32_t index_base, uint32_t k_top,
                          uint32_t *out_idx_dev, double *out_cost_dev);
 int32_t launch_dtw_final_allpairs(ssym_ctx *ctx, uint32_t n_src, uint32_t n_tgt,
                                   const double *costs, const double *dist_dev,
-                                  uint32_t index_base, uint32_t *out_idx_dev,
+                                  uint32_t index_base, uint32_t k_top, uint32_t *out_idx_dev,
                                   double *out_cost_dev);
 int32_t launch_merge_shards(ssym_ctx *ctx, uint32_t n_shards, uint32_t n_targets,
                             const double *costs, const uint32_t *idx, uint32_t *out_idx,
@@ -163,7 +160,7 @@ int32_t launch_merge_shards(ssym_ctx *ctx, uint32_t n_shards, uint32_t n_targets
 int32_t launch_refcos_sims(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt,
                            double *sims /*[n_src][n_tgt]*/);
 int32_t launch_refcos_argmin(ssym_ctx *ctx, uint32_t n_src, uint32_t n_tgt, const double *sims,
-                             const double *dist_dev, uint32_t index_base, uint32_t *out_idx_dev,
-                             double *out_cost_dev);
+                             const double *dist_dev, uint32_t index_base, uint32_t k_top,
+                             uint32_t *out_idx_dev, double *out_cost_dev);
 
 }  // namespace ssym

@@ -159,6 +159,24 @@ class Engine:
         nat.check(rc, self.ctx)
         return idx, cost
 
+    def match_topk(self, d: _Handle, q: _Handle, k: int, distance=None, index_base: int = 0,
+                   force_exact: bool = False) -> Tuple[np.ndarray, np.ndarray]:
+        """ssym_match_topk: (idx [m][k] uint32, cost [m][k] f64); rows are ordered by
+        (|value - distance|, index); missing entries are nat.NO_MATCH / NaN."""
+        m = q.n
+        dist_p = None
+        if distance is not None:
+            dist = np.ascontiguousarray(distance, dtype=np.float64)
+            if dist.size != m:
+                raise ValueError("distance must have one entry per target")
+            dist_p = dist.ctypes.data
+        idx = np.zeros((m, k), dtype=np.uint32)
+        cost = np.zeros((m, k), dtype=np.float64)
+        rc = nat.lib().ssym_match_topk(self.ctx, d.ptr, q.ptr, dist_p, k, index_base, idx.ctypes.data,
+                                       cost.ctypes.data, nat.DTW_FORCE_EXACT if force_exact else 0)
+        nat.check(rc, self.ctx)
+        return idx, cost
+
     def match_batch(self, d: _Handle, feats, offsets, distance=None):
         """ssym_match_batch: pack host targets, match, release."""
         off = np.ascontiguousarray(offsets, dtype=np.uint64)

@@ -127,3 +127,32 @@ def test_reconstruct_and_pcm32(oracle):
     assert out.tolist() == [4, 5, 1, 2, 3, 0, 0, 1, 2, 3]
     assert oracle.pcm32([0.0, 0.5, -0.5, 1.0, 2.0, -2.0, float("nan"), 1e-10]).tolist() == [
         0, 1073741823, -1073741823, 2147483647, 2147483647, -2147483648, 0, 0]
+
+
+def test_topk_first_entry_is_at_distance_and_rows_are_sorted(oracle):
+    # row F1: entry 0 of the top-k is the reference's at_distance whenever something beats the
+    # fold start; rows are ordered by (key, index); NaN keys and keys >= 2.0 never enter
+    rng = np.random.default_rng(0x70B)
+    segs = [rng.normal(size=(int(rng.integers(1, 6)), 3)) for _ in range(23)]
+    segs[5] = segs[2].copy()                                     # an exact tie
+    segs.append(np.full((2, 3), np.nan))                         # NaN similarity to everything
+    tg = [rng.normal(size=(int(rng.integers(1, 6)), 3)) for _ in range(7)]
+    from oracle.oracle import pack_segments
+    sf, so = pack_segments(segs, 3)
+    tf, to = pack_segments(tg, 3)
+    sims = oracle.refcos_matrix(sf, so, tf, to, 3)
+    dist = rng.uniform(0.0, 1.5, size=len(tg))
+    idx, key = oracle.topk(sims, 6, distance=dist)
+    first, val = oracle.refcos_match_all(sf, so, tf, to, 3, distance=dist)
+    for t in range(len(tg)):
+        keys_t = np.abs(sims[:, t] - dist[t])
+        ok = np.where(keys_t < 2.0)[0]                           # NaN < 2.0 is False
+        want = sorted(ok, key=lambda s: (keys_t[s], s))[:6]
+        got = [int(i) for i in idx[t] if i >= 0]
+        assert got == [int(w) for w in want]
+        if got:
+            assert got[0] == first[t] and key[t, 0] == val[t]
+        assert len(segs) - 1 not in got                          # the NaN segment
+    # fewer candidates than k: the tail is (-1, NaN)
+    idx2, key2 = oracle.topk(sims[:2], 4)
+    assert (idx2[:, 2:] == -1).all() and np.isnan(key2[:, 2:]).all()
