@@ -180,6 +180,17 @@ SSYM_API int32_t ssym_match_batch(ssym_ctx *ctx, const ssym_dict *dict, const vo
 SSYM_API int32_t ssym_match_one(ssym_ctx *ctx, const ssym_dict *dict, const void *feats,
                        uint64_t n_frames, double distance, uint32_t *out_idx, double *out_cost);
 
+/* SoundSequence::from_distances (src/sound.rs:405-417): starting from `start`, step i matches the
+ * previous step's result (the start sound for i = 0) with at_distance(distances[i], .) and the
+ * match becomes the next query.  out_idx[i] / out_cost[i] (nullable) are step i's result, as
+ * ssym_match_one would return them.  The chain runs on the device without a host round trip per
+ * step: in refcos the later steps are row lookups in the dictionary's self-similarity matrix,
+ * which is computed on first use and kept with the dictionary (hence the non-const handle;
+ * n^2 f64 of device memory) until ssym_dict_append changes it; in dtw every step re-scores the
+ * dictionary against the current entry with the exact f64 kernel. */
+SSYM_API int32_t ssym_chain(ssym_ctx *ctx, ssym_dict *dict, const void *start_feats, uint64_t start_frames,
+                   const double *distances, uint32_t n_steps, uint32_t *out_idx, double *out_cost);
+
 /* The whole [n_sources][n_targets] matrix in HOST memory, row-major, f64:
  *   refcos: cosine_sim(source, target) (src/sound.rs:22-33), bit for bit;
  *   dtw:    exact = 0 -> the f32 MFMA filter's costs; exact = 1 -> the exact f64 costs. */

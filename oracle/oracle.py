@@ -209,6 +209,30 @@ class Oracle:
             raise ValueError("empty dictionary")
         return (idx, cost, mat) if want_matrix else (idx, cost)
 
+    def chain(self, src_flat, src_off, dim, start, distances, metric: str = "refcos"):
+        """SoundSequence::from_distances (src/sound.rs:405-417): a loop of at_distance calls, the
+        match of one step being the query of the next.  Returns (idx, val) per step."""
+        src_flat = np.ascontiguousarray(src_flat, dtype=np.float64)
+        src_off = np.ascontiguousarray(src_off, dtype=np.uint64)
+        cur = np.ascontiguousarray(start, dtype=np.float64).reshape(-1)
+        idx, val = [], []
+        for d in distances:
+            if metric == "refcos":
+                i, v = self.at_distance(src_flat, src_off, dim, float(d), cur)
+            else:
+                off1 = np.array([0, cur.size // dim], dtype=np.uint64)
+                _, _, mat = self.dtw_match_all(src_flat, src_off, cur, off1, dim, want_matrix=True)
+                keys = np.abs(mat[:, 0] - float(d))
+                i, best = 0, float("inf")
+                for s in range(keys.size):                       # src/sound.rs:361-367
+                    if keys[s] < best:
+                        i, best = s, float(keys[s])
+                v = float(mat[i, 0]) if best < float("inf") else float("inf")
+            idx.append(int(i))
+            val.append(v)
+            cur = src_flat[int(src_off[i]) * dim:int(src_off[i + 1]) * dim]
+        return np.array(idx, dtype=np.int64), np.array(val, dtype=np.float64)
+
     def max_threads(self) -> int:
         return self.lib.ssym_oracle_max_threads()
 

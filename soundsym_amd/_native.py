@@ -37,7 +37,7 @@ ABI_SYMBOLS = [
     "ssym_dict_append", "ssym_dict_size", "ssym_dict_destroy", "ssym_queries_create",
     "ssym_queries_create_device", "ssym_queries_destroy", "ssym_match_queries", "ssym_match_topk",
     "ssym_match_batch",
-    "ssym_match_one", "ssym_pair_matrix", "ssym_merge_shards", "ssym_samples_create",
+    "ssym_match_one", "ssym_chain", "ssym_pair_matrix", "ssym_merge_shards", "ssym_samples_create",
     "ssym_samples_destroy", "ssym_reconstruct",
 ]
 
@@ -165,6 +165,8 @@ def lib() -> ctypes.CDLL:
     L.ssym_match_batch.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp]
     L.ssym_match_one.restype = i32
     L.ssym_match_one.argtypes = [vp, vp, vp, u64, f64, vp, vp]
+    L.ssym_chain.restype = i32
+    L.ssym_chain.argtypes = [vp, vp, vp, u64, vp, u32, vp, vp]
     L.ssym_pair_matrix.restype = i32
     L.ssym_pair_matrix.argtypes = [vp, vp, vp, i32, vp]
     L.ssym_merge_shards.restype = i32

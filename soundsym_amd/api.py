@@ -205,11 +205,14 @@ class SoundSequence:
     @staticmethod
     def from_distances(distances: Sequence[float], start: Sound,
                        dict_: SoundDictionary) -> "SoundSequence":      # src/sound.rs:405-417
-        """Greedy chain: each step's query is the previous result, so it is serial by nature."""
-        sounds = [start]
-        for d in distances:
-            sounds.append(dict_.at_distance(float(d), sounds[-1]))
-        return SoundSequence(sounds)
+        """Greedy chain: each step's query is the previous result.  The steps run on the device
+        back to back (ssym_chain): one call, one wait."""
+        if not len(distances):
+            return SoundSequence([start])
+        if not dict_.sounds:
+            raise EmptyDictionaryError(-2, "empty dictionary")          # reference: panic, :369
+        idx, _ = dict_.engine.chain(dict_.resident(), start.mfccs(), distances)
+        return SoundSequence([start] + [dict_.sounds[int(i)] for i in idx])
 
     def morph_to(self, distances: Sequence[float], dict_: SoundDictionary) -> "SoundSequence":
         """src/sound.rs:440-449: zip(sounds, distances) -> at_distance, here as ONE batch."""

@@ -96,11 +96,12 @@ int32_t ssym_ctx_destroy(ssym_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     DeviceBuf *bufs[] = {&ctx->handoff, &ctx->cmat, &ctx->tmin, &ctx->cand, &ctx->cand2, &ctx->cand_xmin,
-                         &ctx->cand_cost, &ctx->best,
+                         &ctx->cand_cost, &ctx->best, &ctx->selmask, &ctx->selcnt, &ctx->topk,
                          &ctx->dist, &ctx->part, &ctx->out_idx, &ctx->out_cost};
     for (DeviceBuf *b : bufs)
         if (b->ptr)
             (void)hipFree(b->ptr);
+    dev_cache_release(ctx);
     for (auto &ev : ctx->ev)
         if (ev)
             (void)hipEventDestroy(ev);
@@ -133,7 +134,7 @@ static int32_t make_set(ssym_ctx *ctx, SegmentSet &set, const void *feats, bool 
     SSYM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     int32_t rc = pack_segments(ctx, set, feats, on_device, off, n, dim, is_source);
     if (rc != SSYM_OK)
-        free_segments(set);
+        free_segments(ctx, set);
     return rc;
 }
 
@@ -198,7 +199,9 @@ int32_t ssym_dict_destroy(ssym_ctx *ctx, ssym_dict *dict)
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
     }
-    free_segments(dict->set);
+    free_segments(ctx, dict->set);
+    if (dict->selfsim.ptr)
+        (void)hipFree(dict->selfsim.ptr);
     delete dict;
     return SSYM_OK;
 }
@@ -243,11 +246,9 @@ int32_t ssym_queries_destroy(ssym_ctx *ctx, ssym_queries *q)
 {
     if (!q)
         return SSYM_OK;
-    if (ctx) {
+    if (ctx)
         (void)hipSetDevice(ctx->device);
-        (void)hipStreamSynchronize(ctx->stream);
-    }
-    free_segments(q->set);
+    free_segments(ctx, q->set);      // blocks go back to the context's cache; reuse is stream-ordered
     delete q;
     return SSYM_OK;
 }
@@ -346,11 +347,7 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
         if (rc != SSYM_OK)
             return rc;
         SSYM_HIP_CHECK(ctx, hipEventRecord(ev[2], st));
-        SSYM_HIP_CHECK(ctx, hipStreamSynchronize(st));
-        tm.main_ms = ev_ms(ev[0], ev[1]);
-        tm.reduce_ms = ev_ms(ev[1], ev[2]);
-        tm.total_ms = ev_ms(ev[0], ev[2]);
-        tm.main_launches = 1;
+        tm.main_launches = 1;          // event times are read after the one synchronisation below
     } else {
         const bool useFilter = !(flags & SSYM_DTW_FORCE_EXACT) && filter_supported(ctx, src, tgt);
         tm.used_filter = useFilter ? 1 : 0;
@@ -456,7 +453,13 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
         if (out_cost)
             SSYM_HIP_CHECK(ctx, hipMemcpyAsync(out_cost, costDev, sizeof(double) * (size_t)M * k_top,
                                                hipMemcpyDeviceToHost, st));
+    }
+    if (!outDev || ctx->metric == SSYM_METRIC_REFCOS)
         SSYM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    if (ctx->metric == SSYM_METRIC_REFCOS) {
+        tm.main_ms = ev_ms(ev[0], ev[1]);
+        tm.reduce_ms = ev_ms(ev[1], ev[2]);
+        tm.total_ms = ev_ms(ev[0], ev[2]);
     }
     ctx->timings = tm;
     return SSYM_OK;
@@ -501,13 +504,19 @@ int32_t ssym_match_batch(ssym_ctx *ctx, const ssym_dict *dict, const void *tgt_f
     hipEvent_t e0 = ctx->ev[6], e1 = ctx->ev[7];
     SSYM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     SSYM_HIP_CHECK(ctx, hipEventRecord(e0, ctx->stream));
+    ctx->defer_sync = true;        // this call synchronises once, at the end of the match
     int32_t rc = ssym_queries_create(ctx, tgt_feats, tgt_frame_offsets, n_targets, dict->set.dim, &q);
-    if (rc != SSYM_OK)
+    ctx->defer_sync = false;
+    if (rc != SSYM_OK) {
+        (void)hipStreamSynchronize(ctx->stream);      // the caller's buffers may go after an error too
         return rc;
+    }
     SSYM_HIP_CHECK(ctx, hipEventRecord(e1, ctx->stream));
     rc = ssym_match_queries(ctx, dict, q, distance, 0, out_idx, out_cost, 0);
     if (rc == SSYM_OK)
         ctx->timings.pack_ms = ev_ms(e0, e1);
+    else
+        (void)hipStreamSynchronize(ctx->stream);
     ssym_queries_destroy(ctx, q);
     return rc;
 }
@@ -526,6 +535,106 @@ __global__ void f32_to_f64_matrix_kernel(const float *__restrict__ in, uint32_t 
     const uint32_t r = blockIdx.y;
     if (c < cols && r < rows)
         out[(size_t)r * cols + c] = (double)in[(size_t)r * ld + c];
+}
+
+/* from_distances (src/sound.rs:405-417) on the device; see chain.hip. */
+int32_t ssym_chain(ssym_ctx *ctx, ssym_dict *dict, const void *start_feats, uint64_t start_frames,
+                   const double *distances, uint32_t n_steps, uint32_t *out_idx, double *out_cost)
+{
+    if (!ctx)
+        return SSYM_E_INVALID;
+    if (!dict) {
+        ctx->err = "dictionary handle is NULL";
+        return SSYM_E_INVALID;
+    }
+    if (n_steps == 0)
+        return SSYM_OK;
+    if (!distances || !out_idx || (!start_feats && start_frames)) {
+        ctx->err = "ssym_chain: NULL argument";
+        return SSYM_E_INVALID;
+    }
+    const SegmentSet &src = dict->set;
+    const uint32_t N = src.n;
+    if (N == 0) {
+        ctx->err = "empty dictionary";          // the reference panics at the first step (:369)
+        return SSYM_E_EMPTY_DICT;
+    }
+    SSYM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const bool refcos = ctx->metric == SSYM_METRIC_REFCOS;
+    const double init = refcos ? 2.0 : (double)INFINITY;
+
+    // device outputs + the current index
+    int32_t rc = ensure(ctx, ctx->out_idx, sizeof(uint32_t) * ((size_t)n_steps + 1));
+    if (rc != SSYM_OK)
+        return rc;
+    rc = ensure(ctx, ctx->out_cost, sizeof(double) * n_steps);
+    if (rc != SSYM_OK)
+        return rc;
+    uint32_t *idxDev = (uint32_t *)ctx->out_idx.ptr;
+    uint32_t *cur = idxDev + n_steps;
+    double *costDev = (double *)ctx->out_cost.ptr;
+
+    // step 0: the start sound against the whole dictionary (N values)
+    const uint64_t off[2] = {0, start_frames};
+    ssym_queries *q = nullptr;
+    rc = ssym_queries_create(ctx, start_feats, off, 1, src.dim, &q);
+    if (rc != SSYM_OK)
+        return rc;
+    rc = ensure(ctx, ctx->cmat, sizeof(double) * N);
+    if (rc == SSYM_OK)
+        rc = refcos ? launch_refcos_sims(ctx, src, q->set, (double *)ctx->cmat.ptr)
+                    : launch_dtw_exact(ctx, src, q->set, nullptr, nullptr, 0, (double *)ctx->cmat.ptr);
+    if (rc == SSYM_OK)
+        rc = launch_chain_argmin(ctx, (const double *)ctx->cmat.ptr, 0, nullptr, N, distances[0], init, !refcos,
+                                 0, cur, idxDev, costDev);
+    if (rc != SSYM_OK) {
+        ssym_queries_destroy(ctx, q);
+        return rc;
+    }
+
+    if (n_steps > 1 && refcos) {
+        // later queries are dictionary entries: rows of the self-similarity matrix
+        if (dict->selfsim_n != N) {
+            rc = ensure(ctx, dict->selfsim, sizeof(double) * (size_t)N * N);
+            if (rc == SSYM_OK)
+                rc = launch_refcos_sims(ctx, src, src, (double *)dict->selfsim.ptr);
+            if (rc != SSYM_OK) {
+                ssym_queries_destroy(ctx, q);
+                return rc;
+            }
+            dict->selfsim_n = N;
+        }
+        for (uint32_t i = 1; i < n_steps && rc == SSYM_OK; ++i)
+            rc = launch_chain_argmin(ctx, (const double *)dict->selfsim.ptr, N, cur, N, distances[i], init, false, i,
+                                     cur, idxDev, costDev);
+    } else if (n_steps > 1) {
+        rc = ensure(ctx, ctx->cand, sizeof(uint32_t) * 2 + sizeof(uint2) * (size_t)N);
+        if (rc == SSYM_OK)
+            rc = ensure(ctx, ctx->cand_cost, sizeof(double) * N);
+        uint32_t *hdr = (uint32_t *)ctx->cand.ptr;
+        for (uint32_t i = 1; i < n_steps && rc == SSYM_OK; ++i) {
+            rc = launch_chain_pairs(ctx, cur, N, (uint2 *)(hdr + 2), hdr);
+            if (rc == SSYM_OK)
+                rc = launch_dtw_exact(ctx, src, src, (const uint2 *)(hdr + 2), hdr, N, (double *)ctx->cand_cost.ptr);
+            if (rc == SSYM_OK)
+                rc = launch_chain_argmin(ctx, (const double *)ctx->cand_cost.ptr, 0, nullptr, N, distances[i], init,
+                                         true, i, cur, idxDev, costDev);
+        }
+    }
+    if (rc == SSYM_OK) {
+        SSYM_HIP_CHECK(ctx, hipMemcpyAsync(out_idx, idxDev, sizeof(uint32_t) * n_steps, hipMemcpyDeviceToHost, st));
+        if (out_cost)
+            SSYM_HIP_CHECK(ctx, hipMemcpyAsync(out_cost, costDev, sizeof(double) * n_steps, hipMemcpyDeviceToHost,
+                                               st));
+    }
+    hipError_t e = hipStreamSynchronize(st);
+    ssym_queries_destroy(ctx, q);
+    if (rc == SSYM_OK && e != hipSuccess) {
+        ctx->err = std::string("ssym_chain: ") + hipGetErrorString(e);
+        return SSYM_E_HIP;
+    }
+    return rc;
 }
 
 int32_t ssym_pair_matrix(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queries *q, int32_t exact,

@@ -140,12 +140,14 @@ static int32_t ensure_records(ssym_ctx *ctx, const SegmentSet &set, double scale
         set.rec_lead == lead)
         return SSYM_OK;
     if (set.rec && set.rec_bytes != bytes) {
-        SSYM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        (void)hipFree(set.rec);
+        dev_free(ctx, set.rec);
         set.rec = nullptr;
     }
-    if (!set.rec)
-        SSYM_HIP_CHECK(ctx, hipMalloc(&set.rec, bytes));
+    if (!set.rec) {
+        int32_t rca = dev_alloc(ctx, &set.rec, bytes);
+        if (rca != SSYM_OK)
+            return rca;
+    }
     set.rec_bytes = bytes;
     dim3 grid((slots + 63) / 64, set.n_pad);
     build_filter_records_kernel<<<grid, 64, 0, ctx->stream>>>(set.raw, set.off, set.n, set.dim, slots,

@@ -85,15 +85,70 @@ __global__ void segment_stats_kernel(const double *__restrict__ raw, const uint6
     atomicMax(max_abs_bits, __float_as_uint(maf));
 }
 
-void free_segments(SegmentSet &set)
+// ---- cached device blocks ----------------------------------------------------------------------
+constexpr size_t kCacheBlockMax = (size_t)16 << 20;     // larger blocks go straight to the driver
+constexpr size_t kCacheTotalMax = (size_t)512 << 20;
+
+static size_t round_block(size_t bytes)
 {
-    if (set.raw) (void)hipFree(set.raw);
-    if (set.off) (void)hipFree(set.off);
-    if (set.norm) (void)hipFree(set.norm);
-    if (set.rec) (void)hipFree(set.rec);
+    size_t r = 256;
+    while (r < bytes)
+        r <<= 1;
+    return r;
+}
+
+int32_t dev_alloc(ssym_ctx *ctx, void **p, size_t bytes)
+{
+    const size_t want = bytes > kCacheBlockMax ? bytes : round_block(std::max<size_t>(bytes, 1));
+    auto it = ctx->free_blocks.find(want);
+    if (it != ctx->free_blocks.end()) {
+        *p = it->second;
+        ctx->free_blocks.erase(it);
+        ctx->free_bytes -= want;
+    } else {
+        SSYM_HIP_CHECK(ctx, hipMalloc(p, want));
+    }
+    ctx->live_blocks[*p] = want;
+    return SSYM_OK;
+}
+
+void dev_free(ssym_ctx *ctx, void *p)
+{
+    if (!p)
+        return;
+    if (ctx) {
+        auto it = ctx->live_blocks.find(p);
+        if (it != ctx->live_blocks.end()) {
+            const size_t sz = it->second;
+            ctx->live_blocks.erase(it);
+            if (sz <= kCacheBlockMax && ctx->free_bytes + sz <= kCacheTotalMax) {
+                ctx->free_blocks.emplace(sz, p);
+                ctx->free_bytes += sz;
+                return;
+            }
+        }
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    (void)hipFree(p);
+}
+
+void dev_cache_release(ssym_ctx *ctx)
+{
+    for (auto &kv : ctx->free_blocks)
+        (void)hipFree(kv.second);
+    ctx->free_blocks.clear();
+    ctx->free_bytes = 0;
+}
+
+void free_segments(ssym_ctx *ctx, SegmentSet &set)
+{
+    dev_free(ctx, set.raw);
+    dev_free(ctx, set.off);
+    dev_free(ctx, set.norm);
+    dev_free(ctx, set.rec);
     set.rec = nullptr;
-    if (set.len) (void)hipFree(set.len);
-    if (set.max_sqnorm) (void)hipFree(set.max_sqnorm);
+    dev_free(ctx, set.len);
+    dev_free(ctx, set.max_sqnorm);
     set = SegmentSet{};
 }
 
@@ -102,16 +157,16 @@ static int32_t build_derived(ssym_ctx *ctx, SegmentSet &set)
 {
     hipStream_t st = ctx->stream;
     const uint32_t n = set.n, dim = set.dim;
-    if (set.off) { (void)hipFree(set.off); set.off = nullptr; }
-    if (set.norm) { (void)hipFree(set.norm); set.norm = nullptr; }
-    if (set.len) { (void)hipFree(set.len); set.len = nullptr; }
-    if (set.max_sqnorm) { (void)hipFree(set.max_sqnorm); set.max_sqnorm = nullptr; }
+    dev_free(ctx, set.off); set.off = nullptr;
+    dev_free(ctx, set.norm); set.norm = nullptr;
+    dev_free(ctx, set.len); set.len = nullptr;
+    dev_free(ctx, set.max_sqnorm); set.max_sqnorm = nullptr;
 
     set.max_frames = 0;
     for (uint32_t i = 0; i < n; ++i)
         set.max_frames = std::max<uint32_t>(set.max_frames, (uint32_t)(set.h_off[i + 1] - set.h_off[i]));
 
-    SSYM_HIP_CHECK(ctx, hipMalloc((void **)&set.off, sizeof(uint64_t) * (n + 1)));
+    { int32_t rca = dev_alloc(ctx, (void **)&set.off, sizeof(uint64_t) * (n + 1)); if (rca != SSYM_OK) return rca; }
     SSYM_HIP_CHECK(ctx, hipMemcpyAsync(set.off, set.h_off.data(), sizeof(uint64_t) * (n + 1),
                                        hipMemcpyHostToDevice, st));
     if (n == 0) {
@@ -120,7 +175,7 @@ static int32_t build_derived(ssym_ctx *ctx, SegmentSet &set)
     }
 
     if (ctx->metric == SSYM_METRIC_REFCOS) {
-        SSYM_HIP_CHECK(ctx, hipMalloc((void **)&set.norm, sizeof(double) * n));
+        { int32_t rca = dev_alloc(ctx, (void **)&set.norm, sizeof(double) * n); if (rca != SSYM_OK) return rca; }
         segment_norm_kernel<<<(n + 63) / 64, 64, 0, st>>>(set.raw, set.off, n, dim, set.norm);
         SSYM_HIP_CHECK(ctx, hipGetLastError());
     } else {
@@ -130,9 +185,9 @@ static int32_t build_derived(ssym_ctx *ctx, SegmentSet &set)
         uint32_t mf = std::max<uint32_t>(set.max_frames, 1);
         FilterShape shape = filter_shape((int)mf);
         set.frames_pad = set.is_source ? (shape.nt ? (uint32_t)shape.rows() : mf) : mf;
-        SSYM_HIP_CHECK(ctx, hipMalloc((void **)&set.len, sizeof(int32_t) * set.n_pad));
+        { int32_t rca = dev_alloc(ctx, (void **)&set.len, sizeof(int32_t) * set.n_pad); if (rca != SSYM_OK) return rca; }
         SSYM_HIP_CHECK(ctx, hipMemsetAsync(set.len, 0, sizeof(int32_t) * set.n_pad, st));
-        SSYM_HIP_CHECK(ctx, hipMalloc((void **)&set.max_sqnorm, sizeof(float) * (set.n_pad + 1)));
+        { int32_t rca = dev_alloc(ctx, (void **)&set.max_sqnorm, sizeof(float) * (set.n_pad + 1)); if (rca != SSYM_OK) return rca; }
         SSYM_HIP_CHECK(ctx, hipMemsetAsync(set.max_sqnorm, 0, sizeof(float) * (set.n_pad + 1), st));
         dim3 grid((mf + 63) / 64, n);
         segment_stats_kernel<<<grid, 64, 0, st>>>(set.raw, set.off, n, dim, set.len,
@@ -148,14 +203,13 @@ static int32_t build_derived(ssym_ctx *ctx, SegmentSet &set)
             m = std::max(m, h[i]);
         set.max_sqnorm_all = (double)m;
         set.max_abs = (double)h[set.n_pad];
-        if (set.rec) {
-            (void)hipFree(set.rec);
-            set.rec = nullptr;
-        }
+        dev_free(ctx, set.rec);
+        set.rec = nullptr;
         set.rec_scale = 0.0;
         set.rec_bytes = 0;
     }
-    SSYM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    if (!ctx->defer_sync)
+        SSYM_HIP_CHECK(ctx, hipStreamSynchronize(st));
     return SSYM_OK;
 }
 
@@ -189,16 +243,17 @@ static int32_t upload_values(ssym_ctx *ctx, SegmentSet &set, size_t dst_val_offs
     if (ctx->dtype == SSYM_DTYPE_F64) {
         SSYM_HIP_CHECK(ctx, hipMemcpyAsync(dst, feats, count_vals * sizeof(double),
                                            on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
-        SSYM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        if (!ctx->defer_sync)      // the caller's buffer is free to go when this returns
+            SSYM_HIP_CHECK(ctx, hipStreamSynchronize(st));
         return SSYM_OK;
     }
     const float *src_dev = (const float *)feats;
     float *tmp = nullptr;
     if (!on_device) {
-        SSYM_HIP_CHECK(ctx, hipMalloc((void **)&tmp, count_vals * sizeof(float)));
+        { int32_t rca = dev_alloc(ctx, (void **)&tmp, count_vals * sizeof(float)); if (rca != SSYM_OK) return rca; }
         hipError_t e = hipMemcpyAsync(tmp, feats, count_vals * sizeof(float), hipMemcpyHostToDevice, st);
         if (e != hipSuccess) {
-            (void)hipFree(tmp);
+            dev_free(ctx, tmp);
             ctx->err = std::string("hipMemcpyAsync: ") + hipGetErrorString(e);
             return SSYM_E_HIP;
         }
@@ -207,10 +262,10 @@ static int32_t upload_values(ssym_ctx *ctx, SegmentSet &set, size_t dst_val_offs
     unsigned blocks = (unsigned)std::min<size_t>((count_vals + 255) / 256, 4096);
     widen_f32_kernel<<<blocks, 256, 0, st>>>(src_dev, dst, count_vals);
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess)
+    if (e == hipSuccess && !ctx->defer_sync)
         e = hipStreamSynchronize(st);
     if (tmp)
-        (void)hipFree(tmp);
+        dev_free(ctx, tmp);
     if (e != hipSuccess) {
         ctx->err = std::string("widen_f32_kernel: ") + hipGetErrorString(e);
         return SSYM_E_HIP;
@@ -243,7 +298,7 @@ int32_t pack_segments(ssym_ctx *ctx, SegmentSet &set, const void *feats, bool fe
         return SSYM_E_INVALID;
     }
     set.raw_capacity_vals = std::max<size_t>(vals, 1);
-    SSYM_HIP_CHECK(ctx, hipMalloc((void **)&set.raw, set.raw_capacity_vals * sizeof(double)));
+    { int32_t rca = dev_alloc(ctx, (void **)&set.raw, set.raw_capacity_vals * sizeof(double)); if (rca != SSYM_OK) return rca; }
     if (vals > 0) {
         size_t esz = ctx->dtype == SSYM_DTYPE_F64 ? sizeof(double) : sizeof(float);
         const char *base = (const char *)feats + (size_t)frame_offsets[0] * dim * esz;
@@ -273,12 +328,11 @@ int32_t append_segments(ssym_ctx *ctx, SegmentSet &set, const void *feats,
     if (old_vals + add_vals > set.raw_capacity_vals) {
         size_t cap = std::max(old_vals + add_vals, set.raw_capacity_vals * 2);
         double *nraw = nullptr;
-        SSYM_HIP_CHECK(ctx, hipMalloc((void **)&nraw, cap * sizeof(double)));
+        { int32_t rca = dev_alloc(ctx, (void **)&nraw, cap * sizeof(double)); if (rca != SSYM_OK) return rca; }
         if (old_vals)
             SSYM_HIP_CHECK(ctx, hipMemcpyAsync(nraw, set.raw, old_vals * sizeof(double),
                                                hipMemcpyDeviceToDevice, ctx->stream));
-        SSYM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        (void)hipFree(set.raw);
+        dev_free(ctx, set.raw);        // stream-ordered: the copy above is queued before any reuse
         set.raw = nraw;
         set.raw_capacity_vals = cap;
     }

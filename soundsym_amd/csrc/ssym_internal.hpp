@@ -5,7 +5,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <map>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "soundsym_amd.h"
@@ -92,10 +94,22 @@ struct ssym_ctx {
     ssym::DeviceBuf part;       // refcos partial argmin
     ssym::DeviceBuf out_idx, out_cost;  // staging for host outputs
     hipEvent_t ev[8]{};
+    // set by ssym_match_batch / ssym_match_one around their internal pack: the call synchronises
+    // once at its end, so the pack stages need not wait for their copies individually
+    bool defer_sync = false;
+    // small-block cache for per-call segment sets (ssym_match_one packs one query per call; going
+    // to the driver for every hipMalloc / hipFree -- the latter synchronises the device -- cost more
+    // than the match itself).  All users run on `stream`, so reuse is stream-ordered.
+    std::unordered_map<void *, size_t> live_blocks;      // pointer -> rounded size
+    std::multimap<size_t, void *> free_blocks;           // rounded size -> cached pointer
+    size_t free_bytes = 0;
 };
 
 struct ssym_dict {
     ssym::SegmentSet set;
+    // refcos self-similarity matrix [n][n] for ssym_chain, valid while selfsim_n == set.n
+    ssym::DeviceBuf selfsim;
+    uint32_t selfsim_n = 0;
 };
 
 struct ssym_queries {
@@ -120,7 +134,11 @@ int32_t pack_segments(ssym_ctx *ctx, SegmentSet &set, const void *feats, bool fe
                       const uint64_t *frame_offsets, uint32_t n, uint32_t dim, bool is_source);
 int32_t append_segments(ssym_ctx *ctx, SegmentSet &set, const void *feats,
                         const uint64_t *frame_offsets, uint32_t n);
-void free_segments(SegmentSet &set);
+void free_segments(ssym_ctx *ctx, SegmentSet &set);
+// cached device blocks (pack.hip): ctx may be NULL for dev_free (falls back to hipFree)
+int32_t dev_alloc(ssym_ctx *ctx, void **p, size_t bytes);
+void dev_free(ssym_ctx *ctx, void *p);
+void dev_cache_release(ssym_ctx *ctx);
 
 // dtw_filter.hip
 bool filter_supported(const ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt);
@@ -155,6 +173,12 @@ int32_t launch_dtw_final_allpairs(ssym_ctx *ctx, uint32_t n_src, uint32_t n_tgt,
 int32_t launch_merge_shards(ssym_ctx *ctx, uint32_t n_shards, uint32_t n_targets,
                             const double *costs, const uint32_t *idx, uint32_t *out_idx,
                             double *out_cost);
+
+// chain.hip
+int32_t launch_chain_argmin(ssym_ctx *ctx, const double *base, size_t row_stride, const uint32_t *row_sel,
+                            uint32_t n, double distance, double init, bool report_value, uint32_t step,
+                            uint32_t *cur, uint32_t *out_idx, double *out_cost);
+int32_t launch_chain_pairs(ssym_ctx *ctx, const uint32_t *cur, uint32_t n, uint2 *pairs, uint32_t *count);
 
 // refcos.hip
 int32_t launch_refcos_sims(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt,

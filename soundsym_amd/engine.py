@@ -204,6 +204,20 @@ class Engine:
         nat.check(rc, self.ctx)
         return int(idx.value), float(cost.value)
 
+    def chain(self, d: _Handle, start_feats, distances) -> Tuple[np.ndarray, np.ndarray]:
+        """ssym_chain: from_distances (src/sound.rs:405-417) without a host round trip per step.
+        Returns (idx [n_steps], cost [n_steps]); idx[i] is the dictionary entry matched at step i."""
+        f = np.ascontiguousarray(start_feats, dtype=self.np_dtype).reshape(-1)
+        if f.size % d.dim:
+            raise ValueError("start is not a whole number of frames")
+        dist = np.ascontiguousarray(distances, dtype=np.float64).reshape(-1)
+        idx = np.zeros(dist.size, dtype=np.uint32)
+        cost = np.zeros(dist.size, dtype=np.float64)
+        rc = nat.lib().ssym_chain(self.ctx, d.ptr, f.ctypes.data, f.size // d.dim, dist.ctypes.data, dist.size,
+                                  idx.ctypes.data, cost.ctypes.data)
+        nat.check(rc, self.ctx)
+        return idx, cost
+
     def pair_matrix(self, d: _Handle, q: _Handle, exact: bool = False) -> np.ndarray:
         out = np.zeros((d.n, q.n), dtype=np.float64)
         nat.check(nat.lib().ssym_pair_matrix(self.ctx, d.ptr, q.ptr, 1 if exact else 0,

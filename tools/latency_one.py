@@ -19,3 +19,27 @@ for metric, dtype in (("refcos", "f64"), ("dtw", "f64")):
     dt = (time.perf_counter() - t0) / len(qs)
     print(f"{metric}: match_one on a 1024-entry dictionary: {dt * 1e6:.0f} us per call; timings {e.timings()['total_ms']:.3f} ms device")
     e.close()
+
+# from_distances: the chain on the device (ssym_chain) against one host call per step
+rng = np.random.default_rng(7)
+for metric, dtype, steps in (("refcos", "f64", 512), ("dtw", "f64", 64)):
+    e = Engine(metric=metric, dtype=dtype)
+    sf, so = pack_segments([s.astype(np.float64) * 0.05 for s in src], 12)
+    d = e.dictionary(sf, so, 12)
+    dist = rng.uniform(0.2, 1.2, size=steps) if metric == "refcos" else rng.uniform(0.0, 5.0, size=steps)
+    start = tgt[0].astype(np.float64).reshape(-1) * 0.05
+    e.chain(d, start, dist[:4])                       # builds the self-similarity matrix (refcos)
+    t0 = time.perf_counter()
+    idx, _ = e.chain(d, start, dist)
+    t_chain = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    cur, loop = start, []
+    for dd in dist:
+        i, _ = e.match_one(d, cur, float(dd))
+        loop.append(i)
+        cur = sf[int(so[i]) * 12:int(so[i + 1]) * 12]
+    t_loop = time.perf_counter() - t0
+    assert loop == list(idx)
+    print(f"{metric}: from_distances, {steps} steps on a 1024-entry dictionary: ssym_chain {t_chain / steps * 1e6:.1f} us/step, "
+          f"match_one loop {t_loop / steps * 1e6:.1f} us/step")
+    e.close()
