@@ -8,10 +8,10 @@ Like the reference example (examples/reconstruction.rs:26-86) it cuts the source
 dictionary of segments, cuts the target into segments, replaces every target segment by its
 nearest dictionary segment (SoundSequence::clone_from_dictionary) and writes the concatenation
 as a 32-bit WAV.  What differs, and why: segmentation is by fixed-length chunks (or by an Audacity
-label file for the target) instead of the GMM / voting-experts partitioner, and features are
-soundsym_amd.features.frame_features instead of vox_box MFCCs -- both are outside the hot path this
-repository covers.  Matching, length fit, concatenation and the 32-bit
-conversion run on the GPU through the C ABI.
+label file for the target) instead of the GMM / voting-experts partitioner (outside the hot path,
+SURVEY.md section 2), and the MFCCs are this repository's own definition (ssym_mfcc; the
+reference's arithmetic is in the un-vendored vox_box crate).  Feature analysis, matching, length
+fit, concatenation and the 32-bit conversion all run on the GPU through the C ABI.
 """
 import argparse
 import os

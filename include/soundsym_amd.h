@@ -225,6 +225,26 @@ SSYM_API int32_t ssym_reconstruct(ssym_ctx *ctx, const ssym_samples *s, const ui
                          const uint64_t *out_offsets, uint32_t n_targets, double *out_samples,
                          int32_t *out_pcm32);
 
+/* Feature front-end, the step before the hot path: what
+ * Sound::from_samples(.., None, ..) computes through analyze_mfccs (src/sound.rs:215-242) --
+ * 1024-sample Hanning windows hopped by 256 (src/lib.rs:24-25), per window `n_coeffs` MFCCs between
+ * f_lo and f_hi Hz (the reference: 12, 100..8000, src/sound.rs:218), frame-major.
+ * PARITY UNPINNED: the reference's arithmetic is in un-vendored crates (vox_box, sample); this is a
+ * self-consistent extractor whose definition is in csrc/mfcc.hip and DESIGN.md.
+ *   samples      n_samples f64 (HOST)
+ *   flags        SSYM_MFCC_PAD_TAIL: n_samples / 256 frames, samples past the end read as 0
+ *                (default: full windows only, (n_samples - 1024) / 256 + 1);
+ *                SSYM_OUT_DEVICE: out_mfccs is a device pointer (feeds ssym_*_create_device)
+ *   out_mfccs    frames * n_coeffs f64, frames as ssym_mfcc_num_frames reports
+ *   out_mean     nullable, n_coeffs f64 (HOST): analyze_mean_mfccs (src/sound.rs:271-286) */
+#define SSYM_MFCC_BIN 1024
+#define SSYM_MFCC_HOP 256
+#define SSYM_MFCC_PAD_TAIL 4u
+SSYM_API int32_t ssym_mfcc_num_frames(uint64_t n_samples, uint32_t flags, uint64_t *out_frames);
+SSYM_API int32_t ssym_mfcc(ssym_ctx *ctx, const double *samples, uint64_t n_samples, double sample_rate,
+                  uint32_t n_coeffs, double f_lo, double f_hi, uint32_t flags, double *out_mfccs,
+                  double *out_mean);
+
 #ifdef __cplusplus
 }
 #endif

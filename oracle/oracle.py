@@ -73,6 +73,11 @@ class Oracle:
         L.ssym_oracle_topk.argtypes = [_f64p, ctypes.c_uint32, ctypes.c_uint32, _f64p, ctypes.c_double,
                                        ctypes.c_double, ctypes.c_uint32, _i64p, _f64p]
         L.ssym_oracle_topk.restype = ctypes.c_int
+        L.ssym_oracle_mfcc_num_frames.argtypes = [ctypes.c_uint64, ctypes.c_int]
+        L.ssym_oracle_mfcc_num_frames.restype = ctypes.c_uint64
+        L.ssym_oracle_mfcc.argtypes = [_f64p, ctypes.c_uint64, ctypes.c_double, ctypes.c_uint32, ctypes.c_double,
+                                       ctypes.c_double, ctypes.c_int, _f64p]
+        L.ssym_oracle_mfcc.restype = ctypes.c_int
         L.ssym_oracle_length_fit.argtypes = [_f64p, ctypes.c_uint64, ctypes.c_uint64, _f64p]
         L.ssym_oracle_reconstruct.restype = None
         L.ssym_oracle_reconstruct.argtypes = [_f64p, _u64p, _i64p, _u64p, ctypes.c_uint32, _f64p]
@@ -232,6 +237,19 @@ class Oracle:
             val.append(v)
             cur = src_flat[int(src_off[i]) * dim:int(src_off[i + 1]) * dim]
         return np.array(idx, dtype=np.int64), np.array(val, dtype=np.float64)
+
+    def mfcc(self, samples, rate: float, ncoeffs: int = 12, f_lo: float = 100.0, f_hi: float = 8000.0,
+             pad_tail: bool = False) -> np.ndarray:
+        """[frames][ncoeffs] MFCCs by the definition in ssym_oracle.c (parity unpinned, row F3)."""
+        x = np.ascontiguousarray(samples, dtype=np.float64).reshape(-1)
+        t = int(self.lib.ssym_oracle_mfcc_num_frames(x.size, int(pad_tail)))
+        out = np.zeros((t, ncoeffs), dtype=np.float64)
+        if t:
+            rc = self.lib.ssym_oracle_mfcc(_ptr(x, _f64p), x.size, float(rate), ncoeffs, float(f_lo), float(f_hi),
+                                           int(pad_tail), _ptr(out, _f64p))
+            if rc != 0:
+                raise MemoryError
+        return out
 
     def max_threads(self) -> int:
         return self.lib.ssym_oracle_max_threads()

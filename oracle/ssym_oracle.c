@@ -331,6 +331,112 @@ SSYM_ORACLE_API int ssym_oracle_topk(const double *values, uint32_t n_src, uint3
     return 0;
 }
 
+/* ---- feature front-end ---------------------------------------------
+ * CPU restatement of soundsym_amd/csrc/mfcc.hip's definition.  PARITY UNPINNED against the
+ * reference: analyze_mfccs (src/sound.rs:215-242) delegates to vox_box's MFCC (git HEAD,
+ * Cargo.toml:9) and sample 0.9.1's Windower, neither of which is under /root/reference, and no
+ * reference test pins a value.  What the reference does fix is followed: 1024-sample Hanning
+ * windows hopped by 256 (src/lib.rs:24-25, src/sound.rs:228-229), 12 coefficients between 100 and
+ * 8000 Hz (src/sound.rs:218), frame-major output (src/sound.rs:236-240).
+ *   T = (n - 1024) / 256 + 1 full windows (pad_tail: n / 256, zeros past the end);
+ *   w[i] = 0.5 - 0.5 cos(2 pi i / 1024); radix-2 DIT FFT; P[k] = re^2 + im^2;
+ *   NF = 2 nc + 2 triangular filters equally spaced in mel = 1127 ln(1 + f / 700) between f_lo and
+ *   min(f_hi, rate / 2); E[m] = sum_k W[m][k] P[k]; L[m] = ln(max(E[m], 1e-30));
+ *   c[j] = sum_m L[m] cos(pi j (m + 1/2) / NF), j = 1..nc. */
+static double ssym_mel_of(double f) { return 1127.0 * log(1.0 + f / 700.0); }
+static double ssym_hz_of(double m) { return 700.0 * (exp(m / 1127.0) - 1.0); }
+
+SSYM_ORACLE_API uint64_t ssym_oracle_mfcc_num_frames(uint64_t n, int pad_tail)
+{
+    if (pad_tail)
+        return n / 256;
+    return n >= 1024 ? (n - 1024) / 256 + 1 : 0;
+}
+
+SSYM_ORACLE_API int ssym_oracle_mfcc(const double *samples, uint64_t n, double rate, uint32_t nc,
+                                     double f_lo, double f_hi, int pad_tail, double *out)
+{
+    enum { BIN = 1024, HOP = 256, SPEC = 513 };
+    const double PI = 3.14159265358979323846;
+    const int nf = 2 * (int)nc + 2;
+    const uint64_t T = ssym_oracle_mfcc_num_frames(n, pad_tail);
+    double *win = (double *)malloc(sizeof(double) * (BIN + BIN + (size_t)nf * SPEC + (size_t)nc * nf + 2 * BIN + nf));
+    if (!win)
+        return -1;
+    double *twr = win + BIN, *twi = twr + BIN / 2, *W = twi + BIN / 2, *D = W + (size_t)nf * SPEC;
+    double *re = D + (size_t)nc * nf, *im = re + BIN, *L = im + BIN;
+    for (int i = 0; i < BIN; ++i)
+        win[i] = 0.5 - 0.5 * cos(2.0 * PI * (double)i / (double)BIN);
+    for (int k = 0; k < BIN / 2; ++k) {
+        twr[k] = cos(-2.0 * PI * (double)k / (double)BIN);
+        twi[k] = sin(-2.0 * PI * (double)k / (double)BIN);
+    }
+    {
+        const double top = f_hi < 0.5 * rate ? f_hi : 0.5 * rate;
+        const double m0 = ssym_mel_of(f_lo), m1 = ssym_mel_of(top);
+        for (int m = 0; m < nf; ++m) {
+            const double h0 = ssym_hz_of(m0 + (m1 - m0) * (double)m / (double)(nf + 1));
+            const double h1 = ssym_hz_of(m0 + (m1 - m0) * (double)(m + 1) / (double)(nf + 1));
+            const double h2 = ssym_hz_of(m0 + (m1 - m0) * (double)(m + 2) / (double)(nf + 1));
+            for (int k = 0; k < SPEC; ++k) {
+                const double f = (double)k * rate / (double)BIN;
+                double w = 0.0;
+                if (f > h0 && f <= h1)
+                    w = (f - h0) / (h1 - h0);
+                else if (f > h1 && f < h2)
+                    w = (h2 - f) / (h2 - h1);
+                W[(size_t)m * SPEC + k] = w;
+            }
+        }
+    }
+    for (uint32_t j = 0; j < nc; ++j)
+        for (int m = 0; m < nf; ++m)
+            D[(size_t)j * nf + m] = cos(PI * (double)(j + 1) * ((double)m + 0.5) / (double)nf);
+
+    for (uint64_t t = 0; t < T; ++t) {
+        for (int i = 0; i < BIN; ++i) {
+            uint32_t r = 0;
+            for (int b = 0; b < 10; ++b)
+                r |= (uint32_t)((i >> b) & 1) << (9 - b);
+            const uint64_t g = t * HOP + (uint64_t)i;
+            re[r] = (g < n ? samples[g] : 0.0) * win[i];
+            im[r] = 0.0;
+        }
+        for (int s = 1; s <= 10; ++s) {
+            const int half = 1 << (s - 1);
+            for (int b = 0; b < BIN / 2; ++b) {
+                const int j = b & (half - 1);
+                const int i0 = ((b >> (s - 1)) << s) + j, i1 = i0 + half;
+                const int k = j << (10 - s);
+                const double tr = twr[k] * re[i1] - twi[k] * im[i1];
+                const double ti = twr[k] * im[i1] + twi[k] * re[i1];
+                const double ar = re[i0], ai = im[i0];
+                re[i1] = ar - tr;
+                im[i1] = ai - ti;
+                re[i0] = ar + tr;
+                im[i0] = ai + ti;
+            }
+        }
+        for (int k = 0; k < SPEC; ++k)
+            re[k] = re[k] * re[k] + im[k] * im[k];
+        for (int m = 0; m < nf; ++m) {
+            double e = 0.0;
+            for (int k = 0; k < SPEC; ++k)
+                if (W[(size_t)m * SPEC + k] != 0.0)
+                    e = e + W[(size_t)m * SPEC + k] * re[k];
+            L[m] = log(e > 1e-30 ? e : 1e-30);
+        }
+        for (uint32_t j = 0; j < nc; ++j) {
+            double c = 0.0;
+            for (int m = 0; m < nf; ++m)
+                c = c + L[m] * D[(size_t)j * nf + m];
+            out[t * nc + j] = c;
+        }
+    }
+    free(win);
+    return 0;
+}
+
 SSYM_ORACLE_API int ssym_oracle_max_threads(void)
 {
 #ifdef _OPENMP

@@ -38,11 +38,12 @@ ABI_SYMBOLS = [
     "ssym_queries_create_device", "ssym_queries_destroy", "ssym_match_queries", "ssym_match_topk",
     "ssym_match_batch",
     "ssym_match_one", "ssym_chain", "ssym_pair_matrix", "ssym_merge_shards", "ssym_samples_create",
-    "ssym_samples_destroy", "ssym_reconstruct",
+    "ssym_samples_destroy", "ssym_reconstruct", "ssym_mfcc_num_frames", "ssym_mfcc",
 ]
 
 
 NO_MATCH = 0xFFFFFFFF      # SSYM_NO_MATCH
+MFCC_PAD_TAIL = 4           # SSYM_MFCC_PAD_TAIL
 TOPK_MAX = 64              # SSYM_TOPK_MAX
 
 
@@ -167,6 +168,10 @@ def lib() -> ctypes.CDLL:
     L.ssym_match_one.argtypes = [vp, vp, vp, u64, f64, vp, vp]
     L.ssym_chain.restype = i32
     L.ssym_chain.argtypes = [vp, vp, vp, u64, vp, u32, vp, vp]
+    L.ssym_mfcc_num_frames.restype = i32
+    L.ssym_mfcc_num_frames.argtypes = [u64, u32, vp]
+    L.ssym_mfcc.restype = i32
+    L.ssym_mfcc.argtypes = [vp, vp, u64, f64, u32, f64, f64, u32, vp, vp]
     L.ssym_pair_matrix.restype = i32
     L.ssym_pair_matrix.argtypes = [vp, vp, vp, i32, vp]
     L.ssym_merge_shards.restype = i32

@@ -10,9 +10,9 @@ Same names, argument meaning and error behaviour as the reference for the hot pa
 
 Every comparison runs on the GPU through the C ABI (`engine.Engine`); this module only keeps the
 containers, does the length fit of src/sound.rs:456-465 on the matched samples, and translates
-errors.  Feature extraction (MFCC analysis, src/sound.rs:215-242) is out of scope: a Sound is
-built from samples plus ready-made features, the `Some(mfccs)` form of Sound::from_samples
-(src/sound.rs:92-94).
+errors.  A Sound is built from samples plus ready-made features (the `Some(mfccs)` form of
+Sound::from_samples, src/sound.rs:92-94) or analysed on the GPU (`None`: `ssym_mfcc`, a
+self-consistent MFCC -- the reference's arithmetic is in un-vendored crates, parity unpinned).
 """
 from __future__ import annotations
 
@@ -56,10 +56,21 @@ class Sound:
 
     @staticmethod
     def from_samples(samples, sample_rate: float, mfccs=None, name: Optional[str] = None,
-                     ncoeffs: int = NCOEFFS) -> "Sound":
-        """Sound::from_samples (src/sound.rs:92).  mfccs=None leaves the features unset: the
-        reference would run its MFCC analysis here, which this package does not restate."""
+                     ncoeffs: int = NCOEFFS, engine: Optional[Engine] = None) -> "Sound":
+        """Sound::from_samples (src/sound.rs:92-107).  mfccs=None runs the MFCC analysis as the
+        reference does (analyze_mfccs, :215-242) -- here on the GPU (`ssym_mfcc`; its arithmetic is
+        this package's own definition, parity unpinned)."""
+        if mfccs is None:
+            e = engine or default_engine()
+            mfccs = e.mfcc(samples, sample_rate, ncoeffs).reshape(-1)
         return Sound(samples, sample_rate, mfccs, name, ncoeffs)
+
+    def mean_mfccs(self) -> np.ndarray:       # src/sound.rs:205, analyze_mean_mfccs :271-286
+        m = self.mfccs().reshape(-1, self.ncoeffs)
+        acc = np.zeros(self.ncoeffs)
+        for row in m:                         # frames in order, like the reference's fold
+            acc = acc + row
+        return acc / m.shape[0] if m.shape[0] else acc * np.nan
 
     def samples(self) -> np.ndarray:          # src/sound.rs:181
         return self._samples
@@ -69,7 +80,7 @@ class Sound:
 
     def mfccs(self) -> np.ndarray:            # src/sound.rs:191
         if self._mfccs is None:
-            raise ValueError("this Sound carries no features (MFCC analysis is out of scope)")
+            raise ValueError("this Sound carries no features (build it with Sound.from_samples(.., None) to analyse)")
         return self._mfccs
 
     def has_mfccs(self) -> bool:

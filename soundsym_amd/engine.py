@@ -224,6 +224,23 @@ class Engine:
                                              out.ctypes.data), self.ctx)
         return out
 
+    # -- feature front-end (F3) --------------------------------------------------------------
+    def mfcc(self, samples, sample_rate: float, ncoeffs: int = 12, f_lo: float = 100.0, f_hi: float = 8000.0,
+             pad_tail: bool = False, want_mean: bool = False):
+        """ssym_mfcc: [frames][ncoeffs] f64 (analyze_mfccs, src/sound.rs:215-242; parity unpinned),
+        optionally with the per-coefficient mean (analyze_mean_mfccs, :271-286)."""
+        x = np.ascontiguousarray(samples, dtype=np.float64).reshape(-1)
+        flags = nat.MFCC_PAD_TAIL if pad_tail else 0
+        t = ctypes.c_uint64(0)
+        nat.check(nat.lib().ssym_mfcc_num_frames(x.size, flags, ctypes.byref(t)), self.ctx)
+        out = np.zeros((int(t.value), ncoeffs), dtype=np.float64)
+        mean = np.zeros(ncoeffs, dtype=np.float64)
+        rc = nat.lib().ssym_mfcc(self.ctx, x.ctypes.data if x.size else None, x.size, float(sample_rate), ncoeffs,
+                                 float(f_lo), float(f_hi), flags, out.ctypes.data if out.size else None,
+                                 mean.ctypes.data if want_mean else None)
+        nat.check(rc, self.ctx)
+        return (out, mean) if want_mean else out
+
     # -- reconstruction tail (F2) ------------------------------------------------------------
     def samples(self, samples, sample_offsets):
         """Make the dictionary sounds' samples resident (ssym_samples_create)."""

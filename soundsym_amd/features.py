@@ -1,32 +1,25 @@
-"""A stand-in frame feature extractor for the plumbing example -- NOT the reference's MFCC.
+"""Frame features for whole sounds: the MFCC front-end of SURVEY.md section 8 row F3.
 
-The reference's features come from `vox_box`'s MFCC (src/sound.rs:215-242), an un-vendored git
-dependency whose arithmetic cannot be pinned here.  The matching path
-only needs *some* deterministic `frames x 12` feature stream with the reference's framing:
-1024-sample Hanning windows hopped by 256 (src/lib.rs:24-25, src/sound.rs:228-229).  This module
-provides log band energies over 12 bands between 100 Hz and 8 kHz.  Host side, numpy only.
+`analyze_mfccs` (src/sound.rs:215-242) in the reference: 1024-sample Hanning windows hopped by 256
+(src/lib.rs:24-25), 12 MFCCs between 100 Hz and 8 kHz per window (src/sound.rs:218).  The
+arithmetic runs on the GPU (`ssym_mfcc`, csrc/mfcc.hip); its definition is this package's own --
+the reference's lives in the un-vendored `vox_box` / `sample` crates, so PARITY IS UNPINNED.
 """
 from __future__ import annotations
 
+from typing import Optional
+
 import numpy as np
 
-from .api import BIN, HOP, NCOEFFS
+from .api import NCOEFFS, default_engine
+from .engine import Engine
 
 
-def frame_features(samples: np.ndarray, sample_rate: float, ncoeffs: int = NCOEFFS) -> np.ndarray:
-    """[n_frames * ncoeffs] f64, frame-major, n_frames = len(samples) // HOP (zero-padded tail)."""
-    x = np.asarray(samples, dtype=np.float64).reshape(-1)
-    n_frames = x.size // HOP
-    if n_frames == 0:
-        return np.zeros(0)
-    pad = np.concatenate([x, np.zeros(BIN)])
-    idx = np.arange(n_frames)[:, None] * HOP + np.arange(BIN)[None, :]
-    win = 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(BIN) / BIN)
-    spec = np.abs(np.fft.rfft(pad[idx] * win, axis=1)) ** 2
-    freqs = np.fft.rfftfreq(BIN, 1.0 / sample_rate)
-    edges = np.geomspace(100.0, min(8000.0, sample_rate / 2 - 1), ncoeffs + 1)
-    feats = np.empty((n_frames, ncoeffs))
-    for k in range(ncoeffs):
-        band = (freqs >= edges[k]) & (freqs < edges[k + 1])
-        feats[:, k] = np.log10(spec[:, band].sum(axis=1) + 1e-12)
-    return feats.reshape(-1)
+def frame_features(samples: np.ndarray, sample_rate: float, ncoeffs: int = NCOEFFS,
+                   engine: Optional[Engine] = None, pad_tail: bool = True) -> np.ndarray:
+    """[n_frames * ncoeffs] f64, frame-major.  pad_tail=True gives len(samples) // 256 frames (the
+    tail windows read zeros past the end), which is what the segment arithmetic of
+    SoundDictionary::add_segments (`seg / HOP * NCOEFFS` values per segment, src/sound.rs:335)
+    expects of a parent sound; pad_tail=False keeps full windows only."""
+    e = engine or default_engine()
+    return e.mfcc(samples, sample_rate, ncoeffs, pad_tail=pad_tail).reshape(-1)

@@ -51,10 +51,19 @@ def test_length_fit_matches_oracle(oracle):
 
 
 def test_sound_without_features_raises():
-    s = api.Sound.from_samples(np.zeros(10), 44100.0, None)
+    s = api.Sound(np.zeros(10), 44100.0, None)
     assert not s.has_mfccs()
     with pytest.raises(ValueError):
         s.mfccs()
+
+
+def test_from_samples_none_needs_the_gpu_and_says_so():
+    # Sound::from_samples(.., None, ..) analyses (src/sound.rs:92-107): here on the GPU only --
+    # without a device the call fails loudly, there is no CPU fallback
+    from soundsym_amd import SsymError
+    with pytest.raises(SsymError) as ei:
+        api.Sound.from_samples(np.zeros(4096), 44100.0, None)
+    assert "no CPU path" in str(ei.value)
 
 
 def test_empty_dictionary_errors_like_the_reference_panics():

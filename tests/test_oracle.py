@@ -156,3 +156,33 @@ def test_topk_first_entry_is_at_distance_and_rows_are_sorted(oracle):
     # fewer candidates than k: the tail is (-1, NaN)
     idx2, key2 = oracle.topk(sims[:2], 4)
     assert (idx2[:, 2:] == -1).all() and np.isnan(key2[:, 2:]).all()
+
+
+def test_mfcc_oracle_against_a_numpy_fft_restatement(oracle):
+    # row F3 (parity unpinned against the reference): the C restatement (own radix-2 FFT, explicit
+    # filter loops) against the same definition written with numpy's FFT and matrix products
+    rng = np.random.default_rng(0xF3)
+    rate, nc = 44100.0, 12
+    x = rng.normal(size=6000) * 0.1 + np.sin(2 * np.pi * 440 * np.arange(6000) / rate)
+    got = oracle.mfcc(x, rate, nc)
+    frames = (x.size - 1024) // 256 + 1
+    win = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(1024) / 1024)
+    fr = np.stack([x[t * 256:t * 256 + 1024] * win for t in range(frames)])
+    power = np.abs(np.fft.rfft(fr, axis=1)) ** 2
+    nf = 2 * nc + 2
+    mel = lambda f: 1127 * np.log(1 + f / 700)          # noqa: E731
+    hz = lambda m: 700 * (np.exp(m / 1127) - 1)         # noqa: E731
+    pts = hz(mel(100.0) + (mel(8000.0) - mel(100.0)) * np.arange(nf + 2) / (nf + 1))
+    f = np.arange(513) * rate / 1024
+    w = np.zeros((nf, 513))
+    for m in range(nf):
+        h0, h1, h2 = pts[m], pts[m + 1], pts[m + 2]
+        up, dn = (f > h0) & (f <= h1), (f > h1) & (f < h2)
+        w[m, up] = (f[up] - h0) / (h1 - h0)
+        w[m, dn] = (h2 - f[dn]) / (h2 - h1)
+    loge = np.log(np.maximum(power @ w.T, 1e-30))
+    dct = np.cos(np.pi * np.arange(1, nc + 1)[:, None] * (np.arange(nf) + 0.5)[None, :] / nf)
+    assert got.shape == (frames, nc)
+    assert np.abs(got - loge @ dct.T).max() < 1e-9
+    assert oracle.mfcc(x[:1023], rate).shape == (0, 12)
+    assert oracle.mfcc(x[:1023], rate, pad_tail=True).shape == (3, 12)
