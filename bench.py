@@ -75,11 +75,61 @@ def cpu_baseline(grid, gpu_idx, budget_s=12.0):
     }
 
 
+def secondary_metrics(device: int, with_cpu: bool) -> dict:
+    """Outside the timed region: the reference's own metric (refcos, SURVEY.md 8(d) "also report")
+    and the neighbouring rows (chain F4, MFCC F3), each one short measurement."""
+    from soundsym_amd import Engine, synth
+    out = {}
+    n, f, dd = 4096, 128, 12
+    g = synth.make_grid(n, n, f, dd, 0x5EED0103)
+    off = np.arange(n + 1, dtype=np.uint64) * f
+    e = Engine(metric="refcos", dtype="f64", device=device)
+    d = e.dictionary(g.sources.astype(np.float64).reshape(-1), off, dd)
+    q = e.queries(g.targets.astype(np.float64).reshape(-1), off, dd)
+    e.match(d, q)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        e.match(d, q)
+    dt = (time.perf_counter() - t0) / 5
+    out["refcos"] = {"value": n * n / dt, "unit": "segment-pairs/s", "ms_per_step": dt * 1e3,
+                     "workload": f"{n}x{n} segments, {f} frames x {dd} dims, f64, reference metric "
+                                 "(cosine_sim + at_distance, bit-exact)"}
+    dist_ = np.linspace(0.2, 1.2, 256)
+    e.chain(d, g.targets[0].astype(np.float64).reshape(-1), dist_[:2])
+    t0 = time.perf_counter()
+    e.chain(d, g.targets[0].astype(np.float64).reshape(-1), dist_)
+    out["chain"] = {"value": (time.perf_counter() - t0) / dist_.size * 1e6, "unit": "us/step",
+                    "workload": f"from_distances, 256 steps on the {n}-entry dictionary (refcos)"}
+    rate = 44100.0
+    x = np.sin(2 * np.pi * 440.0 * np.arange(int(rate * 120)) / rate)
+    e.mfcc(x[:44100], rate)
+    t0 = time.perf_counter()
+    fr = e.mfcc(x, rate).shape[0]
+    dt = time.perf_counter() - t0
+    out["mfcc"] = {"value": fr / dt, "unit": "frames/s", "workload": "120 s of 44.1 kHz audio, host to host"}
+    if with_cpu:
+        import oracle as oracle_pkg
+        o = oracle_pkg.load()
+        k = 192
+        offk = np.arange(k + 1, dtype=np.uint64) * f
+        sf = g.sources[:k].astype(np.float64).reshape(-1)
+        tf = g.targets[:k].astype(np.float64).reshape(-1)
+        t0 = time.perf_counter()
+        o.refcos_match_all(sf, offk, tf, offk, dd)
+        dt = time.perf_counter() - t0
+        out["refcos"]["cpu_baseline"] = {"value": k * k / dt, "unit": "segment-pairs/s", "cores": 1, "kind": "port",
+                                         "sample": f"{k}x{k} sub-grid, single thread as the reference runs it"}
+    e.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the refcos / chain / mfcc measurements reported beside the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--src-per-gpu", type=int, default=SRC_PER_GPU)
     ap.add_argument("--targets", type=int, default=N_TGT)
@@ -240,6 +290,8 @@ def main():
         }
         if n_gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(grid, idx_host)
+        if n_gpus == 1 and not args.no_secondary:
+            line["secondary"] = secondary_metrics(local_rank, not args.no_cpu_baseline)
         print(json.dumps(line), flush=True)
     eng.close()
     if world > 1 or force_dist:
