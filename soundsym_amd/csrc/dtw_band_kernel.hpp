@@ -22,7 +22,10 @@ constexpr int kBandTgtQuantum = 256;   // targets are padded to this (8 groups o
 // WB = waves per workgroup = target groups (of 32) per task; OCC = waves per SIMD the register
 // budget is held to.  Up to 3 tiles of diagonals fit two waves per SIMD; wider bands (r = 32 is
 // 5 tiles: 81 column registers) run one wave per SIMD with the whole 512-register file.
-template <int NTB, int WB, int OCC, bool SQ>
+// LASTN = diagonals of the last tile that get a DP cell: 16, or 1 when 2r+1 = 16(NTB-1) + 1 (every
+// radius that is a multiple of 8, r = 32 included) -- the matrix pipe still produces the whole tile,
+// but the VALU, which sets the pace, skips the 15 cells that lie outside the band.
+template <int NTB, int WB, int OCC, bool SQ, int LASTN>
 __global__ __launch_bounds__(64 * WB, OCC) void dtw_band_kernel(
     const _Float16 *__restrict__ srcRec, const _Float16 *__restrict__ tgtRec,
     const int *__restrict__ srcLen, const int *__restrict__ tgtLen, int srcSlots, int radius,
@@ -30,7 +33,7 @@ __global__ __launch_bounds__(64 * WB, OCC) void dtw_band_kernel(
     float *__restrict__ cmat)
 {
     constexpr int REC = kFilterRecHalfs;
-    constexpr int KB = NTB * 16;           // diagonals held in registers (>= 2r+1)
+    constexpr int KB = (NTB - 1) * 16 + LASTN;   // diagonals held in registers (>= 2r+1)
     const float INF = __builtin_inff();
     extern __shared__ __attribute__((aligned(16))) _Float16 ldsSrc[];   // [2][srcSlots][48]
 
@@ -122,11 +125,11 @@ __global__ __launch_bounds__(64 * WB, OCC) void dtw_band_kernel(
                             }
                         }
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
+                        for (int r = 0; r < (T == NTB - 1 ? LASTN : 16); ++r) {
                             const int k = T * 16 + r;
                             const float x = acc[r];
                             float c = SQ ? __builtin_fabsf(x) : __builtin_amdgcn_sqrtf(__builtin_fabsf(x));
-                            if (T == NTB - 1)
+                            if (T == NTB - 1 && LASTN > 1)
                                 c = (k <= twoR) ? c : INF;       // diagonals beyond the band (wave-uniform)
                             const float m3 = __builtin_fminf(__builtin_fminf(up, L[k]), L[k + 1]);
                             const float cur = c + m3;

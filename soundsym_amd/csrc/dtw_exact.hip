@@ -19,11 +19,14 @@
 
 namespace ssym {
 
+// value of lane - 1 (lane 0 keeps its own): one DPP move per half (wave_shr:1, gfx9 encoding 0x138)
+// instead of a ds_bpermute round trip through the LDS crossbar -- the shuffle sits on the critical
+// path of every anti-diagonal step
 __device__ __forceinline__ double shfl_up1(double v)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __shfl_up(lo, 1);
-    hi = __shfl_up(hi, 1);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
 

@@ -173,7 +173,7 @@ static void launch_one(hipStream_t st, const SegmentSet &src, const SegmentSet &
         (int)tgt.frames_pad, (int)tgt.n_pad, nSrcBlocks, nTasks, outScale, handoff, cmat);
 }
 
-template <int NTB, int WB, int OCC, bool SQ>
+template <int NTB, int WB, int OCC, bool SQ, int LASTN>
 static int32_t launch_band_cfg(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, uint32_t slots,
                                size_t lds, float outScale, float *cmat)
 {
@@ -181,7 +181,7 @@ static int32_t launch_band_cfg(ssym_ctx *ctx, const SegmentSet &src, const Segme
     const int nTasks = ((int)src.n_pad / 2) * nTgtBlocks;
     const int grid = std::max(1, std::min(ctx->num_cus, nTasks));
     const int tasksPerBlock = (nTasks + grid - 1) / grid;
-    auto kern = dtw_band_kernel<NTB, WB, OCC, SQ>;
+    auto kern = dtw_band_kernel<NTB, WB, OCC, SQ, LASTN>;
     if (lds > 64 * 1024)
         SSYM_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     kern<<<dim3(grid), 64 * WB, lds, ctx->stream>>>(
@@ -200,9 +200,13 @@ static int32_t launch_band(ssym_ctx *ctx, const SegmentSet &src, const SegmentSe
                            size_t lds, float outScale, float *cmat)
 {
     static const bool forceOcc1 = getenv("SSYM_BAND_OCC1") != nullptr;
+    // radii that are multiples of 8 end exactly one diagonal into their last tile
+    const bool last1 = 2 * ctx->band + 1 == 16 * (NTB - 1) + 1;
     if (NTB <= 5 && !forceOcc1)
-        return launch_band_cfg<NTB, 8, 2, SQ>(ctx, src, tgt, slots, lds, outScale, cmat);
-    return launch_band_cfg<NTB, 4, 1, SQ>(ctx, src, tgt, slots, lds, outScale, cmat);
+        return last1 ? launch_band_cfg<NTB, 8, 2, SQ, 1>(ctx, src, tgt, slots, lds, outScale, cmat)
+                     : launch_band_cfg<NTB, 8, 2, SQ, 16>(ctx, src, tgt, slots, lds, outScale, cmat);
+    return last1 ? launch_band_cfg<NTB, 4, 1, SQ, 1>(ctx, src, tgt, slots, lds, outScale, cmat)
+                 : launch_band_cfg<NTB, 4, 1, SQ, 16>(ctx, src, tgt, slots, lds, outScale, cmat);
 }
 
 static int32_t launch_dtw_filter_banded(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, float *cmat)
