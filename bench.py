@@ -183,11 +183,13 @@ def main():
     out_idx = torch.empty(m, dtype=torch.int32, device="cuda")
     out_cost = torch.empty(m, dtype=torch.float64, device="cuda")
 
+    bounds = torch.empty(m, dtype=torch.float64, device="cuda")
+
     def step():
-        eng.match(d, q, index_base=lo, out_idx=out_idx, out_cost=out_cost)
         if world > 1 or force_dist:
-            costs, idxs = sharding.gather_candidates(out_cost, out_idx)
-            return sharding.merge_shards(eng, costs, idxs)
+            # filter -> all-reduce(MIN) of the per-target bounds -> select / re-score -> all-gather + merge
+            return sharding.match_sharded(eng, d, q, lo, out_idx, out_cost, bounds)
+        eng.match(d, q, index_base=lo, out_idx=out_idx, out_cost=out_cost)
         return out_idx, out_cost
 
     def fence():

@@ -197,6 +197,25 @@ SSYM_API int32_t ssym_chain(ssym_ctx *ctx, ssym_dict *dict, const void *start_fe
 SSYM_API int32_t ssym_pair_matrix(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queries *q,
                          int32_t exact, double *out_matrix);
 
+/* Source-sharded multi-GPU, dtw metric: the one real exchange the path has.  Each rank's filter gives,
+ * per target, an upper bound on the best key in ITS shard; a rank whose shard does not hold a
+ * target's neighbour would otherwise re-score ~10^2 of its own pairs per target for nothing.
+ *   ssym_match_begin   runs the filter and writes the per-target bound to bounds_dev (n_targets f64,
+ *                      DEVICE memory of the caller, e.g. a torch tensor); the stream is synchronised
+ *   (caller)           all-reduce(MIN) of bounds_dev over the ranks (RCCL; n_targets * 8 bytes)
+ *   ssym_match_finish  selects candidates against the reduced bounds, re-scores them exactly and
+ *                      writes what ssym_match_queries would (index 0 + base / +inf for a target
+ *                      none of whose pairs in this shard can win -- ssym_merge_shards then takes
+ *                      another shard's entry)
+ * dict / q / distance must stay alive between the two calls; flags as for ssym_match_queries.
+ * Where the filter does not apply (refcos, shapes outside its limits) begin writes +inf and finish
+ * is a plain ssym_match_queries, so callers need no second code path.  With one rank, or without
+ * the all-reduce, the pair is equivalent to ssym_match_queries. */
+SSYM_API int32_t ssym_match_begin(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queries *q,
+                         const double *distance, uint32_t index_base, double *bounds_dev);
+SSYM_API int32_t ssym_match_finish(ssym_ctx *ctx, const double *bounds_dev, uint32_t *out_idx,
+                          double *out_cost, uint32_t flags);
+
 /* Source-sharded multi-GPU: after an all-gather of every shard's (cost, global index) per target
  * (n_shards x n_targets each, shard-major, DEVICE memory), pick per target the shard entry with
  * the smallest cost, lowest global index on equal cost -- the same first-minimum rule as

@@ -35,7 +35,8 @@ ABI_SYMBOLS = [
     "ssym_abi_version", "ssym_ctx_create", "ssym_ctx_destroy", "ssym_last_error",
     "ssym_ctx_synchronize", "ssym_get_timings", "ssym_dict_create", "ssym_dict_create_device",
     "ssym_dict_append", "ssym_dict_size", "ssym_dict_destroy", "ssym_queries_create",
-    "ssym_queries_create_device", "ssym_queries_destroy", "ssym_match_queries", "ssym_match_topk",
+    "ssym_queries_create_device", "ssym_queries_destroy", "ssym_match_queries", "ssym_match_begin",
+    "ssym_match_finish", "ssym_match_topk",
     "ssym_match_batch",
     "ssym_match_one", "ssym_chain", "ssym_pair_matrix", "ssym_merge_shards", "ssym_samples_create",
     "ssym_samples_destroy", "ssym_reconstruct", "ssym_mfcc_num_frames", "ssym_mfcc",
@@ -160,6 +161,10 @@ def lib() -> ctypes.CDLL:
     L.ssym_queries_destroy.argtypes = [vp, vp]
     L.ssym_match_queries.restype = i32
     L.ssym_match_queries.argtypes = [vp, vp, vp, vp, u32, vp, vp, u32]
+    L.ssym_match_begin.restype = i32
+    L.ssym_match_begin.argtypes = [vp, vp, vp, vp, u32, vp]
+    L.ssym_match_finish.restype = i32
+    L.ssym_match_finish.argtypes = [vp, vp, vp, vp, u32]
     L.ssym_match_topk.restype = i32
     L.ssym_match_topk.argtypes = [vp, vp, vp, vp, u32, u32, vp, vp, u32]
     L.ssym_match_batch.restype = i32

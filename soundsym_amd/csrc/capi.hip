@@ -284,10 +284,13 @@ static int32_t check_match_args(ssym_ctx *ctx, const ssym_dict *dict, const ssym
 
 }  // extern "C"
 
-// k_top = 1: ssym_match_queries (outputs [M]); k_top > 1: ssym_match_topk (outputs [M][k_top])
+// k_top = 1: ssym_match_queries (outputs [M]); k_top > 1: ssym_match_topk (outputs [M][k_top]).
+// phase 0: the whole match.  Phases 1 / 2 are ssym_match_begin / ssym_match_finish: phase 1 stops
+// after the filter and the per-target threshold (copied to bounds_dev), phase 2 takes the threshold
+// back from bounds_dev (after the ranks' all-reduce) and runs selection, re-scoring and the fold.
 static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queries *q,
                           const double *distance, uint32_t index_base, uint32_t k_top, uint32_t *out_idx,
-                          double *out_cost, uint32_t flags)
+                          double *out_cost, uint32_t flags, int phase = 0, double *bounds_dev = nullptr)
 {
     int32_t rc = check_match_args(ctx, dict, q);
     if (rc != SSYM_OK)
@@ -301,7 +304,7 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
         ctx->timings = tm;
         return SSYM_OK;
     }
-    if (!out_idx) {
+    if (!out_idx && phase != 1) {
         ctx->err = "out_idx is NULL";
         return SSYM_E_INVALID;
     }
@@ -311,7 +314,9 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
 
     // per-target distance (morph_to, src/sound.rs:440-446)
     const double *distDev = nullptr;
-    if (distance) {
+    if (phase == 2) {
+        distDev = ctx->pending.has_dist ? (const double *)ctx->dist.ptr : nullptr;   // uploaded by phase 1
+    } else if (distance) {
         rc = ensure(ctx, ctx->dist, sizeof(double) * M);
         if (rc != SSYM_OK)
             return rc;
@@ -356,12 +361,32 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
             if (rc != SSYM_OK)
                 return rc;
             float *cmat = (float *)ctx->cmat.ptr;
-            SSYM_HIP_CHECK(ctx, hipEventRecord(ev[0], st));
-            rc = launch_dtw_filter(ctx, src, tgt, cmat);
-            if (rc != SSYM_OK)
-                return rc;
-            SSYM_HIP_CHECK(ctx, hipEventRecord(ev[1], st));
+            if (phase != 2) {
+                SSYM_HIP_CHECK(ctx, hipEventRecord(ev[0], st));
+                rc = launch_dtw_filter(ctx, src, tgt, cmat);
+                if (rc != SSYM_OK)
+                    return rc;
+                SSYM_HIP_CHECK(ctx, hipEventRecord(ev[1], st));
+                rc = launch_dtw_bounds(ctx, src, tgt, cmat, distDev, k_top);
+                if (rc != SSYM_OK)
+                    return rc;
+            }
             tm.main_launches = 1;
+            if (phase == 1) {
+                // hand the threshold out: non-negative doubles (or +inf), bit for bit what stage 1 uses
+                SSYM_HIP_CHECK(ctx, hipMemcpyAsync(bounds_dev, ctx->tmin.ptr, sizeof(double) * M,
+                                                   hipMemcpyDeviceToDevice, st));
+                SSYM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+                ctx->pending.main_ms = ev_ms(ev[0], ev[1]);
+                tm.main_ms = ctx->pending.main_ms;
+                ctx->timings = tm;
+                return SSYM_OK;
+            }
+            if (phase == 2) {
+                SSYM_HIP_CHECK(ctx, hipMemcpyAsync(ctx->tmin.ptr, bounds_dev, sizeof(double) * M,
+                                                   hipMemcpyDeviceToDevice, st));
+                SSYM_HIP_CHECK(ctx, hipEventRecord(ev[0], st));
+            }
             // list 1 (worst-case margin) is a few pairs per target when near-duplicates exist and
             // ~10^2 when they do not; on overflow stage 1 reports the size it wanted, the later
             // stages see the flag and do nothing, and the selection is redone with that room
@@ -371,7 +396,7 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
             float sel_ms = 0.f, ref_ms = 0.f, red_ms = 0.f;
             for (int attempt = 0; attempt < 2; ++attempt) {
                 SSYM_HIP_CHECK(ctx, hipEventRecord(ev[2], st));
-                rc = launch_dtw_select(ctx, src, tgt, cmat, distDev, (uint32_t)cap, k_top);   // stage 1
+                rc = launch_dtw_select(ctx, src, tgt, cmat, distDev, (uint32_t)cap);          // stage 1
                 if (rc != SSYM_OK)
                     return rc;
                 uint32_t *hdr1 = (uint32_t *)ctx->cand.ptr;
@@ -420,11 +445,11 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
                     return SSYM_E_UNSUPPORTED;
                 }
             }
-            tm.main_ms = ev_ms(ev[0], ev[1]);
+            tm.main_ms = phase == 2 ? ctx->pending.main_ms : ev_ms(ev[0], ev[1]);
             tm.select_ms = sel_ms;
             tm.refine_ms = ref_ms;
             tm.reduce_ms = red_ms;
-            tm.total_ms = ev_ms(ev[0], ev[5]);
+            tm.total_ms = ev_ms(ev[0], ev[5]) + (phase == 2 ? ctx->pending.main_ms : 0.f);
         } else {
             rc = ensure(ctx, ctx->cmat, sizeof(double) * (size_t)N * M);
             if (rc != SSYM_OK)
@@ -484,6 +509,65 @@ int32_t ssym_match_topk(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queries
         return SSYM_E_INVALID;
     }
     return match_impl(ctx, dict, q, distance, index_base, k, out_idx, out_cost, flags);
+}
+
+// Two-phase match for source-sharded runs (see the header).  A tiny kernel-free helper fills the
+// bounds with +inf when the filter does not apply; the all-reduce then changes nothing.
+int32_t ssym_match_begin(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queries *q, const double *distance,
+                         uint32_t index_base, double *bounds_dev)
+{
+    int32_t rc = check_match_args(ctx, dict, q);
+    if (rc != SSYM_OK)
+        return rc;
+    if (!bounds_dev) {
+        ctx->err = "ssym_match_begin: bounds_dev is NULL";
+        return SSYM_E_INVALID;
+    }
+    ssym_ctx::Pending &pd = ctx->pending;
+    pd = ssym_ctx::Pending{};
+    pd.dict = dict;
+    pd.q = q;
+    pd.index_base = index_base;
+    pd.has_dist = distance != nullptr;
+    const uint32_t M = q->set.n;
+    if (distance)
+        pd.dist_host.assign(distance, distance + M);
+    pd.filter = ctx->metric == SSYM_METRIC_DTW && M > 0 && filter_supported(ctx, dict->set, q->set);
+    if (pd.filter) {
+        rc = match_impl(ctx, dict, q, distance, index_base, 1, nullptr, nullptr, 0, 1, bounds_dev);
+        if (rc != SSYM_OK)
+            return rc;
+    } else if (M > 0) {
+        SSYM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+        std::vector<double> inf(M, (double)INFINITY);
+        SSYM_HIP_CHECK(ctx, hipMemcpyAsync(bounds_dev, inf.data(), sizeof(double) * M, hipMemcpyHostToDevice,
+                                           ctx->stream));
+        SSYM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    pd.valid = true;
+    return SSYM_OK;
+}
+
+int32_t ssym_match_finish(ssym_ctx *ctx, const double *bounds_dev, uint32_t *out_idx, double *out_cost,
+                          uint32_t flags)
+{
+    if (!ctx)
+        return SSYM_E_INVALID;
+    ssym_ctx::Pending &pd = ctx->pending;
+    if (!pd.valid) {
+        ctx->err = "ssym_match_finish without ssym_match_begin";
+        return SSYM_E_INVALID;
+    }
+    pd.valid = false;
+    if (!bounds_dev) {
+        ctx->err = "ssym_match_finish: bounds_dev is NULL";
+        return SSYM_E_INVALID;
+    }
+    const double *dist = pd.has_dist ? pd.dist_host.data() : nullptr;
+    if (!pd.filter)
+        return match_impl(ctx, pd.dict, pd.q, dist, pd.index_base, 1, out_idx, out_cost, flags);
+    return match_impl(ctx, pd.dict, pd.q, dist, pd.index_base, 1, out_idx, out_cost, flags, 2,
+                      const_cast<double *>(bounds_dev));
 }
 
 int32_t ssym_match_batch(ssym_ctx *ctx, const ssym_dict *dict, const void *tgt_feats,

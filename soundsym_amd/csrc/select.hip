@@ -255,7 +255,8 @@ __global__ void dtw_stage2_keep_kernel(const uint32_t *__restrict__ hdr1, const 
                                        uint32_t mPad, const double *__restrict__ dist, const int *__restrict__ srcLen,
                                        const float *__restrict__ srcMaxSq, const int *__restrict__ tgtLen,
                                        const float *__restrict__ tgtMaxSq, MarginParams mp,
-                                       const unsigned long long *__restrict__ ub, uint32_t *__restrict__ hdr2,
+                                       const unsigned long long *__restrict__ ub,
+                                       const unsigned long long *__restrict__ ub1, uint32_t *__restrict__ hdr2,
                                        uint2 *__restrict__ pairs2)
 {
     const uint32_t n = hdr1[1] ? 0u : min(hdr1[0], cap);     // overflowed list 1: the host redoes stage 1
@@ -264,7 +265,10 @@ __global__ void dtw_stage2_keep_kernel(const uint32_t *__restrict__ hdr1, const 
         double klo, khi;
         dtw_key_interval(mp, (double)cmat[(size_t)p.x * mPad + p.y], (double)xmin[k], (double)srcMaxSq[p.x],
                          (double)tgtMaxSq[p.y], srcLen[p.x], tgtLen[p.y], dist ? dist[p.y] : 0.0, klo, khi);
-        if (klo <= __longlong_as_double((long long)ub[p.y]))
+        // ub1 = the stage-1 threshold: never above ub on one GPU, but in a source-sharded run it is
+        // the minimum over ALL ranks (ssym_match_begin / _finish) and may undercut this shard's best
+        const double thr = fmin(__longlong_as_double((long long)ub[p.y]), __longlong_as_double((long long)ub1[p.y]));
+        if (klo <= thr)
             pairs2[atomicAdd(&hdr2[0], 1u)] = p;     // list 2 has list 1's capacity: cannot overflow
     }
 }
@@ -561,7 +565,11 @@ int32_t launch_dtw_select2(ssym_ctx *ctx, const SegmentSet &src, const SegmentSe
     int32_t rc = ensure(ctx, ctx->cand2, sizeof(uint32_t) * 2 + sizeof(uint2) * (size_t)cap);
     if (rc != SSYM_OK)
         return rc;
-    unsigned long long *ub = (unsigned long long *)ctx->tmin.ptr;
+    rc = ensure(ctx, ctx->tmin2, sizeof(unsigned long long) * tgt.n);
+    if (rc != SSYM_OK)
+        return rc;
+    unsigned long long *ub = (unsigned long long *)ctx->tmin2.ptr;
+    const unsigned long long *ub1 = (const unsigned long long *)ctx->tmin.ptr;     // stage-1 threshold
     const uint32_t *hdr1 = (const uint32_t *)ctx->cand.ptr;
     const uint2 *pairs1 = (const uint2 *)(hdr1 + 2);
     uint32_t *hdr2 = (uint32_t *)ctx->cand2.ptr;
@@ -587,37 +595,23 @@ int32_t launch_dtw_select2(ssym_ctx *ctx, const SegmentSet &src, const SegmentSe
         }
     }
     dtw_stage2_keep_kernel<<<blocks, 256, 0, st>>>(hdr1, pairs1, xmin, cap, cmat, tgt.n_pad, dist_dev, src.len,
-                                                   src.max_sqnorm, tgt.len, tgt.max_sqnorm, mp, ub, hdr2, pairs2);
+                                                   src.max_sqnorm, tgt.len, tgt.max_sqnorm, mp, ub, ub1, hdr2, pairs2);
     SSYM_HIP_CHECK(ctx, hipGetLastError());
     return SSYM_OK;
 }
 
-int32_t launch_dtw_select(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt,
-                          const float *cmat, const double *dist_dev, uint32_t cap, uint32_t k_top)
+// stage-1 threshold per target -> ctx->tmin: the smallest (k-th smallest distinct) worst-case upper key bound
+int32_t launch_dtw_bounds(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, const float *cmat,
+                          const double *dist_dev, uint32_t k_top)
 {
     hipStream_t st = ctx->stream;
     const MarginParams mp = margin_params(ctx, src);
     int32_t rc = ensure(ctx, ctx->tmin, sizeof(unsigned long long) * tgt.n);
     if (rc != SSYM_OK)
         return rc;
-    rc = ensure(ctx, ctx->cand, sizeof(uint32_t) * 2 + sizeof(uint2) * (size_t)cap);
-    if (rc != SSYM_OK)
-        return rc;
     unsigned long long *ub = (unsigned long long *)ctx->tmin.ptr;
-    uint32_t *hdr = (uint32_t *)ctx->cand.ptr;
-    uint2 *pairs = (uint2 *)(hdr + 2);
-    const unsigned long long infBits = kInfBits;
     const uint32_t nChunks = (src.n + kSelChunk - 1) / kSelChunk;
-    rc = ensure(ctx, ctx->selmask, sizeof(unsigned long long) * (size_t)nChunks * tgt.n);
-    if (rc != SSYM_OK)
-        return rc;
-    rc = ensure(ctx, ctx->selcnt, sizeof(uint32_t) * 2 * (size_t)tgt.n);
-    if (rc != SSYM_OK)
-        return rc;
-    unsigned long long *mask = (unsigned long long *)ctx->selmask.ptr;
-    uint32_t *cnt = (uint32_t *)ctx->selcnt.ptr, *fill = cnt + tgt.n;
-    fill_u64_kernel<<<(tgt.n + 255) / 256, 256, 0, st>>>(ub, infBits, tgt.n);
-    SSYM_HIP_CHECK(ctx, hipMemsetAsync(cnt, 0, sizeof(uint32_t) * 2 * (size_t)tgt.n, st));
+    fill_u64_kernel<<<(tgt.n + 255) / 256, 256, 0, st>>>(ub, kInfBits, tgt.n);
     dim3 grid((tgt.n + 255) / 256, nChunks);
     if (k_top <= 1) {
         dtw_colmin_kernel<<<grid, 256, 0, st>>>(cmat, src.n, tgt.n, tgt.n_pad, dist_dev, src.len,
@@ -634,6 +628,33 @@ int32_t launch_dtw_select(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
             topk_advance_kernel<<<(tgt.n + 255) / 256, 256, 0, st>>>(ub, prev, tgt.n, (int)r, r + 1 == k_top);
         }
     }
+    SSYM_HIP_CHECK(ctx, hipGetLastError());
+    return SSYM_OK;
+}
+
+// stage 1: every pair whose worst-case lower key bound does not exceed ctx->tmin[target] -> list 1
+int32_t launch_dtw_select(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt,
+                          const float *cmat, const double *dist_dev, uint32_t cap)
+{
+    hipStream_t st = ctx->stream;
+    const MarginParams mp = margin_params(ctx, src);
+    int32_t rc = ensure(ctx, ctx->cand, sizeof(uint32_t) * 2 + sizeof(uint2) * (size_t)cap);
+    if (rc != SSYM_OK)
+        return rc;
+    const unsigned long long *ub = (const unsigned long long *)ctx->tmin.ptr;
+    uint32_t *hdr = (uint32_t *)ctx->cand.ptr;
+    uint2 *pairs = (uint2 *)(hdr + 2);
+    const uint32_t nChunks = (src.n + kSelChunk - 1) / kSelChunk;
+    rc = ensure(ctx, ctx->selmask, sizeof(unsigned long long) * (size_t)nChunks * tgt.n);
+    if (rc != SSYM_OK)
+        return rc;
+    rc = ensure(ctx, ctx->selcnt, sizeof(uint32_t) * 2 * (size_t)tgt.n);
+    if (rc != SSYM_OK)
+        return rc;
+    unsigned long long *mask = (unsigned long long *)ctx->selmask.ptr;
+    uint32_t *cnt = (uint32_t *)ctx->selcnt.ptr, *fill = cnt + tgt.n;
+    SSYM_HIP_CHECK(ctx, hipMemsetAsync(cnt, 0, sizeof(uint32_t) * 2 * (size_t)tgt.n, st));
+    dim3 grid((tgt.n + 255) / 256, nChunks);
     dtw_mark_kernel<<<grid, 256, 0, st>>>(cmat, src.n, tgt.n, tgt.n_pad, dist_dev, src.len,
                                           src.max_sqnorm, tgt.len, tgt.max_sqnorm, mp, ub, mask, cnt);
     dtw_scan_kernel<<<1, 1024, 0, st>>>(cnt, tgt.n, cap, hdr);

@@ -81,7 +81,8 @@ struct ssym_ctx {
     // scratch (grown on demand, reused across calls)
     ssym::DeviceBuf handoff;    // dtw filter: per-wave row hand-off between row-block passes
     ssym::DeviceBuf cmat;       // dtw filter costs f32 [n_pad][m_pad]  /  refcos sims f64
-    ssym::DeviceBuf tmin;       // per-target min key bits
+    ssym::DeviceBuf tmin;       // per-target stage-1 threshold (smallest worst-case upper key bound, f64 bits)
+    ssym::DeviceBuf tmin2;      // per-target stage-2 threshold (per-pair certificates)
     ssym::DeviceBuf cand;       // candidate pairs (uint2) + counter + overflow flag (list 1)
     ssym::DeviceBuf selmask;    // stage-1 hit masks, one u64 per (64-source chunk, target)
     ssym::DeviceBuf selcnt;     // stage-1 per-target counts / segment starts / fill cursors
@@ -97,6 +98,15 @@ struct ssym_ctx {
     // set by ssym_match_batch / ssym_match_one around their internal pack: the call synchronises
     // once at its end, so the pack stages need not wait for their copies individually
     bool defer_sync = false;
+    // ssym_match_begin .. ssym_match_finish (two-phase match of a source-sharded run)
+    struct Pending {
+        bool valid = false, filter = false, has_dist = false;
+        const ssym_dict *dict = nullptr;
+        const ssym_queries *q = nullptr;
+        uint32_t index_base = 0;
+        std::vector<double> dist_host;
+        float main_ms = 0.f;
+    } pending;
     // small-block cache for per-call segment sets (ssym_match_one packs one query per call; going
     // to the driver for every hipMalloc / hipFree -- the latter synchronises the device -- cost more
     // than the match itself).  All users run on `stream`, so reuse is stream-ordered.
@@ -158,8 +168,10 @@ int32_t launch_dtw_exact(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet 
 // select.hip.  k_top = 1: the reference's first-minimum fold; k_top > 1: ssym_match_topk, outputs
 // [n_tgt][k_top] (rounds of the same fold, each above the previous round's (key, index))
 // stage 1: worst-case margin over the whole filter matrix -> ctx->cand (list 1)
+int32_t launch_dtw_bounds(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, const float *cmat,
+                          const double *dist_dev, uint32_t k_top);      // threshold per target -> ctx->tmin
 int32_t launch_dtw_select(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt,
-                          const float *cmat, const double *dist_dev, uint32_t cap, uint32_t k_top);
+                          const float *cmat, const double *dist_dev, uint32_t cap);
 // stage 2: per-pair intervals from the certificates of list 1 -> ctx->cand2 (list 2, same capacity)
 int32_t launch_dtw_select2(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, const float *cmat,
                            const float *xmin, const double *dist_dev, uint32_t cap, uint32_t k_top);

@@ -159,6 +159,24 @@ class Engine:
         nat.check(rc, self.ctx)
         return idx, cost
 
+    def match_begin(self, d: _Handle, q: _Handle, bounds, distance=None, index_base: int = 0) -> None:
+        """ssym_match_begin: filter + per-target bound into `bounds` (torch CUDA float64 [m])."""
+        dist_p = None
+        if distance is not None:
+            dist = np.ascontiguousarray(distance, dtype=np.float64)
+            if dist.size != q.n:
+                raise ValueError("distance must have one entry per target")
+            dist_p = dist.ctypes.data
+        nat.check(nat.lib().ssym_match_begin(self.ctx, d.ptr, q.ptr, dist_p, index_base, bounds.data_ptr()),
+                  self.ctx)
+
+    def match_finish(self, bounds, out_idx, out_cost):
+        """ssym_match_finish with device outputs (torch CUDA tensors)."""
+        nat.check(nat.lib().ssym_match_finish(self.ctx, bounds.data_ptr(), out_idx.data_ptr(),
+                                              out_cost.data_ptr() if out_cost is not None else None,
+                                              nat.OUT_DEVICE), self.ctx)
+        return out_idx, out_cost
+
     def match_topk(self, d: _Handle, q: _Handle, k: int, distance=None, index_base: int = 0,
                    force_exact: bool = False) -> Tuple[np.ndarray, np.ndarray]:
         """ssym_match_topk: (idx [m][k] uint32, cost [m][k] f64); rows are ordered by

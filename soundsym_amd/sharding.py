@@ -5,7 +5,9 @@ per target its best (cost, global index).  One all-gather of M x (8 + 4) bytes p
 xGMI when the tensors are on GPUs; gloo in the CPU rehearsal tests) gives every rank the G x M
 candidates; the final per-target pick -- smallest cost, lowest global index on equal cost, i.e.
 the reference's first-minimum rule (src/sound.rs:361-367) since shards are ordered by index --
-is the HIP kernel behind ssym_merge_shards.
+is the HIP kernel behind ssym_merge_shards.  Before that, one all-reduce(MIN) of M x 8 bytes lets the
+ranks agree on each target's upper bound (ssym_match_begin / ssym_match_finish), so that a rank
+whose shard does not hold a target's neighbour re-scores nothing for it.
 
 This module only moves bytes and computes ranges; it contains no arithmetic of the path and no
 CPU substitute for the merge kernel.
@@ -52,6 +54,36 @@ def gather_candidates(cost, idx, group=None):
     if via_host:
         costs, idxs = costs.to(dev), idxs.to(dev)
     return costs.view(world, m), idxs.view(world, m)
+
+
+def reduce_bounds(bounds, group=None):
+    """all_reduce(MIN) of the per-target bounds of ssym_match_begin, in place (M x 8 bytes; RCCL
+    over xGMI on GPUs).  No process group: nothing to do."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return bounds
+    if dist.get_backend(group) == "gloo" and bounds.is_cuda:
+        host = bounds.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.MIN, group=group)
+        bounds.copy_(host)
+    else:
+        dist.all_reduce(bounds, op=dist.ReduceOp.MIN, group=group)
+    return bounds
+
+
+def match_sharded(engine, d, q, index_base, out_idx, out_cost, bounds, group=None):
+    """One rank's part of a source-sharded match: filter, agree on the per-target bound with the
+    other ranks, select / re-score against it, gather every rank's winners and merge them.
+    All tensors are CUDA tensors on this rank's GPU; returns (idx [M], cost [M])."""
+    import torch
+
+    engine.match_begin(d, q, bounds, index_base=index_base)
+    reduce_bounds(bounds, group)
+    torch.cuda.current_stream().synchronize()      # the library runs on its own stream
+    engine.match_finish(bounds, out_idx, out_cost)
+    costs, idxs = gather_candidates(out_cost, out_idx, group)
+    return merge_shards(engine, costs, idxs)
 
 
 def merge_shards(engine, costs, idx):
