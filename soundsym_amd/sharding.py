@@ -61,7 +61,7 @@ def reduce_bounds(bounds, group=None):
     over xGMI on GPUs).  No process group: nothing to do."""
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return bounds
     if dist.get_backend(group) == "gloo" and bounds.is_cuda:
         host = bounds.cpu()
