@@ -100,12 +100,26 @@ class Sound {
         s.name = std::move(name);
         return s;
     }
+    // The `None` form of from_samples (src/sound.rs:97-101): run the MFCC analysis (analyze_mfccs,
+    // :215-242) -- on the GPU, ssym_mfcc; its arithmetic is this library's own definition (parity
+    // with the un-vendored vox_box MFCC is unpinned).
+    template <class Ctx>
+    static Sound from_samples(Ctx &ctx, std::vector<double> samples, double sample_rate,
+                              std::optional<std::string> name = std::nullopt)
+    {
+        uint64_t frames = 0;
+        ssym_mfcc_num_frames(samples.size(), 0, &frames);
+        std::vector<double> m(frames * NCOEFFS);
+        ctx.check(ssym_mfcc(ctx.get(), samples.data(), samples.size(), sample_rate, (uint32_t)NCOEFFS, 100.0,
+                            8000.0, 0, m.data(), nullptr));
+        return from_samples(std::move(samples), sample_rate, std::move(m), std::move(name));
+    }
     const std::vector<double> &samples() const { return samples_; }   // :181
     double sample_rate() const { return sample_rate_; }                // :185
     const std::vector<double> &mfccs() const                           // :191
     {
         if (!has_mfccs_)
-            throw Error(SSYM_E_INVALID, "this Sound carries no features (MFCC analysis is out of scope)");
+            throw Error(SSYM_E_INVALID, "this Sound carries no features (use the from_samples overload that analyses)");
         return mfccs_;
     }
     bool has_mfccs() const { return has_mfccs_; }
@@ -198,6 +212,42 @@ class SoundDictionary {
         return idx;
     }
 
+    // the k best sounds per target, best first (ssym_match_topk; the crate has no counterpart:
+    // at_distance keeps only the first minimum, :361-367)
+    std::vector<std::vector<ArcSound>> candidates(const std::vector<ArcSound> &targets, uint32_t k,
+                                                  const double *distances = nullptr) const
+    {
+        if (sounds.empty())
+            throw EmptyDictionary();
+        std::vector<double> flat;
+        std::vector<uint64_t> off;
+        pack_features(targets, flat, off);
+        ssym_queries *q = nullptr;
+        ctx_->check(ssym_queries_create(ctx_->get(), flat.data(), off.data(), (uint32_t)targets.size(),
+                                        (uint32_t)NCOEFFS, &q));
+        std::vector<uint32_t> idx(targets.size() * k);
+        int32_t rc = ssym_match_topk(ctx_->get(), resident(), q, distances, k, 0, idx.data(), nullptr, 0);
+        ssym_queries_destroy(ctx_->get(), q);
+        ctx_->check(rc);
+        std::vector<std::vector<ArcSound>> out(targets.size());
+        for (std::size_t t = 0; t < targets.size(); ++t)
+            for (uint32_t r = 0; r < k; ++r)
+                if (idx[t * k + r] != SSYM_NO_MATCH)
+                    out[t].push_back(sounds[idx[t * k + r]]);
+        return out;
+    }
+    // from_distances' chain of at_distance calls, on the device in one call (ssym_chain)
+    std::vector<uint32_t> chain_indices(const Sound &start, const std::vector<double> &distances) const
+    {
+        if (sounds.empty())
+            throw EmptyDictionary();
+        std::vector<uint32_t> idx(distances.size());
+        ctx_->check(ssym_chain(ctx_->get(), const_cast<ssym_dict *>(resident()), start.mfccs().data(),
+                               start.num_frames(), distances.data(), (uint32_t)distances.size(), idx.data(),
+                               nullptr));
+        return idx;
+    }
+
   private:
     // the dictionary's features are packed once per content change, not per query
     const ssym_dict *resident() const
@@ -234,13 +284,15 @@ class SoundSequence {
     }
     const std::vector<ArcSound> &sounds() const { return sounds_; }   // :432
 
-    // :405-417 greedy chain: each step's query is the previous result
+    // :405-417 greedy chain: each step's query is the previous result; the steps run on the device
+    // back to back (one call, one wait)
     static SoundSequence from_distances(const std::vector<double> &distances, ArcSound start,
                                         const SoundDictionary &dict)
     {
-        std::vector<ArcSound> sounds{std::move(start)};
-        for (double d : distances)
-            sounds.push_back(dict.at_distance(d, *sounds.back()));
+        std::vector<ArcSound> sounds{start};
+        if (!distances.empty())
+            for (uint32_t i : dict.chain_indices(*start, distances))
+                sounds.push_back(dict.sounds[i]);
         return new_(std::move(sounds));
     }
     // :440-449 zip(sounds, distances) -> at_distance, as ONE batch

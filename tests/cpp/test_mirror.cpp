@@ -6,6 +6,7 @@
 //   empty dictionary                    the panic at src/sound.rs:369
 //
 // Build: tests/cpp/Makefile.  Exit code 0 = all checks passed.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -19,6 +20,8 @@ int ssym_oracle_dtw_match_all(const double *src, const uint64_t *src_off, uint32
                               const uint64_t *tgt_off, uint32_t n_tgt, uint32_t dim, int64_t band, int squared,
                               int nthreads, int64_t *out_idx, double *out_cost, double *cost_matrix);
 void ssym_oracle_length_fit(const double *matched, uint64_t n_matched, uint64_t n_target, double *out);
+int ssym_oracle_mfcc(const double *samples, uint64_t n, double rate, uint32_t nc, double f_lo, double f_hi,
+                     int pad_tail, double *out);
 }
 
 using namespace soundsym;
@@ -99,6 +102,28 @@ int main()
         ArcSound want = dict->sounds[oracle_at_distance(*dict, std::vector<double>{0.01, 0.02, 0.0}[k], *cur)];
         CHECK(chain.sounds()[k + 1] == want);
         cur = want;
+    }
+    // candidates: the first of the k best is at_distance's answer, no sound appears twice
+    {
+        auto cands = dict->candidates({tdict->sounds[0], tdict->sounds[2]}, 3);
+        CHECK(cands.size() == 2 && cands[0].size() == 3);
+        CHECK(cands[0][0] == dict->sounds[oracle_at_distance(*dict, 1.0, *tdict->sounds[0])]);
+        CHECK(cands[1][0] == dict->sounds[oracle_at_distance(*dict, 1.0, *tdict->sounds[2])]);
+        CHECK(cands[0][0] != cands[0][1] && cands[0][1] != cands[0][2] && cands[0][0] != cands[0][2]);
+    }
+    // from_samples without features analyses on the GPU: 1024-sample windows hopped by 256
+    {
+        std::vector<double> smp(4096);
+        for (std::size_t i = 0; i < smp.size(); ++i)
+            smp[i] = std::sin(0.05 * (double)i);
+        Sound analysed = Sound::from_samples(*ctx, smp, 44100.0);
+        CHECK(analysed.num_frames() == (4096 - 1024) / 256 + 1);
+        std::vector<double> want(analysed.mfccs().size());
+        ssym_oracle_mfcc(smp.data(), smp.size(), 44100.0, NCOEFFS, 100.0, 8000.0, 0, want.data());
+        double worst = 0.0;
+        for (std::size_t i = 0; i < want.size(); ++i)
+            worst = std::max(worst, std::fabs(want[i] - analysed.mfccs()[i]) / (1.0 + std::fabs(want[i])));
+        CHECK(worst <= 1e-12);
     }
     // add_segments invalidates the resident copy; indices continue
     dict->add_segments(tsrc, {HOP * 9});
