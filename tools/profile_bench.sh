@@ -8,7 +8,7 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$tag
 mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
-cmd="python3 $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+cmd="python3 $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- $cmd > $out/trace.log 2>&1 || echo "trace pass failed"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- $cmd > $out/pmc_fetch.log 2>&1 || echo "fetch pass failed"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- $cmd > $out/pmc_write.log 2>&1 || echo "write pass failed"

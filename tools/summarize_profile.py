@@ -34,7 +34,7 @@ def main():
     stats = kernel_stats(src)
     out = {"source": src, "kernels": [], "pmc": {}}
     lines = ["# rocprofv3 summary (%s)" % os.path.basename(dst), "",
-             "Command: `python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline` "
+             "Command: `python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary` "
              "(4096x4096 segments, 128 frames x 13 dims, 1 MI355X).", "",
              "## kernel trace (--kernel-trace --stats)", "",
              "| kernel | calls | total ms | avg ms | % |", "|---|---|---|---|---|"]
