@@ -53,6 +53,19 @@ def main():
     idx, cost, mat = o.dtw_match_all(sf, so, tf, to, 13, want_matrix=True)
     np.savez(os.path.join(HERE, "dtw_ragged.npz"), src=sf.astype(np.float32), src_off=so,
              tgt=tf.astype(np.float32), tgt_off=to, idx=idx, cost=cost, matrix=mat)
+    # rows F1 / F3 / F4: top-k, MFCC front-end, greedy chain -- one small case each
+    g = np.load(os.path.join(HERE, "refcos_ragged.npz"))
+    sims = o.refcos_matrix(g["src"], g["src_off"], g["tgt"], g["tgt_off"], 12)
+    top_idx, top_key = o.topk(sims, 4, distance=g["dist"])
+    u = synth.splitmix64(0x5EED0104, 6000).astype(np.float64) / 2.0 ** 64      # uniform [0, 1)
+    t = np.arange(6000) / 44100.0
+    wave = 0.4 * np.sin(2 * np.pi * 440.0 * t) + 0.2 * np.sin(2 * np.pi * 3100.0 * t) + 0.05 * (u - 0.5)
+    mfcc = o.mfcc(wave, 44100.0)
+    start = g["tgt"][int(g["tgt_off"][1]) * 12:int(g["tgt_off"][2]) * 12]
+    chain_dist = np.linspace(0.9, 1.1, 9)
+    chain_idx, chain_val = o.chain(g["src"], g["src_off"], 12, start, chain_dist)
+    np.savez(os.path.join(HERE, "rows_f.npz"), top_idx=top_idx, top_key=top_key, wave=wave, mfcc=mfcc,
+             chain_start=start, chain_dist=chain_dist, chain_idx=chain_idx, chain_val=chain_val)
     print("golden fixtures written to", HERE)
 
 

@@ -513,3 +513,19 @@ def test_device_resident_inputs_and_outputs(dtw, oracle):
     want_idx, want_cost = oracle.dtw_match_all(sf.astype(np.float64), so, tf.astype(np.float64), to, 13)
     assert np.array_equal(out_idx.cpu().numpy(), want_idx)
     assert np.allclose(out_cost.cpu().numpy(), want_cost, rtol=EXACT_RTOL, atol=0)
+
+
+def test_rows_f_golden_fixture(refcos):
+    # committed vectors for top-k, the MFCC front-end and the greedy chain (tests/golden/rows_f.npz)
+    from soundsym_amd._native import NO_MATCH
+    g = np.load(os.path.join(GOLD, "refcos_ragged.npz"))
+    f = np.load(os.path.join(GOLD, "rows_f.npz"))
+    d = refcos.dictionary(g["src"], g["src_off"], 12)
+    q = refcos.queries(g["tgt"], g["tgt_off"], 12)
+    idx, key = refcos.match_topk(d, q, 4, g["dist"])
+    assert np.array_equal(np.where(idx == NO_MATCH, -1, idx.astype(np.int64)), f["top_idx"])
+    assert np.array_equal(key, f["top_key"], equal_nan=True)
+    m = refcos.mfcc(f["wave"], 44100.0)
+    assert np.all(np.abs(m - f["mfcc"]) <= 1e-12 * (1 + np.abs(f["mfcc"])))
+    ci, cv = refcos.chain(d, f["chain_start"], f["chain_dist"])
+    assert np.array_equal(ci, f["chain_idx"]) and np.array_equal(cv, f["chain_val"])

@@ -186,3 +186,19 @@ def test_mfcc_oracle_against_a_numpy_fft_restatement(oracle):
     assert np.abs(got - loge @ dct.T).max() < 1e-9
     assert oracle.mfcc(x[:1023], rate).shape == (0, 12)
     assert oracle.mfcc(x[:1023], rate, pad_tail=True).shape == (3, 12)
+
+
+def test_rows_f_golden_fixture_matches_oracle(oracle):
+    # top-k / MFCC / chain fixtures of tests/golden/rows_f.npz (make_golden.py): the oracle today
+    # still produces what was committed; MFCC values may move by libm ulps between machines
+    g = np.load(os.path.join(GOLD, "refcos_ragged.npz"))
+    f = np.load(os.path.join(GOLD, "rows_f.npz"))
+    sims = oracle.refcos_matrix(g["src"], g["src_off"], g["tgt"], g["tgt_off"], 12)
+    assert np.array_equal(sims, g["sims"])
+    idx, key = oracle.topk(sims, 4, distance=g["dist"])
+    assert np.array_equal(idx, f["top_idx"]) and np.array_equal(key, f["top_key"], equal_nan=True)
+    assert np.array_equal(idx[:, 0], g["idx_d"]) and np.array_equal(key[:, 0], g["val_d"])
+    m = oracle.mfcc(f["wave"], 44100.0)
+    assert m.shape == f["mfcc"].shape and np.all(np.abs(m - f["mfcc"]) <= 1e-12 * (1 + np.abs(f["mfcc"])))
+    ci, cv = oracle.chain(g["src"], g["src_off"], 12, f["chain_start"], f["chain_dist"])
+    assert np.array_equal(ci, f["chain_idx"]) and np.array_equal(cv, f["chain_val"])
