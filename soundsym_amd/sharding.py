@@ -93,6 +93,9 @@ def merge_shards(engine, costs, idx):
     if not costs.is_cuda or not idx.is_cuda:
         raise RuntimeError("merge_shards runs the HIP kernel: tensors must be on the GPU")
     g, m = costs.shape
+    # the gathered tensors were produced on torch's stream (RCCL enqueues and returns); the library
+    # launches on its own stream, so the host orders the two
+    torch.cuda.current_stream(costs.device).synchronize()
     out_idx = torch.empty(m, dtype=idx.dtype, device=idx.device)
     out_cost = torch.empty(m, dtype=torch.float64, device=costs.device)
     engine.merge_shards(costs.contiguous(), idx.contiguous(), out_idx, out_cost)
