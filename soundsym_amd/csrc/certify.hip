@@ -11,65 +11,26 @@
 // v_min3_f32 over the accumulators, one wave reduction at the end.
 //
 // The kernel is bound by fetching records, not by the matrix pipe (a 128 x 128 pair is 24 KB of
-// records for 48 MFMAs), so the list arrives grouped by target (select.hip) and, when the targets
-// have at most 128 frames, a wave walks a run of consecutive list entries with the current
-// target's (up to) four column tiles held in registers: a pair then costs its source records only.
+// records for 48 MFMAs), so the list arrives grouped by target (select.hip) and a wave walks a run
+// of consecutive list entries with (up to) four column tiles of the current target held in
+// registers: a pair then costs its source records only.  Targets longer than 128 frames are covered
+// in column groups of 128, the run's minima staying in registers between groups.
 #include "ssym_internal.hpp"
 #include "dtw_filter_kernel.hpp"
 
 namespace ssym {
 
-__global__ __launch_bounds__(64) void certify_kernel(const _Float16 *__restrict__ srcRec,
-                                                     const _Float16 *__restrict__ tgtRec,
-                                                     const int *__restrict__ srcLen, const int *__restrict__ tgtLen,
-                                                     int srcSlots, int srcLead, int tgtSlots,
-                                                     const uint32_t *__restrict__ candHdr,
-                                                     const uint2 *__restrict__ pairs, uint32_t cap, float outScaleSq,
-                                                     float *__restrict__ xmin)
-{
-    constexpr int REC = kFilterRecHalfs;
-    const float INF = __builtin_inff();
-    const int lane = threadIdx.x;
-    const int rc = lane & 31, kh = lane >> 5;
-    const uint32_t n = candHdr[1] ? 0u : min(candHdr[0], cap);   // overflowed list: the host redoes stage 1
-    for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) {
-        const uint2 p = pairs[k];
-        const int fa = srcLen[p.x], fb = tgtLen[p.y];
-        float m = INF;
-        if (fa > 0 && fb > 0) {
-            // frame f of the source sits in slot first + f (end-aligned when srcLead < 0)
-            const int first = srcLead < 0 ? srcSlots - fa : srcLead;
-            const _Float16 *sBase = srcRec + ((size_t)p.x * srcSlots + first) * REC + kh * 24;
-            const _Float16 *tBase = tgtRec + tgt_rec_offset(p.y, tgtSlots, 0, 0, kh);
-            for (int i0 = 0; i0 < fa; i0 += 32) {
-                half8 A[kFilterKM];
-                load_rec(sBase + (size_t)min(i0 + rc, fa - 1) * REC, A);      // rows past the end repeat the last frame
-                for (int j0 = 0; j0 < fb; j0 += 32) {
-                    half8 B[kFilterKM];
-                    load_tgt_rec(tBase, min(j0 + rc, fb - 1), B);
-                    const f32x16 acc = mfma_tile<kFilterKM>(A, B);
-#pragma unroll
-                    for (int r = 0; r < 16; r += 2)
-                        m = __builtin_fminf(__builtin_fminf(m, acc[r]), acc[r + 1]);
-                }
-            }
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1)
-                m = __builtin_fminf(m, __shfl_xor(m, o));
-        }
-        if (lane == 0)
-            xmin[k] = m * outScaleSq;
-    }
-}
-
 constexpr int kCertRun = 8;   // consecutive list entries per wave visit (same target, mostly)
 
-template <int NB>   // column tiles of a target kept in registers: targets have <= 32 NB frames
+// NB = column tiles of a target kept in registers at a time (32 NB frames); longer targets are
+// covered by further column groups, with the running minimum of every entry of the run in registers.
+template <int NB>
 __global__ __launch_bounds__(64) void certify_run_kernel(const _Float16 *__restrict__ srcRec,
                                                          const _Float16 *__restrict__ tgtRec,
                                                          const int *__restrict__ srcLen,
                                                          const int *__restrict__ tgtLen, int srcSlots, int srcLead,
-                                                         int tgtSlots, const uint32_t *__restrict__ candHdr,
+                                                         int tgtSlots, int tgtMaxFrames,
+                                                         const uint32_t *__restrict__ candHdr,
                                                          const uint2 *__restrict__ pairs, uint32_t cap,
                                                          float outScaleSq, float *__restrict__ xmin)
 {
@@ -77,34 +38,42 @@ __global__ __launch_bounds__(64) void certify_run_kernel(const _Float16 *__restr
     const float INF = __builtin_inff();
     const int lane = threadIdx.x;
     const int rc = lane & 31, kh = lane >> 5;
-    const uint32_t n = candHdr[1] ? 0u : min(candHdr[0], cap);
+    const uint32_t n = candHdr[1] ? 0u : min(candHdr[0], cap);   // overflowed list: the host redoes stage 1
     for (uint64_t g = (uint64_t)blockIdx.x * kCertRun; g < n; g += (uint64_t)gridDim.x * kCertRun) {
-        const uint32_t gEnd = (uint32_t)min(g + kCertRun, (uint64_t)n);
-        half8 B[NB][kFilterKM];
-        uint32_t cachedT = 0xffffffffu;
-        int fb = 0;
-        for (uint32_t k = (uint32_t)g; k < gEnd; ++k) {
-            const uint2 p = pairs[k];
-            if (p.y != cachedT) {
-                cachedT = p.y;
-                fb = tgtLen[p.y];
-                const _Float16 *tBase = tgtRec + tgt_rec_offset(p.y, tgtSlots, 0, 0, kh);
+        float mrun[kCertRun];
 #pragma unroll
-                for (int q = 0; q < NB; ++q)      // columns past the end repeat the last frame
-                    load_tgt_rec(tBase, max(min(q * 32 + rc, fb - 1), 0), B[q]);
-            }
-            const int fa = srcLen[p.x];
-            float m = INF;
-            if (fa > 0 && fb > 0) {
+        for (int e = 0; e < kCertRun; ++e)
+            mrun[e] = INF;
+        for (int c0 = 0; c0 < tgtMaxFrames; c0 += 32 * NB) {
+            half8 B[NB][kFilterKM];
+            uint32_t cachedT = 0xffffffffu;
+#pragma unroll
+            for (int e = 0; e < kCertRun; ++e) {
+                const uint64_t k = g + e;
+                if (k >= n)
+                    continue;                                  // wave-uniform
+                const uint2 p = pairs[k];
+                const int fb = tgtLen[p.y], fa = srcLen[p.x];
+                if (c0 >= fb || fa <= 0)
+                    continue;                                  // wave-uniform
+                if (p.y != cachedT) {
+                    cachedT = p.y;
+                    const _Float16 *tBase = tgtRec + tgt_rec_offset(p.y, tgtSlots, 0, 0, kh);
+#pragma unroll
+                    for (int q = 0; q < NB; ++q)      // columns past the end repeat the last frame
+                        load_tgt_rec(tBase, min(c0 + q * 32 + rc, fb - 1), B[q]);
+                }
+                // frame f of the source sits in slot first + f (end-aligned when srcLead < 0)
                 const int first = srcLead < 0 ? srcSlots - fa : srcLead;
                 const _Float16 *sBase = srcRec + ((size_t)p.x * srcSlots + first) * REC + kh * 24;
                 half8 A[kFilterKM], An[kFilterKM];
-                load_rec(sBase + (size_t)min(rc, fa - 1) * REC, A);
+                load_rec(sBase + (size_t)min(rc, fa - 1) * REC, A);   // rows past the end repeat the last frame
+                float m = mrun[e];
                 for (int i0 = 0; i0 < fa; i0 += 32) {
                     load_rec(sBase + (size_t)min(i0 + 32 + rc, fa - 1) * REC, An);   // next row tile in flight
 #pragma unroll
                     for (int q = 0; q < NB; ++q) {
-                        if (q * 32 < fb) {
+                        if (c0 + q * 32 < fb) {
                             const f32x16 acc = mfma_tile<kFilterKM>(A, B[q]);
 #pragma unroll
                             for (int r = 0; r < 16; r += 2)
@@ -115,12 +84,17 @@ __global__ __launch_bounds__(64) void certify_run_kernel(const _Float16 *__restr
                     for (int v = 0; v < kFilterKM; ++v)
                         A[v] = An[v];
                 }
-#pragma unroll
-                for (int o = 32; o >= 1; o >>= 1)
-                    m = __builtin_fminf(m, __shfl_xor(m, o));
+                mrun[e] = m;
             }
-            if (lane == 0)
-                xmin[k] = m * outScaleSq;
+        }
+#pragma unroll
+        for (int e = 0; e < kCertRun; ++e) {
+            float m = mrun[e];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1)
+                m = __builtin_fminf(m, __shfl_xor(m, o));
+            if (lane == 0 && g + e < n)
+                xmin[g + e] = m * outScaleSq;
         }
     }
 }
@@ -132,27 +106,21 @@ int32_t launch_certify(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &t
         return SSYM_OK;
     const double s = src.rec_scale > 0.0 ? src.rec_scale : 1.0;
     const float outScaleSq = (float)(1.0 / (s * s));
-    if (tgt.max_frames <= 128) {
-        const unsigned runs = (unsigned)std::min<uint64_t>(((uint64_t)cap + kCertRun - 1) / kCertRun,
-                                                           (uint64_t)ctx->num_cus * 64);
+    const int maxF = (int)std::max<uint32_t>(tgt.max_frames, 1);
+    const unsigned runs = (unsigned)std::min<uint64_t>(((uint64_t)cap + kCertRun - 1) / kCertRun,
+                                                       (uint64_t)ctx->num_cus * 64);
 #define SSYM_CERT_RUN(NB)                                                                                   \
     certify_run_kernel<NB><<<runs, 64, 0, ctx->stream>>>((const _Float16 *)src.rec, (const _Float16 *)tgt.rec, \
                                                          src.len, tgt.len, (int)src.rec_slots, src.rec_lead,  \
-                                                         (int)tgt.rec_slots, candHdr, pairs, cap, outScaleSq, xmin)
-        switch ((std::max<uint32_t>(tgt.max_frames, 1) + 31) / 32) {
-        case 1: SSYM_CERT_RUN(1); break;
-        case 2: SSYM_CERT_RUN(2); break;
-        case 3: SSYM_CERT_RUN(3); break;
-        default: SSYM_CERT_RUN(4); break;
-        }
-#undef SSYM_CERT_RUN
-        SSYM_HIP_CHECK(ctx, hipGetLastError());
-        return SSYM_OK;
+                                                         (int)tgt.rec_slots, maxF, candHdr, pairs, cap,       \
+                                                         outScaleSq, xmin)
+    switch ((maxF + 31) / 32) {
+    case 1: SSYM_CERT_RUN(1); break;
+    case 2: SSYM_CERT_RUN(2); break;
+    case 3: SSYM_CERT_RUN(3); break;
+    default: SSYM_CERT_RUN(4); break;
     }
-    const unsigned grid = (unsigned)std::min<uint64_t>(cap, (uint64_t)ctx->num_cus * 64);
-    certify_kernel<<<grid, 64, 0, ctx->stream>>>((const _Float16 *)src.rec, (const _Float16 *)tgt.rec, src.len,
-                                                  tgt.len, (int)src.rec_slots, src.rec_lead, (int)tgt.rec_slots,
-                                                  candHdr, pairs, cap, outScaleSq, xmin);
+#undef SSYM_CERT_RUN
     SSYM_HIP_CHECK(ctx, hipGetLastError());
     return SSYM_OK;
 }
