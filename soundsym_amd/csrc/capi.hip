@@ -284,6 +284,33 @@ static int32_t check_match_args(ssym_ctx *ctx, const ssym_dict *dict, const ssym
 
 }  // extern "C"
 
+// filter costs live in record-slot coordinates; the caller sees segments in its own order
+__global__ void f32_to_f64_matrix_kernel(const float *__restrict__ in, uint32_t rows, uint32_t cols,
+                                         uint32_t ld, const uint32_t *__restrict__ permRow,
+                                         const uint32_t *__restrict__ permCol, double *__restrict__ out)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t r = blockIdx.y;
+    if (c < cols && r < rows)
+        out[(size_t)permRow[r] * cols + permCol[c]] = (double)in[(size_t)r * ld + c];
+}
+
+// per-target values between slot order (inside) and the caller's target order (outside)
+__global__ void slots_to_targets_kernel(const double *__restrict__ bySlot, const uint32_t *__restrict__ perm,
+                                        uint32_t n, double *__restrict__ byTarget)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        byTarget[perm[i]] = bySlot[i];
+}
+__global__ void targets_to_slots_kernel(const double *__restrict__ byTarget, const uint32_t *__restrict__ perm,
+                                        uint32_t n, double *__restrict__ bySlot)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        bySlot[i] = byTarget[perm[i]];
+}
+
 // k_top = 1: ssym_match_queries (outputs [M]); k_top > 1: ssym_match_topk (outputs [M][k_top]).
 // phase 0: the whole match.  Phases 1 / 2 are ssym_match_begin / ssym_match_finish: phase 1 stops
 // after the filter and the per-target threshold (copied to bounds_dev), phase 2 takes the threshold
@@ -374,8 +401,9 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
             tm.main_launches = 1;
             if (phase == 1) {
                 // hand the threshold out: non-negative doubles (or +inf), bit for bit what stage 1 uses
-                SSYM_HIP_CHECK(ctx, hipMemcpyAsync(bounds_dev, ctx->tmin.ptr, sizeof(double) * M,
-                                                   hipMemcpyDeviceToDevice, st));
+                slots_to_targets_kernel<<<(M + 255) / 256, 256, 0, st>>>((const double *)ctx->tmin.ptr, tgt.perm, M,
+                                                                         bounds_dev);
+                SSYM_HIP_CHECK(ctx, hipGetLastError());
                 SSYM_HIP_CHECK(ctx, hipStreamSynchronize(st));
                 ctx->pending.main_ms = ev_ms(ev[0], ev[1]);
                 tm.main_ms = ctx->pending.main_ms;
@@ -383,8 +411,9 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
                 return SSYM_OK;
             }
             if (phase == 2) {
-                SSYM_HIP_CHECK(ctx, hipMemcpyAsync(ctx->tmin.ptr, bounds_dev, sizeof(double) * M,
-                                                   hipMemcpyDeviceToDevice, st));
+                targets_to_slots_kernel<<<(M + 255) / 256, 256, 0, st>>>(bounds_dev, tgt.perm, M,
+                                                                         (double *)ctx->tmin.ptr);
+                SSYM_HIP_CHECK(ctx, hipGetLastError());
                 SSYM_HIP_CHECK(ctx, hipEventRecord(ev[0], st));
             }
             // list 1 (worst-case margin) is a few pairs per target when near-duplicates exist and
@@ -612,15 +641,6 @@ int32_t ssym_match_one(ssym_ctx *ctx, const ssym_dict *dict, const void *feats, 
     return ssym_match_batch(ctx, dict, feats, off, 1, &distance, out_idx, out_cost);
 }
 
-__global__ void f32_to_f64_matrix_kernel(const float *__restrict__ in, uint32_t rows, uint32_t cols,
-                                         uint32_t ld, double *__restrict__ out)
-{
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t r = blockIdx.y;
-    if (c < cols && r < rows)
-        out[(size_t)r * cols + c] = (double)in[(size_t)r * ld + c];
-}
-
 /* from_distances (src/sound.rs:405-417) on the device; see chain.hip. */
 int32_t ssym_chain(ssym_ctx *ctx, ssym_dict *dict, const void *start_feats, uint64_t start_frames,
                    const double *distances, uint32_t n_steps, uint32_t *out_idx, double *out_cost)
@@ -757,7 +777,8 @@ int32_t ssym_pair_matrix(ssym_ctx *ctx, const ssym_dict *dict, const ssym_querie
         rc = launch_dtw_filter(ctx, src, tgt, (float *)ctx->cmat.ptr);
         if (rc == SSYM_OK) {
             dim3 grid((M + 255) / 256, N);
-            f32_to_f64_matrix_kernel<<<grid, 256, 0, st>>>((const float *)ctx->cmat.ptr, N, M, tgt.n_pad, mat);
+            f32_to_f64_matrix_kernel<<<grid, 256, 0, st>>>((const float *)ctx->cmat.ptr, N, M, tgt.n_pad, src.perm,
+                                                           tgt.perm, mat);
             SSYM_HIP_CHECK(ctx, hipGetLastError());
         }
     }

@@ -26,10 +26,12 @@ namespace ssym {
 // Source slots that hold no frame (and all slots of padding segments) get |a|^2 = +inf so that
 // their DP cells stay at +inf; empty target slots are all-zero records.
 __global__ void build_filter_records_kernel(const double *__restrict__ raw, const uint64_t *__restrict__ off,
-                                            uint32_t n, uint32_t dim, uint32_t frames_pad, int is_source,
+                                            const uint32_t *__restrict__ perm, uint32_t n, uint32_t dim,
+                                            uint32_t frames_pad, int is_source,
                                             int lead, int pieces, double scale, _Float16 *__restrict__ rec)
 {
-    const uint32_t s = blockIdx.y;                              // < n_pad
+    const uint32_t s = blockIdx.y;                              // record slot of the segment, < n_pad
+    const uint32_t seg = perm[s];                               // the segment it holds (0xffffffff: none)
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= frames_pad)
         return;
@@ -37,14 +39,14 @@ __global__ void build_filter_records_kernel(const double *__restrict__ raw, cons
 #pragma unroll
     for (int i = 0; i < kFilterRecHalfs; ++i)
         out[i] = (_Float16)0.0f;
-    const uint32_t nf = s < n ? (uint32_t)(off[s + 1] - off[s]) : 0u;
+    const uint32_t nf = seg < n ? (uint32_t)(off[seg + 1] - off[seg]) : 0u;
     const uint32_t first = lead < 0 ? frames_pad - nf : (uint32_t)lead;
     const bool real = slot >= first && slot < first + nf;
     const uint32_t f = slot - first;
     if (!real && is_source)
         out[filter_slot_offset((pieces == 2 ? 3 : 1) * (int)dim)] = (_Float16)__builtin_inff();   // |a|^2 = +inf
     if (real) {
-        const double *p = raw + (off[s] + f) * dim;
+        const double *p = raw + (off[seg] + f) * dim;
         double nrm = 0.0;
         for (uint32_t e = 0; e < dim; ++e) {
             const double v = p[e] * scale;                       // exact: scale is a power of two
@@ -150,7 +152,7 @@ static int32_t ensure_records(ssym_ctx *ctx, const SegmentSet &set, double scale
     }
     set.rec_bytes = bytes;
     dim3 grid((slots + 63) / 64, set.n_pad);
-    build_filter_records_kernel<<<grid, 64, 0, ctx->stream>>>(set.raw, set.off, set.n, set.dim, slots,
+    build_filter_records_kernel<<<grid, 64, 0, ctx->stream>>>(set.raw, set.off, set.perm, set.n, set.dim, slots,
                                                               set.is_source ? 1 : 0, lead,
                                                               filter_pieces((int)set.dim), scale,
                                                               (_Float16 *)set.rec);
@@ -163,14 +165,15 @@ static int32_t ensure_records(ssym_ctx *ctx, const SegmentSet &set, double scale
 
 template <int NT, bool SQ>
 static void launch_one(hipStream_t st, const SegmentSet &src, const SegmentSet &tgt, int nPasses,
-                       int gridBlocks, float outScale, float *handoff, float *cmat)
+                       int gridBlocks, float outScale, float *handoff, unsigned *taskCtr, float *cmat)
 {
-    const int nSrcBlocks = (int)src.n_pad / (2 * kFilterWavesPerBlock);
+    const int nSrcPairs = (int)src.n_pad / 2;
     const int nTgtGroups = (int)tgt.n_pad / 32;
-    const int nTasks = nSrcBlocks * nTgtGroups;
-    dtw_filter_kernel<NT, SQ><<<dim3(std::min(gridBlocks, (nTasks + 7) / 8 * 8)), 64 * kFilterWavesPerBlock, 0, st>>>(
+    const int nTasks = nSrcPairs * nTgtGroups;            // one wave's 64 pairs each
+    const int blocksWanted = (nTasks + kFilterWavesPerBlock - 1) / kFilterWavesPerBlock;
+    dtw_filter_kernel<NT, SQ><<<dim3(std::min(gridBlocks, (blocksWanted + 7) / 8 * 8)), 64 * kFilterWavesPerBlock, 0, st>>>(
         (const _Float16 *)src.rec, (const _Float16 *)tgt.rec, src.len, tgt.len, (int)src.frames_pad, nPasses,
-        (int)tgt.frames_pad, (int)tgt.n_pad, nSrcBlocks, nTasks, outScale, handoff, cmat);
+        (int)tgt.frames_pad, (int)tgt.n_pad, nSrcPairs, nTasks, outScale, handoff, taskCtr, cmat);
 }
 
 template <int NTB, int WB, int OCC, bool SQ, int LASTN>
@@ -259,17 +262,21 @@ int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
     // persistent grid: 2 workgroups of 4 waves per CU (2 waves per SIMD), a multiple of 8 so that
     // task & 7 is the XCD group; one hand-off row of [target frames][64] floats per wave
     const int gridBlocks = std::max(8, ctx->num_cus * 2 / 8 * 8);
-    rc = ensure(ctx, ctx->handoff, (size_t)gridBlocks * kFilterWavesPerBlock * tgt.frames_pad * 64 * sizeof(float));
+    // + 8 task counters behind the hand-off rows
+    const size_t handBytes = (size_t)gridBlocks * kFilterWavesPerBlock * tgt.frames_pad * 64 * sizeof(float);
+    rc = ensure(ctx, ctx->handoff, handBytes + 8 * sizeof(unsigned));
     if (rc != SSYM_OK)
         return rc;
+    unsigned *taskCtr = (unsigned *)((char *)ctx->handoff.ptr + handBytes);
+    SSYM_HIP_CHECK(ctx, hipMemsetAsync(taskCtr, 0, 8 * sizeof(unsigned), ctx->stream));
     hipStream_t st = ctx->stream;
     const bool sq = ctx->squared != 0;
     const float outScale = (float)(sq ? 1.0 / (scale * scale) : 1.0 / scale);
     float *hand = (float *)ctx->handoff.ptr;
 #define SSYM_CASE(NT_)                                                                          \
     case NT_:                                                                                   \
-        if (sq) launch_one<NT_, true>(st, src, tgt, shape.rb, gridBlocks, outScale, hand, cmat);  \
-        else launch_one<NT_, false>(st, src, tgt, shape.rb, gridBlocks, outScale, hand, cmat);    \
+        if (sq) launch_one<NT_, true>(st, src, tgt, shape.rb, gridBlocks, outScale, hand, taskCtr, cmat);  \
+        else launch_one<NT_, false>(st, src, tgt, shape.rb, gridBlocks, outScale, hand, taskCtr, cmat);    \
         break;
     switch (shape.nt) {
         SSYM_CASE(1) SSYM_CASE(2) SSYM_CASE(3) SSYM_CASE(4)

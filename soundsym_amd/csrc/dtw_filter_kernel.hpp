@@ -150,14 +150,14 @@ constexpr int kFilterSlotBytes = kFilterKM * 1024 + 256;        // 64 lanes x (3
 constexpr int kWaitVm6 = 0x0F76;                                // vmcnt(6), nothing else
 constexpr int kWaitVm9 = 0x0F79;                                // vmcnt(9)
 
-// Persistent kernel: workgroup b works on tasks b, b + gridDim.x, ...; a task is (target group of
-// 32, block of 8 sources); each of the 4 waves owns one source pair of the block = 64 pairs.
+// Persistent kernel: every wave keeps taking (source pair, target group) tasks of 64 pairs until
+// none is left (taskCtr: 8 counters, zeroed by the host before the launch).
 template <int NT, bool SQ>
 __global__ __launch_bounds__(64 * kFilterWavesPerBlock, 2) void dtw_filter_kernel(
     const _Float16 *__restrict__ srcRec, const _Float16 *__restrict__ tgtRec,
     const int *__restrict__ srcLen, const int *__restrict__ tgtLen, int srcRows, int nPasses,
-    int tgtFramesPad, int mPad, int nSrcBlocks, int nTasks, float outScale,
-    float *__restrict__ handoff, float *__restrict__ cmat)
+    int tgtFramesPad, int mPad, int nSrcPairs, int nTasks, float outScale,
+    float *__restrict__ handoff, unsigned *__restrict__ taskCtr, float *__restrict__ cmat)
 {
     constexpr int REC = kFilterRecHalfs;
     constexpr int BR = NT * 16;            // rows per pass
@@ -173,15 +173,29 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, 2) void dtw_filter_kerne
     __shared__ __attribute__((aligned(16))) char ring[kFilterWavesPerBlock][kFilterRing * kFilterSlotBytes];
     char *const myRing = ring[wave];
 
-    for (unsigned task = blockIdx.x; task < (unsigned)nTasks; task += gridDim.x) {
-        // XCD-aware task order: workgroups b, b+8, ... share an XCD and gridDim.x is a multiple of
-        // 8, so task & 7 names the XCD group; give each group a contiguous range of the
-        // (target group, source block) space so a group's 32 targets stay in that XCD's L2.
-        const unsigned xcd = task & 7u, qd = (unsigned)nTasks >> 3, rm = (unsigned)nTasks & 7u;
-        const unsigned lin = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (task >> 3);
-        const int tg = (int)(lin / (unsigned)nSrcBlocks);
-        const int sb = (int)(lin % (unsigned)nSrcBlocks);
-        const int sp = sb * kFilterWavesPerBlock + wave;    // source pair of this wave
+    // Work distribution: a task is one wave's (source pair, target group) = 64 pairs; waves take
+    // tasks from 8 counters, one per XCD group (workgroups b, b+8, ... share an XCD and gridDim.x is a
+    // multiple of 8), each counter covering a contiguous range of the (target group, source pair)
+    // space so that a group's targets stay in that XCD's L2.  Ranges are walked from their END:
+    // record slots are ordered by segment length, so the longest tasks start first and the short
+    // ones fill the tail (with ragged segment lengths a static assignment left most of the chip
+    // waiting for the workgroup that held the longest sources).  A wave whose range is exhausted
+    // helps the next XCD's range, so every wave leaves only when all counters are spent.
+    const unsigned qd = (unsigned)nTasks >> 3, rm = (unsigned)nTasks & 7u;
+    for (unsigned hop = 0; hop < 8; ++hop) {
+      const unsigned xcd = (blockIdx.x + hop) & 7u;
+      const unsigned rangeLo = xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd;
+      const unsigned rangeLen = qd + (xcd < rm ? 1u : 0u);
+      for (;;) {
+        unsigned got = 0;
+        if (lane == 0)
+            got = atomicAdd(&taskCtr[xcd], 1u);
+        got = (unsigned)__builtin_amdgcn_readfirstlane((int)got);
+        if (got >= rangeLen)
+            break;
+        const unsigned lin = rangeLo + (rangeLen - 1u - got);
+        const int tg = (int)(lin / (unsigned)nSrcPairs);
+        const int sp = (int)(lin % (unsigned)nSrcPairs);    // source pair of this wave
 
         const int fa = srcLen[2 * sp + half];
         const int fb_m1 = tgtLen[32 * tg + col] - 1;
@@ -317,6 +331,7 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, 2) void dtw_filter_kerne
             }
         }
         cmat[(size_t)(2 * sp + half) * mPad + 32 * tg + col] = res * outScale;
+      }
     }
 }
 

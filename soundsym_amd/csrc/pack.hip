@@ -56,18 +56,20 @@ __global__ void segment_norm_kernel(const double *__restrict__ raw, const uint64
 
 // dtw: per-segment frame count and max squared frame norm, and the set-wide max |value|
 // (bits of non-negative floats order like unsigned integers; a non-finite value poisons the max).
+// Outputs are indexed by record SLOT (blockIdx.y); the slot's segment is perm[slot].
 __global__ void segment_stats_kernel(const double *__restrict__ raw, const uint64_t *__restrict__ off,
-                                     uint32_t n, uint32_t dim, int32_t *__restrict__ len,
-                                     unsigned *__restrict__ max_sqnorm_bits,
+                                     const uint32_t *__restrict__ perm, uint32_t n, uint32_t dim,
+                                     int32_t *__restrict__ len, unsigned *__restrict__ max_sqnorm_bits,
                                      unsigned *__restrict__ max_abs_bits)
 {
-    const uint32_t s = blockIdx.y;
+    const uint32_t slot = blockIdx.y;
     const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t s = perm[slot];
     if (s >= n)
         return;
     const uint32_t nf = (uint32_t)(off[s + 1] - off[s]);
     if (f == 0)
-        len[s] = (int32_t)nf;
+        len[slot] = (int32_t)nf;
     if (f >= nf)
         return;
     const double *p = raw + (off[s] + f) * dim;
@@ -81,7 +83,7 @@ __global__ void segment_stats_kernel(const double *__restrict__ raw, const uint6
     float sqf = (float)sq * 1.000001f;            // rounded up
     float maf = (float)ma * 1.000001f;
     if (!(sqf == sqf) || !(maf == maf)) { sqf = __builtin_inff(); maf = __builtin_inff(); }
-    atomicMax(&max_sqnorm_bits[s], __float_as_uint(sqf));
+    atomicMax(&max_sqnorm_bits[slot], __float_as_uint(sqf));
     atomicMax(max_abs_bits, __float_as_uint(maf));
 }
 
@@ -149,6 +151,7 @@ void free_segments(ssym_ctx *ctx, SegmentSet &set)
     set.rec = nullptr;
     dev_free(ctx, set.len);
     dev_free(ctx, set.max_sqnorm);
+    dev_free(ctx, set.perm);
     set = SegmentSet{};
 }
 
@@ -161,6 +164,7 @@ static int32_t build_derived(ssym_ctx *ctx, SegmentSet &set)
     dev_free(ctx, set.norm); set.norm = nullptr;
     dev_free(ctx, set.len); set.len = nullptr;
     dev_free(ctx, set.max_sqnorm); set.max_sqnorm = nullptr;
+    dev_free(ctx, set.perm); set.perm = nullptr;
 
     set.max_frames = 0;
     for (uint32_t i = 0; i < n; ++i)
@@ -185,12 +189,22 @@ static int32_t build_derived(ssym_ctx *ctx, SegmentSet &set)
         uint32_t mf = std::max<uint32_t>(set.max_frames, 1);
         FilterShape shape = filter_shape((int)mf);
         set.frames_pad = set.is_source ? (shape.nt ? (uint32_t)shape.rows() : mf) : mf;
+        // slots ordered by length (stable: equal lengths keep the caller's order)
+        set.h_perm.assign(set.n_pad, 0xffffffffu);
+        for (uint32_t i = 0; i < n; ++i)
+            set.h_perm[i] = i;
+        std::stable_sort(set.h_perm.begin(), set.h_perm.begin() + n, [&](uint32_t a, uint32_t b) {
+            return set.h_off[a + 1] - set.h_off[a] < set.h_off[b + 1] - set.h_off[b];
+        });
+        { int32_t rca = dev_alloc(ctx, (void **)&set.perm, sizeof(uint32_t) * set.n_pad); if (rca != SSYM_OK) return rca; }
+        SSYM_HIP_CHECK(ctx, hipMemcpyAsync(set.perm, set.h_perm.data(), sizeof(uint32_t) * set.n_pad,
+                                           hipMemcpyHostToDevice, st));
         { int32_t rca = dev_alloc(ctx, (void **)&set.len, sizeof(int32_t) * set.n_pad); if (rca != SSYM_OK) return rca; }
         SSYM_HIP_CHECK(ctx, hipMemsetAsync(set.len, 0, sizeof(int32_t) * set.n_pad, st));
         { int32_t rca = dev_alloc(ctx, (void **)&set.max_sqnorm, sizeof(float) * (set.n_pad + 1)); if (rca != SSYM_OK) return rca; }
         SSYM_HIP_CHECK(ctx, hipMemsetAsync(set.max_sqnorm, 0, sizeof(float) * (set.n_pad + 1), st));
         dim3 grid((mf + 63) / 64, n);
-        segment_stats_kernel<<<grid, 64, 0, st>>>(set.raw, set.off, n, dim, set.len,
+        segment_stats_kernel<<<grid, 64, 0, st>>>(set.raw, set.off, set.perm, n, dim, set.len,
                                                   (unsigned *)set.max_sqnorm,
                                                   (unsigned *)set.max_sqnorm + set.n_pad);
         SSYM_HIP_CHECK(ctx, hipGetLastError());

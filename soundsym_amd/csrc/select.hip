@@ -104,12 +104,15 @@ __global__ __launch_bounds__(256) void dtw_colmin_kernel(
     const float *__restrict__ cmat, uint32_t nSrc, uint32_t nTgt,
     uint32_t mPad, const double *__restrict__ dist, const int *__restrict__ srcLen,
     const float *__restrict__ srcMaxSq, const int *__restrict__ tgtLen, const float *__restrict__ tgtMaxSq,
-    MarginParams mp, const unsigned long long *__restrict__ prev, unsigned long long *__restrict__ ub)
+    MarginParams mp, const uint32_t *__restrict__ permT, const unsigned long long *__restrict__ prev,
+    unsigned long long *__restrict__ ub)
 {
+    // s, t are record SLOTS (the filter's coordinates); the caller's per-target distance is looked up
+    // through the slot's segment
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nTgt)
         return;
-    const double delta = dist ? dist[t] : 0.0;
+    const double delta = dist ? dist[permT[t]] : 0.0;
     const double nb = (double)tgtMaxSq[t];
     const int fb = tgtLen[t];
     const uint32_t s0 = blockIdx.y * kSelChunk;
@@ -138,8 +141,8 @@ __global__ __launch_bounds__(256) void dtw_mark_kernel(
     const float *__restrict__ cmat, uint32_t nSrc, uint32_t nTgt,
     uint32_t mPad, const double *__restrict__ dist, const int *__restrict__ srcLen,
     const float *__restrict__ srcMaxSq, const int *__restrict__ tgtLen, const float *__restrict__ tgtMaxSq,
-    MarginParams mp, const unsigned long long *__restrict__ ub, unsigned long long *__restrict__ mask,
-    uint32_t *__restrict__ cnt)
+    MarginParams mp, const uint32_t *__restrict__ permT, const unsigned long long *__restrict__ ub,
+    unsigned long long *__restrict__ mask, uint32_t *__restrict__ cnt)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nTgt)
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(256) void dtw_mark_kernel(
     unsigned long long hits = 0;
     const double thr = __longlong_as_double((long long)ub[t]);
     if (thr < __builtin_inf()) {     // else no finite cost for this target: the fold keeps (0, +inf)
-        const double delta = dist ? dist[t] : 0.0;
+        const double delta = dist ? dist[permT[t]] : 0.0;
         const double nb = (double)tgtMaxSq[t];
         const int fb = tgtLen[t];
         const uint32_t s0 = blockIdx.y * kSelChunk;
@@ -235,6 +238,7 @@ __global__ void dtw_stage2_ub_kernel(const uint32_t *__restrict__ hdr1, const ui
                                      uint32_t mPad, const double *__restrict__ dist, const int *__restrict__ srcLen,
                                      const float *__restrict__ srcMaxSq, const int *__restrict__ tgtLen,
                                      const float *__restrict__ tgtMaxSq, MarginParams mp,
+                                     const uint32_t *__restrict__ permT,
                                      const unsigned long long *__restrict__ prev,
                                      unsigned long long *__restrict__ ub)
 {
@@ -243,7 +247,7 @@ __global__ void dtw_stage2_ub_kernel(const uint32_t *__restrict__ hdr1, const ui
         const uint2 p = pairs1[k];
         double klo, khi;
         dtw_key_interval(mp, (double)cmat[(size_t)p.x * mPad + p.y], (double)xmin[k], (double)srcMaxSq[p.x],
-                         (double)tgtMaxSq[p.y], srcLen[p.x], tgtLen[p.y], dist ? dist[p.y] : 0.0, klo, khi);
+                         (double)tgtMaxSq[p.y], srcLen[p.x], tgtLen[p.y], dist ? dist[permT[p.y]] : 0.0, klo, khi);
         const double floorv = prev ? __longlong_as_double((long long)prev[p.y]) : -1.0;
         if (khi < __builtin_inf() && khi > floorv)
             atomicMin(&ub[p.y], (unsigned long long)__double_as_longlong(khi));
@@ -255,6 +259,7 @@ __global__ void dtw_stage2_keep_kernel(const uint32_t *__restrict__ hdr1, const 
                                        uint32_t mPad, const double *__restrict__ dist, const int *__restrict__ srcLen,
                                        const float *__restrict__ srcMaxSq, const int *__restrict__ tgtLen,
                                        const float *__restrict__ tgtMaxSq, MarginParams mp,
+                                       const uint32_t *__restrict__ permS, const uint32_t *__restrict__ permT,
                                        const unsigned long long *__restrict__ ub,
                                        const unsigned long long *__restrict__ ub1, uint32_t *__restrict__ hdr2,
                                        uint2 *__restrict__ pairs2)
@@ -264,12 +269,12 @@ __global__ void dtw_stage2_keep_kernel(const uint32_t *__restrict__ hdr1, const 
         const uint2 p = pairs1[k];
         double klo, khi;
         dtw_key_interval(mp, (double)cmat[(size_t)p.x * mPad + p.y], (double)xmin[k], (double)srcMaxSq[p.x],
-                         (double)tgtMaxSq[p.y], srcLen[p.x], tgtLen[p.y], dist ? dist[p.y] : 0.0, klo, khi);
+                         (double)tgtMaxSq[p.y], srcLen[p.x], tgtLen[p.y], dist ? dist[permT[p.y]] : 0.0, klo, khi);
         // ub1 = the stage-1 threshold: never above ub on one GPU, but in a source-sharded run it is
         // the minimum over ALL ranks (ssym_match_begin / _finish) and may undercut this shard's best
         const double thr = fmin(__longlong_as_double((long long)ub[p.y]), __longlong_as_double((long long)ub1[p.y]));
-        if (klo <= thr)
-            pairs2[atomicAdd(&hdr2[0], 1u)] = p;     // list 2 has list 1's capacity: cannot overflow
+        if (klo <= thr)      // list 2 leaves the filter's slot coordinates: (segment, segment) as the caller counts them
+            pairs2[atomicAdd(&hdr2[0], 1u)] = make_uint2(permS[p.x], permT[p.y]);   // list 1's capacity: cannot overflow
     }
 }
 
@@ -580,7 +585,7 @@ int32_t launch_dtw_select2(ssym_ctx *ctx, const SegmentSet &src, const SegmentSe
     const unsigned blocks = std::max(1u, std::min((cap + 255) / 256, 2048u));
     if (k_top <= 1) {
         dtw_stage2_ub_kernel<<<blocks, 256, 0, st>>>(hdr1, pairs1, xmin, cap, cmat, tgt.n_pad, dist_dev, src.len,
-                                                     src.max_sqnorm, tgt.len, tgt.max_sqnorm, mp, nullptr, ub);
+                                                     src.max_sqnorm, tgt.len, tgt.max_sqnorm, mp, tgt.perm, nullptr, ub);
     } else {
         unsigned long long *prev;
         uint32_t *prevIdx;
@@ -589,13 +594,14 @@ int32_t launch_dtw_select2(ssym_ctx *ctx, const SegmentSet &src, const SegmentSe
             return rc;
         for (uint32_t r = 0; r < k_top; ++r) {
             dtw_stage2_ub_kernel<<<blocks, 256, 0, st>>>(hdr1, pairs1, xmin, cap, cmat, tgt.n_pad, dist_dev,
-                                                         src.len, src.max_sqnorm, tgt.len, tgt.max_sqnorm, mp,
+                                                         src.len, src.max_sqnorm, tgt.len, tgt.max_sqnorm, mp, tgt.perm,
                                                          r ? prev : nullptr, ub);
             topk_advance_kernel<<<tb, 256, 0, st>>>(ub, prev, tgt.n, (int)r, r + 1 == k_top);
         }
     }
     dtw_stage2_keep_kernel<<<blocks, 256, 0, st>>>(hdr1, pairs1, xmin, cap, cmat, tgt.n_pad, dist_dev, src.len,
-                                                   src.max_sqnorm, tgt.len, tgt.max_sqnorm, mp, ub, ub1, hdr2, pairs2);
+                                                   src.max_sqnorm, tgt.len, tgt.max_sqnorm, mp, src.perm, tgt.perm, ub, ub1, hdr2,
+                                                   pairs2);
     SSYM_HIP_CHECK(ctx, hipGetLastError());
     return SSYM_OK;
 }
@@ -615,7 +621,7 @@ int32_t launch_dtw_bounds(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
     dim3 grid((tgt.n + 255) / 256, nChunks);
     if (k_top <= 1) {
         dtw_colmin_kernel<<<grid, 256, 0, st>>>(cmat, src.n, tgt.n, tgt.n_pad, dist_dev, src.len,
-                                                src.max_sqnorm, tgt.len, tgt.max_sqnorm, mp, nullptr, ub);
+                                                src.max_sqnorm, tgt.len, tgt.max_sqnorm, mp, tgt.perm, nullptr, ub);
     } else {
         unsigned long long *prev;
         uint32_t *prevIdx;
@@ -624,7 +630,7 @@ int32_t launch_dtw_bounds(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
             return rc;
         for (uint32_t r = 0; r < k_top; ++r) {
             dtw_colmin_kernel<<<grid, 256, 0, st>>>(cmat, src.n, tgt.n, tgt.n_pad, dist_dev, src.len, src.max_sqnorm,
-                                                    tgt.len, tgt.max_sqnorm, mp, r ? prev : nullptr, ub);
+                                                    tgt.len, tgt.max_sqnorm, mp, tgt.perm, r ? prev : nullptr, ub);
             topk_advance_kernel<<<(tgt.n + 255) / 256, 256, 0, st>>>(ub, prev, tgt.n, (int)r, r + 1 == k_top);
         }
     }
@@ -656,7 +662,7 @@ int32_t launch_dtw_select(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
     SSYM_HIP_CHECK(ctx, hipMemsetAsync(cnt, 0, sizeof(uint32_t) * 2 * (size_t)tgt.n, st));
     dim3 grid((tgt.n + 255) / 256, nChunks);
     dtw_mark_kernel<<<grid, 256, 0, st>>>(cmat, src.n, tgt.n, tgt.n_pad, dist_dev, src.len,
-                                          src.max_sqnorm, tgt.len, tgt.max_sqnorm, mp, ub, mask, cnt);
+                                          src.max_sqnorm, tgt.len, tgt.max_sqnorm, mp, tgt.perm, ub, mask, cnt);
     dtw_scan_kernel<<<1, 1024, 0, st>>>(cnt, tgt.n, cap, hdr);
     dtw_scatter_kernel<<<grid, 256, 0, st>>>(mask, tgt.n, cnt, fill, hdr, pairs);
     SSYM_HIP_CHECK(ctx, hipGetLastError());

@@ -59,6 +59,13 @@ struct SegmentSet {
     // f16 operand records, (re)built by dtw_filter.hip whenever the common scale changes
     mutable void *rec = nullptr;    // [n_pad][frames_pad][48] _Float16
     mutable double rec_scale = 0.0;
+    // dtw: record slot p holds segment perm[p]; slots are ordered by segment length so that the
+    // segments sharing a wave / workgroup / target group need about the same rows and columns
+    // (ragged real-world segmentations otherwise pay for the longest member).  len / max_sqnorm
+    // are indexed by slot; pad slots map to 0xffffffff.  Everything outside the filter, certify and
+    // selection kernels keeps the caller's indices.
+    uint32_t *perm = nullptr;
+    std::vector<uint32_t> h_perm;
     mutable size_t rec_bytes = 0;
     mutable uint32_t rec_slots = 0;   // record slots per segment in `rec`
     mutable int rec_lead = 0;         // slot of frame 0 (-1: end-aligned)

@@ -26,22 +26,24 @@ int run(int N, int M, int F, int reps, int blocksPerCU)
     for (auto &v : hs) v = (_Float16)(4.0f * rnd());
     for (auto &v : ht) v = (_Float16)(4.0f * rnd());
     std::vector<int> ls(N, F), lt(M, F);
-    _Float16 *ds, *dt; float *dc, *dc2, *dh; int *dls, *dlt;
+    _Float16 *ds, *dt; float *dc, *dc2, *dh; int *dls, *dlt; unsigned *dctr;
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
     const int grid = prop.multiProcessorCount * blocksPerCU / 8 * 8;
     CK(hipMalloc(&ds, hs.size() * 2)); CK(hipMalloc(&dt, ht.size() * 2));
     CK(hipMalloc(&dc, (size_t)N * M * 4)); CK(hipMalloc(&dc2, (size_t)N * M * 4)); CK(hipMalloc(&dls, N * 4)); CK(hipMalloc(&dlt, M * 4));
     CK(hipMalloc(&dh, (size_t)grid * kFilterWavesPerBlock * F * 64 * 4));
+    CK(hipMalloc(&dctr, 8 * sizeof(unsigned)));
     CK(hipMemcpy(ds, hs.data(), hs.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(dt, ht.data(), ht.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(dls, ls.data(), N * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dlt, lt.data(), M * 4, hipMemcpyHostToDevice));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    const int nSrcBlocks = N / (2 * kFilterWavesPerBlock);
-    const int nTasks = nSrcBlocks * (M / 32);
+    const int nSrcPairs = N / 2;
+    const int nTasks = nSrcPairs * (M / 32);
     auto launch = [&]() {
-        dtw_filter_kernel<NT, SSYM_TOOL_SQ><<<grid, 64 * kFilterWavesPerBlock>>>(ds, dt, dls, dlt, rows, nPasses, F, M, nSrcBlocks,
-                                                                         nTasks, 1.0f, dh, dc);
+        (void)hipMemsetAsync(dctr, 0, 8 * sizeof(unsigned), 0);
+        dtw_filter_kernel<NT, SSYM_TOOL_SQ><<<grid, 64 * kFilterWavesPerBlock>>>(ds, dt, dls, dlt, rows, nPasses, F, M, nSrcPairs,
+                                                                         nTasks, 1.0f, dh, dctr, dc);
     };
     for (int w = 0; w < 2; ++w) launch();
     CK(hipDeviceSynchronize());
