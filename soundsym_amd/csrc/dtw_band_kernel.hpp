@@ -29,7 +29,7 @@ template <int NTB, int WB, int OCC, bool SQ, int LASTN>
 __global__ __launch_bounds__(64 * WB, OCC) void dtw_band_kernel(
     const _Float16 *__restrict__ srcRec, const _Float16 *__restrict__ tgtRec,
     const int *__restrict__ srcLen, const int *__restrict__ tgtLen, int srcSlots, int radius,
-    int tgtFramesPad, int mPad, int nTgtBlocks, int nTasks, int tasksPerBlock, float outScale,
+    int tgtFramesPad, int mPad, int nTgtBlocks, int nTasks, unsigned *__restrict__ taskCtr, float outScale,
     float *__restrict__ cmat)
 {
     constexpr int REC = kFilterRecHalfs;
@@ -49,22 +49,31 @@ __global__ __launch_bounds__(64 * WB, OCC) void dtw_band_kernel(
     const int a_local = (arow & 3) + 4 * (arow >> 3);
     const _Float16 *const aLane = ldsSrc + ((size_t)a_h * srcSlots + a_local) * REC + half * 24;
 
-    int curSp = -1;
-    const int t0 = blockIdx.x * tasksPerBlock;
-    const int t1 = min(t0 + tasksPerBlock, nTasks);
-    for (int task = t0; task < t1; ++task) {
-        const int sp = task / nTgtBlocks;              // source pair (tasks are sp-major)
-        const int tg = (task % nTgtBlocks) * WB + wave;
-        if (sp != curSp) {                             // workgroup-uniform
-            __syncthreads();                           // everyone is done with the previous pair
+    // Workgroups take SOURCE PAIRS from one counter, longest first (record slots are ordered by segment
+    // length, so the list is walked from its end), and sweep all target blocks against the pair while
+    // it sits in LDS.  (Handing out single (pair, target block) tasks instead cost 8 % at r = 32: the
+    // pair was re-staged for every task.)
+    __shared__ unsigned sTask;
+    const int nPairs = nTasks / nTgtBlocks;
+    for (;;) {
+        __syncthreads();                               // everyone has read the previous sTask and left LDS
+        if (threadIdx.x == 0)
+            sTask = atomicAdd(taskCtr, 1u);
+        __syncthreads();
+        const unsigned got = sTask;
+        if (got >= (unsigned)nPairs)
+            break;
+        const int sp = nPairs - 1 - (int)got;
+        {
             const uint4 *g = reinterpret_cast<const uint4 *>(srcRec + (size_t)(2 * sp) * srcSlots * REC);
             uint4 *l = reinterpret_cast<uint4 *>(ldsSrc);
             const int n16 = 2 * srcSlots * REC * 2 / 16;
             for (int i = threadIdx.x; i < n16; i += 64 * WB)
                 l[i] = g[i];
             __syncthreads();
-            curSp = sp;
         }
+      for (int tb = nTgtBlocks - 1; tb >= 0; --tb) {
+        const int tg = tb * WB + wave;
 
         const int fa = srcLen[2 * sp + half];
         const int fb_m1 = tgtLen[32 * tg + col] - 1;
@@ -151,6 +160,7 @@ __global__ __launch_bounds__(64 * WB, OCC) void dtw_band_kernel(
             }
         }
         cmat[(size_t)(2 * sp + half) * mPad + 32 * tg + col] = res * outScale;
+      }
     }
 }
 

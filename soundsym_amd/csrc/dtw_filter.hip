@@ -113,7 +113,7 @@ bool filter_supported(const ssym_ctx *ctx, const SegmentSet &src, const SegmentS
         // banded kernel: 2r+1 diagonals in registers (<= 6 tiles) and the source pair in LDS
         if (2 * ctx->band + 1 > 6 * 16)
             return false;
-        if (band_lds_bytes(ctx->band, src, tgt) > 160 * 1024)
+        if (band_lds_bytes(ctx->band, src, tgt) > 160 * 1024 - 64)      // + the kernel's few static bytes
             return false;
     } else if (filter_shape((int)src.max_frames).nt == 0) {
         return false;   // more than 4096 source frames
@@ -183,13 +183,17 @@ static int32_t launch_band_cfg(ssym_ctx *ctx, const SegmentSet &src, const Segme
     const int nTgtBlocks = (int)tgt.n_pad / (32 * WB);
     const int nTasks = ((int)src.n_pad / 2) * nTgtBlocks;
     const int grid = std::max(1, std::min(ctx->num_cus, nTasks));
-    const int tasksPerBlock = (nTasks + grid - 1) / grid;
+    int32_t rc = ensure(ctx, ctx->handoff, 8 * sizeof(unsigned));      // the banded kernel's task counter
+    if (rc != SSYM_OK)
+        return rc;
+    unsigned *taskCtr = (unsigned *)ctx->handoff.ptr;
+    SSYM_HIP_CHECK(ctx, hipMemsetAsync(taskCtr, 0, sizeof(unsigned), ctx->stream));
     auto kern = dtw_band_kernel<NTB, WB, OCC, SQ, LASTN>;
     if (lds > 64 * 1024)
         SSYM_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     kern<<<dim3(grid), 64 * WB, lds, ctx->stream>>>(
         (const _Float16 *)src.rec, (const _Float16 *)tgt.rec, src.len, tgt.len, (int)slots, ctx->band,
-        (int)tgt.frames_pad, (int)tgt.n_pad, nTgtBlocks, nTasks, tasksPerBlock, outScale, cmat);
+        (int)tgt.frames_pad, (int)tgt.n_pad, nTgtBlocks, nTasks, taskCtr, outScale, cmat);
     SSYM_HIP_CHECK(ctx, hipGetLastError());
     return SSYM_OK;
 }
