@@ -126,8 +126,8 @@ def secondary_metrics(device: int, with_cpu: bool) -> dict:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the refcos / chain / mfcc measurements reported beside the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
