@@ -172,6 +172,166 @@ __global__ __launch_bounds__(64) void dtw_exact_kernel(
     }
 }
 
+// Variant for frames of at most DIMR values (DIMR = 16 covers the 12 / 13-coefficient features of
+// the reference and the north star, DIMR = 48 the 40-dimensional configuration).  Same wavefront,
+// same operation order, but
+//   * the lane's own source frame sits in REGISTERS for the whole chunk (it was re-read from LDS at
+//     every step), padded with zeros up to DIMR;
+//   * target frames are staged in LDS zero-padded to DIMR values, rows of DIMR + 2 doubles (16-byte
+//     aligned and, for 128-bit reads by consecutive lanes, bank-conflict free), so a step issues
+//     DIMR / 2 unconditional ds_read_b128 back to back -- the generic kernel waited for LDS after
+//     every two values -- and the loads of step tau + 1 are in flight while step tau computes;
+//   * (0 - 0)^2 = +0.0 added to a non-negative sum leaves it unchanged bit for bit, so the padding
+//     does not alter the result.
+template <int DIMR>
+__global__ __launch_bounds__(64) void dtw_exact_reg_kernel(
+    const double *__restrict__ srcRaw, const uint64_t *__restrict__ srcOff,
+    const double *__restrict__ tgtRaw, const uint64_t *__restrict__ tgtOff, uint32_t nSrc,
+    uint32_t nTgt, uint32_t dim, int band, int squared, const uint2 *__restrict__ pairs,
+    const uint32_t *__restrict__ countDev, uint32_t maxPairs, uint32_t fbCap,
+    double *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int LD = DIMR + 2;
+    double *bound0 = smem;                       // [fbCap]
+    double *bound1 = smem + fbCap;               // [fbCap]
+    double *ldsB = smem + 2 * (size_t)fbCap;     // [fbCap][LD], fbCap is even so rows stay 16-byte aligned
+    const double INF = __builtin_inf();
+    const int lane = threadIdx.x;
+
+    uint64_t total;
+    if (pairs) {
+        uint32_t c = *countDev;
+        total = c < maxPairs ? c : maxPairs;
+    } else {
+        total = (uint64_t)nSrc * nTgt;
+    }
+    for (uint64_t k = blockIdx.x; k < total; k += gridDim.x) {
+        uint32_t s, t;
+        if (pairs) {
+            uint2 p = pairs[k];
+            s = p.x;
+            t = p.y;
+        } else {
+            s = (uint32_t)(k / nTgt);
+            t = (uint32_t)(k % nTgt);
+        }
+        const int Fa = (int)(srcOff[s + 1] - srcOff[s]);
+        const int Fb = (int)(tgtOff[t + 1] - tgtOff[t]);
+        const double *a0 = srcRaw + srcOff[s] * dim;
+        const double *b0 = tgtRaw + tgtOff[t] * dim;
+        if (Fa == 0 || Fb == 0) {
+            if (lane == 0)
+                out[k] = INF;
+            continue;
+        }
+        __syncthreads();   // previous pair's LDS reads are done
+        if (band < 0)
+            for (int i = lane; i < Fb * DIMR; i += 64) {
+                const int fr = i / DIMR, e = i % DIMR;
+                ldsB[(size_t)fr * LD + e] = e < (int)dim ? b0[(size_t)fr * dim + e] : 0.0;
+            }
+        double result = INF;
+        int chunk = 0;
+        for (int c0 = 0; c0 < Fa; c0 += 64, ++chunk) {
+            const int r = c0 + lane;
+            const bool rowValid = r < Fa;
+            const int rowsHere = min(64, Fa - c0);
+            double ar[DIMR];
+            {
+                const double *arow = a0 + (size_t)(rowValid ? r : c0) * dim;
+#pragma unroll
+                for (int e = 0; e < DIMR; ++e)
+                    ar[e] = e < (int)dim ? arow[e] : 0.0;
+            }
+            const double *boundPrev = (chunk & 1) ? bound0 : bound1;
+            double *boundCur = (chunk & 1) ? bound1 : bound0;
+            int jlo = 0, jhi = Fb - 1;
+            if (band >= 0) {
+                jlo = max(0, c0 - band);
+                jhi = min(Fb - 1, c0 + rowsHere - 1 + band);
+            }
+            // banded: only the columns this chunk can reach are staged (frame j at row j - wlo), so long
+            // targets with wide frames still fit a few workgroups per CU
+            const int wlo = band >= 0 ? jlo : 0, whi = band >= 0 ? jhi : Fb - 1;
+            if (band >= 0) {
+                __syncthreads();   // the previous chunk's window is no longer read
+                for (int i = lane; i < (whi - wlo + 1) * DIMR; i += 64) {
+                    const int fr = i / DIMR, e = i % DIMR;
+                    ldsB[(size_t)fr * LD + e] = e < (int)dim ? b0[(size_t)(wlo + fr) * dim + e] : 0.0;
+                }
+            }
+            for (int j = lane; j < Fb; j += 64)
+                boundCur[j] = INF;
+            __syncthreads();       // staged frames, cleared boundary, previous chunk's boundary row visible
+
+            double mine = INF;      // D(r, j-1)
+            double diagReg = INF;   // D(r-1, j-1)
+            const int tauEnd = jhi + rowsHere;     // exclusive: lane l works on column tau - l
+            typedef double d2 __attribute__((ext_vector_type(2)));
+            d2 bv[DIMR / 2], bn[DIMR / 2];
+            {
+                const int jc = min(max(jlo - lane, wlo), whi) - wlo;
+                const d2 *bp = reinterpret_cast<const d2 *>(ldsB + (size_t)jc * LD);
+#pragma unroll
+                for (int e = 0; e < DIMR / 2; ++e)
+                    bn[e] = bp[e];
+            }
+            for (int tau = jlo; tau < tauEnd; ++tau) {
+                const int j = tau - lane;
+#pragma unroll
+                for (int e = 0; e < DIMR / 2; ++e)
+                    bv[e] = bn[e];
+                {   // next step's frame (clamped to a valid row; unused when out of range)
+                    const int jc = min(max(j + 1, wlo), whi) - wlo;
+                    const d2 *bp = reinterpret_cast<const d2 *>(ldsB + (size_t)jc * LD);
+#pragma unroll
+                    for (int e = 0; e < DIMR / 2; ++e)
+                        bn[e] = bp[e];
+                }
+                double fromAbove = shfl_up1(mine);        // D(r-1, j) for lanes >= 1
+                double diagv = diagReg;
+                if (lane == 0) {
+                    if (c0 == 0) {
+                        fromAbove = INF;
+                        diagv = (j == 0) ? 0.0 : INF;     // virtual D(-1,-1) = 0
+                    } else {
+                        fromAbove = (j >= 0 && j < Fb) ? boundPrev[j] : INF;
+                        diagv = (j >= 1 && j <= Fb) ? boundPrev[j - 1] : INF;
+                    }
+                }
+                // sum_k (a_k - b_k)^2, k ascending, sub / mul / add rounded separately (the oracle's order)
+                double acc = 0.0;
+#pragma unroll
+                for (int e = 0; e < DIMR; ++e) {
+                    const double df = __dsub_rn(ar[e], bv[e >> 1][e & 1]);
+                    acc = __dadd_rn(acc, __dmul_rn(df, df));
+                }
+                const double c = squared ? acc : sqrt(acc);
+                const bool active = rowValid && j >= 0 && j < Fb;
+                if (active) {
+                    double cur = INF;
+                    const int dij = r - j;
+                    if (band < 0 || (dij <= band && -dij <= band)) {
+                        double best = fromAbove;              // D(i-1, j)
+                        if (mine < best) best = mine;         // D(i,   j-1)
+                        if (diagv < best) best = diagv;       // D(i-1, j-1)
+                        cur = __dadd_rn(c, best);
+                    }
+                    if (lane == 63)
+                        boundCur[j] = cur;
+                    if (r == Fa - 1 && j == Fb - 1)
+                        result = cur;
+                    mine = cur;
+                }
+                diagReg = fromAbove;
+            }
+        }
+        if ((Fa - 1) % 64 == lane)
+            out[k] = result;
+    }
+}
+
 int32_t launch_dtw_exact(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt,
                          const uint2 *pairs, const uint32_t *count_dev, uint32_t max_pairs,
                          double *out)
@@ -188,14 +348,32 @@ int32_t launch_dtw_exact(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet 
         ctx->err = "dtw exact: target segment too long (boundary row does not fit LDS)";
         return SSYM_E_UNSUPPORTED;
     }
-    const bool ldsFrames = boundBytes + frameBytes <= 64 * 1024;
-    const size_t lds = boundBytes + (ldsFrames ? frameBytes : 0);
     uint64_t total = pairs ? max_pairs : (uint64_t)src.n * tgt.n;
     if (total == 0)
         return SSYM_OK;
     // enough single-wave blocks to fill the chip several times over; grid-stride covers the rest
     unsigned grid = (unsigned)std::min<uint64_t>(total, (uint64_t)ctx->num_cus * 64);
     hipStream_t st = ctx->stream;
+    // frames of up to 48 values: source frame in registers, target frames zero-padded in LDS
+    const uint32_t fbEven = (fbCap + 1) & ~1u;
+    const int dimr = dim <= 16 ? 16 : (dim <= 48 ? 48 : 0);
+    // staged target rows: all of them, or (banded) the widest window a 64-row chunk can reach
+    const uint32_t winRows = ctx->band >= 0 ? std::min<uint32_t>(fbEven, 64 + 2 * (uint32_t)ctx->band + 2) : fbEven;
+    const size_t regLds = 2 * (size_t)fbEven * sizeof(double) + (size_t)winRows * (dimr + 2) * sizeof(double);
+    if (dimr && regLds <= 64 * 1024) {
+        if (dimr == 16)
+            dtw_exact_reg_kernel<16><<<grid, 64, regLds, st>>>(src.raw, src.off, tgt.raw, tgt.off, src.n, tgt.n, dim,
+                                                              ctx->band, ctx->squared, pairs, count_dev, max_pairs,
+                                                              fbEven, out);
+        else
+            dtw_exact_reg_kernel<48><<<grid, 64, regLds, st>>>(src.raw, src.off, tgt.raw, tgt.off, src.n, tgt.n, dim,
+                                                              ctx->band, ctx->squared, pairs, count_dev, max_pairs,
+                                                              fbEven, out);
+        SSYM_HIP_CHECK(ctx, hipGetLastError());
+        return SSYM_OK;
+    }
+    const bool ldsFrames = boundBytes + frameBytes <= 64 * 1024;
+    const size_t lds = boundBytes + (ldsFrames ? frameBytes : 0);
     if (ldsFrames)
         dtw_exact_kernel<true><<<grid, 64, lds, st>>>(src.raw, src.off, tgt.raw, tgt.off, src.n, tgt.n,
                                                      dim, ctx->band, ctx->squared, pairs, count_dev,

@@ -77,5 +77,8 @@ int main(int argc, char **argv)
     VARIANT(2, 128, 3);     // 3: 4 passes of 32 rows, 3 waves/SIMD
     VARIANT(2, 128, 2);     // 4: same, 2 waves/SIMD
     VARIANT(4, 256, 2);     // 5: 256 frames = 4 passes
+    VARIANT(3, 48, 2);      // 6: 48 frames, one pass
+    VARIANT(2, 32, 2);      // 7: 32 frames, one pass
+    VARIANT(1, 16, 2);      // 8: 16 frames, one pass
     return 0;
 }
