@@ -172,13 +172,13 @@ __global__ __launch_bounds__(64) void dtw_exact_kernel(
     }
 }
 
-// Variant for frames of at most DIMR values (DIMR = 16 covers the 12 / 13-coefficient features of
-// the reference and the north star, DIMR = 48 the 40-dimensional configuration).  Same wavefront,
+// Variant for frames of at most DIMR values (instantiated for 12, 14, 16, 40 and 48: the 12 / 13
+// coefficients of the reference and the north star, and the 40-dimensional configuration).  Same wavefront,
 // same operation order, but
 //   * the lane's own source frame sits in REGISTERS for the whole chunk (it was re-read from LDS at
 //     every step), padded with zeros up to DIMR;
-//   * target frames are staged in LDS zero-padded to DIMR values, rows of DIMR + 2 doubles (16-byte
-//     aligned and, for 128-bit reads by consecutive lanes, bank-conflict free), so a step issues
+//   * target frames are staged in LDS zero-padded to DIMR values, rows of LD = 2 (mod 4) doubles
+//     (16-byte aligned and, for 128-bit reads by consecutive lanes, bank-conflict free), so a step issues
 //     DIMR / 2 unconditional ds_read_b128 back to back -- the generic kernel waited for LDS after
 //     every two values -- and the loads of step tau + 1 are in flight while step tau computes;
 //   * (0 - 0)^2 = +0.0 added to a non-negative sum leaves it unchanged bit for bit, so the padding
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(64) void dtw_exact_reg_kernel(
     double *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    constexpr int LD = DIMR + 2;
+    constexpr int LD = (DIMR % 4 == 2) ? DIMR : DIMR + 2;     // = 2 mod 4 doubles: see above
     double *bound0 = smem;                       // [fbCap]
     double *bound1 = smem + fbCap;               // [fbCap]
     double *ldsB = smem + 2 * (size_t)fbCap;     // [fbCap][LD], fbCap is even so rows stay 16-byte aligned
@@ -356,19 +356,24 @@ int32_t launch_dtw_exact(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet 
     hipStream_t st = ctx->stream;
     // frames of up to 48 values: source frame in registers, target frames zero-padded in LDS
     const uint32_t fbEven = (fbCap + 1) & ~1u;
-    const int dimr = dim <= 16 ? 16 : (dim <= 48 ? 48 : 0);
+    const int dimr = dim <= 12 ? 12 : dim <= 14 ? 14 : dim <= 16 ? 16 : dim <= 40 ? 40 : dim <= 48 ? 48 : 0;
+    const int ldr = (dimr % 4 == 2) ? dimr : dimr + 2;
     // staged target rows: all of them, or (banded) the widest window a 64-row chunk can reach
     const uint32_t winRows = ctx->band >= 0 ? std::min<uint32_t>(fbEven, 64 + 2 * (uint32_t)ctx->band + 2) : fbEven;
-    const size_t regLds = 2 * (size_t)fbEven * sizeof(double) + (size_t)winRows * (dimr + 2) * sizeof(double);
+    const size_t regLds = 2 * (size_t)fbEven * sizeof(double) + (size_t)winRows * ldr * sizeof(double);
     if (dimr && regLds <= 64 * 1024) {
-        if (dimr == 16)
-            dtw_exact_reg_kernel<16><<<grid, 64, regLds, st>>>(src.raw, src.off, tgt.raw, tgt.off, src.n, tgt.n, dim,
-                                                              ctx->band, ctx->squared, pairs, count_dev, max_pairs,
-                                                              fbEven, out);
-        else
-            dtw_exact_reg_kernel<48><<<grid, 64, regLds, st>>>(src.raw, src.off, tgt.raw, tgt.off, src.n, tgt.n, dim,
-                                                              ctx->band, ctx->squared, pairs, count_dev, max_pairs,
-                                                              fbEven, out);
+#define SSYM_EXACT_REG(D_)                                                                                     \
+    dtw_exact_reg_kernel<D_><<<grid, 64, regLds, st>>>(src.raw, src.off, tgt.raw, tgt.off, src.n, tgt.n, dim,   \
+                                                       ctx->band, ctx->squared, pairs, count_dev, max_pairs,   \
+                                                       fbEven, out)
+        switch (dimr) {
+        case 12: SSYM_EXACT_REG(12); break;
+        case 14: SSYM_EXACT_REG(14); break;
+        case 16: SSYM_EXACT_REG(16); break;
+        case 40: SSYM_EXACT_REG(40); break;
+        default: SSYM_EXACT_REG(48); break;
+        }
+#undef SSYM_EXACT_REG
         SSYM_HIP_CHECK(ctx, hipGetLastError());
         return SSYM_OK;
     }
