@@ -267,7 +267,7 @@ int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
     // task & 7 is the XCD group; one hand-off row of [target frames][64] floats per wave
     const int gridBlocks = std::max(8, ctx->num_cus * 2 / 8 * 8);
     // + 8 task counters behind the hand-off rows
-    const size_t handBytes = (size_t)gridBlocks * kFilterWavesPerBlock * tgt.frames_pad * 64 * sizeof(float);
+    const size_t handBytes = (size_t)gridBlocks * kFilterWavesPerBlock * ((tgt.frames_pad + 3) / 4) * 256 * sizeof(float);
     rc = ensure(ctx, ctx->handoff, handBytes + 8 * sizeof(unsigned));
     if (rc != SSYM_OK)
         return rc;

@@ -31,9 +31,9 @@
 //     persistent); pass p+1 reads it back as its top boundary.  Waves never synchronise with each
 //     other -- a first version that pipelined row blocks across waves with one workgroup barrier
 //     per column spent half of its wave-cycles waiting (profiles/);
-//   * target records (group-major, 1 KB per MFMA operand plane per column) and the hand-off row
-//     reach the wave through a per-wave LDS ring filled by global_load_lds DMA three columns
-//     ahead of use: loads in flight hold no registers (the kernel sits at the 256-VGPR limit of two
+//   * target records (group-major, 1 KB per MFMA operand plane per column) reach the wave through a
+//     per-wave LDS ring filled by global_load_lds DMA three columns ahead of use, the hand-off row
+//     four columns per 16-byte access (one store and one DMA per FOUR columns): loads in flight hold no registers (the kernel sits at the 256-VGPR limit of two
 //     waves per SIMD) and s_waitcnt vmcnt(6) at the top of a column never waits for a young load;
 //   * measured on MI355X (rocprofv3 PMC): plain VALU instructions occupy the SIMD for 4 cycles,
 //     v_sqrt_f32 for 8, whatever the occupancy -- 16 cycles per cell is the floor of this
@@ -145,7 +145,9 @@ __device__ __forceinline__ float dp_column(const half8 (&A)[NT][kFilterKM], cons
 
 constexpr int kFilterWavesPerBlock = 4;
 constexpr int kFilterRing = 4;                                  // target columns staged in LDS per wave
-constexpr int kFilterSlotBytes = kFilterKM * 1024 + 256;        // 64 lanes x (3 x 16 B operands + 1 float)
+constexpr int kFilterSlotBytes = kFilterKM * 1024;              // 64 lanes x 3 x 16 B operands of one column
+constexpr int kFilterTopBytes = 2 * 1024;                       // hand-off values of 2 groups of 4 columns
+constexpr int kFilterWaveLds = kFilterRing * kFilterSlotBytes + kFilterTopBytes;
 // s_waitcnt immediates (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14])
 constexpr int kWaitVm6 = 0x0F76;                                // vmcnt(6), nothing else
 constexpr int kWaitVm9 = 0x0F79;                                // vmcnt(9)
@@ -167,11 +169,14 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, 2) void dtw_filter_kerne
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int col = lane & 31;         // output column: target 32*tg + col
     const int half = lane >> 5;        // operand role: K half; output role: source 2*sp + half
-    // this wave's hand-off row, [tgtFramesPad][64] floats (wave-uniform base + lane offset)
-    char *const handRow = reinterpret_cast<char *>(handoff + ((size_t)blockIdx.x * kFilterWavesPerBlock + wave) * (size_t)tgtFramesPad * 64);
-    const uint32_t laneOff16 = lane * 16, laneOff4 = lane * 4;
-    __shared__ __attribute__((aligned(16))) char ring[kFilterWavesPerBlock][kFilterRing * kFilterSlotBytes];
+    // this wave's hand-off row, [ceil(tgtFramesPad / 4)][64 lanes][4 columns] floats: one 16-byte
+    // access per lane moves FOUR columns (a store and a DMA per column cost ~6 % of the kernel)
+    const size_t handGroups = ((size_t)tgtFramesPad + 3) / 4;
+    char *const handRow = reinterpret_cast<char *>(handoff + ((size_t)blockIdx.x * kFilterWavesPerBlock + wave) * handGroups * 256);
+    const uint32_t laneOff16 = lane * 16;
+    __shared__ __attribute__((aligned(16))) char ring[kFilterWavesPerBlock][kFilterWaveLds];
     char *const myRing = ring[wave];
+    char *const myTop = myRing + kFilterRing * kFilterSlotBytes;
 
     // Work distribution: a task is one wave's (source pair, target group) = 64 pairs; waves take
     // tasks from 8 counters, one per XCD group (workgroups b, b+8, ... share an XCD and gridDim.x is a
@@ -242,10 +247,13 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, 2) void dtw_filter_kerne
                 __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 0);
                 __builtin_amdgcn_global_load_lds(gp, lp, 16, 1024, 0);
                 __builtin_amdgcn_global_load_lds(gp, lp, 16, 2048, 0);
-                if (haveTop)
-                    __builtin_amdgcn_global_load_lds(
-                        (const __attribute__((address_space(1))) void *)(handRow + (ptrdiff_t)cc * 256 - kFilterKM * 1024 + laneOff4),
-                        (__attribute__((address_space(3))) void *)slot, 4, kFilterKM * 1024, 0);
+            };
+            // hand-off values of column group g (4 columns) -> top buffer g & 1
+            auto stageTop = [&](int g) {
+                const int gg = min(g, (nCols - 1) >> 2);
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(handRow + (size_t)gg * 1024 + laneOff16),
+                    (__attribute__((address_space(3))) void *)(myTop + (g & 1) * 1024), 16, 0, 0);
             };
             auto fetch = [&](int c, half8 (&B)[kFilterKM], float &top) {
                 const char *slot = myRing + (c & (kFilterRing - 1)) * kFilterSlotBytes;
@@ -253,9 +261,8 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, 2) void dtw_filter_kerne
                 for (int m = 0; m < kFilterKM; ++m)
                     B[m] = *reinterpret_cast<const half8 *>(slot + m * 1024 + lane * 16);
                 // read unconditionally (no branch, no wait at a block end); unused when !haveTop
-                top = *reinterpret_cast<const float *>(slot + kFilterKM * 1024 + lane * 4);
+                top = *reinterpret_cast<const float *>(myTop + ((c >> 2) & 1) * 1024 + lane * 16 + (c & 3) * 4);
             };
-
             // A operands of this pass: the pad rows above a source carry |a|^2 = +inf
             half8 A[NT][kFilterKM];
             {
@@ -269,6 +276,8 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, 2) void dtw_filter_kerne
             }
 
             asm volatile("" ::: "memory");      // A loads are issued (program order) before the staging DMAs
+            if (haveTop)
+                stageTop(0);
 #pragma unroll
             for (int c = 0; c < kFilterRing; ++c)
                 stage(c);
@@ -293,39 +302,48 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, 2) void dtw_filter_kerne
             fetch(0, B0, topN);
             f32x16 acc = mfma_tile<kFilterKM>(A[0], B0);
 
-            for (int j0 = 0; j0 < nCols; j0 += 2) {
+            float bq[4] = {INF, INF, INF, INF};                     // bottoms of the current group of 4 columns
+            for (int j0 = 0; j0 < nCols; j0 += 4) {
 #pragma unroll
-                for (int par = 0; par < 2; ++par) {
-                    const int j = j0 + par;
+                for (int q = 0; q < 4; ++q) {
+                    const int j = j0 + q;
                     if (j < nCols) {                                // wave-uniform
                         const float up = haveTop ? topN : INF;
                         const float diag = (j == 0) ? diagCol0 : prevTop;
                         prevTop = up;
                         // column j+1 was staged kFilterRing - 1 columns ago; at least the two
-                        // groups after it (>= 6 DMAs) are younger, so vmcnt(6) covers it
+                        // groups after it (>= 6 DMAs) are younger, so vmcnt(6) covers it -- and the
+                        // hand-off group it may open, which was requested four columns ago
                         __builtin_amdgcn_s_waitcnt(kWaitVm6);
                         asm volatile("" ::: "memory");
-                        if (par == 0)
+                        if ((q & 1) == 0)
                             fetch(j + 1, B1, topN);
                         else
                             fetch(j + 1, B0, topN);
 #ifndef SSYM_ABL_NOSTAGE
                         stage(j + kFilterRing);                     // into the slot column j just left
 #endif
+                        if (q == 0 && haveTop)
+                            stageTop((j >> 2) + 1);                 // the next group's top values
                         float bottom;
-                        if (par == 0)
+                        if ((q & 1) == 0)
                             bottom = dp_column<NT, SQ>(A, B0, B1, acc, up, diag, L0, L1);
                         else
                             bottom = dp_column<NT, SQ>(A, B1, B0, acc, up, diag, L1, L0);
+                        bq[q] = bottom;
+                        if (!lastPass) {
 #ifndef SSYM_ABL_NOHAND
-                        if (!lastPass)
-                            *reinterpret_cast<float *>(handRow + (size_t)j * 256 + laneOff4) = bottom;   // top boundary of the next pass
+                            if (q == 3 || j == nCols - 1) {         // top boundary of the next pass, 4 columns at a time
+                                typedef float f32x4 __attribute__((ext_vector_type(4)));
+                                *reinterpret_cast<f32x4 *>(handRow + (size_t)(j >> 2) * 1024 + laneOff16) =
+                                    f32x4{bq[0], bq[1], bq[2], bq[3]};
+                            }
 #else
-                        if (!lastPass)
                             res = (j == fb_m1 - 1) ? bottom : res;
 #endif
-                        else
+                        } else {
                             res = (j == fb_m1) ? bottom : res;      // D(fa-1, fb-1)
+                        }
                     }
                 }
             }
