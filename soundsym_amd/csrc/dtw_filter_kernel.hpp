@@ -27,7 +27,7 @@
 //   * a wave keeps 16*NT rows of the column in registers; longer sources are processed in row-block
 //     PASSES by the same wave: pass p sweeps all columns for rows [p*16*NT, (p+1)*16*NT) and leaves
 //     the bottom row of its block, D(last row, j), in a per-wave hand-off row in global memory
-//     (256 coalesced bytes per column, L2 / Infinity-Cache resident because the grid is
+//     (1 KB per four columns, L2 / Infinity-Cache resident because the grid is
 //     persistent); pass p+1 reads it back as its top boundary.  Waves never synchronise with each
 //     other -- a first version that pipelined row blocks across waves with one workgroup barrier
 //     per column spent half of its wave-cycles waiting (profiles/);
