@@ -171,9 +171,16 @@ static void launch_one(hipStream_t st, const SegmentSet &src, const SegmentSet &
     const int nTgtGroups = (int)tgt.n_pad / 32;
     const int nTasks = nSrcPairs * nTgtGroups;            // one wave's 64 pairs each
     const int blocksWanted = (nTasks + kFilterWavesPerBlock - 1) / kFilterWavesPerBlock;
-    dtw_filter_kernel<NT, SQ><<<dim3(std::min(gridBlocks, (blocksWanted + 7) / 8 * 8)), 64 * kFilterWavesPerBlock, 0, st>>>(
+    const int grid = std::min(gridBlocks, (blocksWanted + 7) / 8 * 8);
+    // tasks per grab: several SHORT tasks at a time so that the L2 atomics stay invisible (at 16 frames a
+    // task is ~1 us of work), one at a time once a task is long enough to matter for the tail; always
+    // at least 16 grabs per wave
+    const long cellsPerTask = (long)src.frames_pad * std::max<uint32_t>(tgt.max_frames, 1);
+    int taskChunk = (int)std::max(1L, std::min(8L, 8192 / std::max(1L, cellsPerTask)));
+    taskChunk = std::max(1, std::min(taskChunk, nTasks / (grid * kFilterWavesPerBlock * 16)));
+    dtw_filter_kernel<NT, SQ><<<dim3(grid), 64 * kFilterWavesPerBlock, 0, st>>>(
         (const _Float16 *)src.rec, (const _Float16 *)tgt.rec, src.len, tgt.len, (int)src.frames_pad, nPasses,
-        (int)tgt.frames_pad, (int)tgt.n_pad, nSrcPairs, nTasks, outScale, handoff, taskCtr, cmat);
+        (int)tgt.frames_pad, (int)tgt.n_pad, nSrcPairs, nTasks, taskChunk, outScale, handoff, taskCtr, cmat);
 }
 
 template <int NTB, int WB, int OCC, bool SQ, int LASTN>
@@ -268,11 +275,11 @@ int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
     const int gridBlocks = std::max(8, ctx->num_cus * 2 / 8 * 8);
     // + 8 task counters behind the hand-off rows
     const size_t handBytes = (size_t)gridBlocks * kFilterWavesPerBlock * ((tgt.frames_pad + 3) / 4) * 256 * sizeof(float);
-    rc = ensure(ctx, ctx->handoff, handBytes + 8 * sizeof(unsigned));
+    rc = ensure(ctx, ctx->handoff, handBytes + 8 * kTaskCtrStride * sizeof(unsigned));
     if (rc != SSYM_OK)
         return rc;
     unsigned *taskCtr = (unsigned *)((char *)ctx->handoff.ptr + handBytes);
-    SSYM_HIP_CHECK(ctx, hipMemsetAsync(taskCtr, 0, 8 * sizeof(unsigned), ctx->stream));
+    SSYM_HIP_CHECK(ctx, hipMemsetAsync(taskCtr, 0, 8 * kTaskCtrStride * sizeof(unsigned), ctx->stream));
     hipStream_t st = ctx->stream;
     const bool sq = ctx->squared != 0;
     const float outScale = (float)(sq ? 1.0 / (scale * scale) : 1.0 / scale);

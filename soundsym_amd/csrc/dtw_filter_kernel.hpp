@@ -144,6 +144,7 @@ __device__ __forceinline__ float dp_column(const half8 (&A)[NT][kFilterKM], cons
 }
 
 constexpr int kFilterWavesPerBlock = 4;
+constexpr int kTaskCtrStride = 64;      // the 8 task counters sit in separate 256-byte lines (separate L2 channels)
 constexpr int kFilterRing = 4;                                  // target columns staged in LDS per wave
 constexpr int kFilterSlotBytes = kFilterKM * 1024;              // 64 lanes x 3 x 16 B operands of one column
 constexpr int kFilterTopBytes = 2 * 1024;                       // hand-off values of 2 groups of 4 columns
@@ -158,7 +159,7 @@ template <int NT, bool SQ>
 __global__ __launch_bounds__(64 * kFilterWavesPerBlock, 2) void dtw_filter_kernel(
     const _Float16 *__restrict__ srcRec, const _Float16 *__restrict__ tgtRec,
     const int *__restrict__ srcLen, const int *__restrict__ tgtLen, int srcRows, int nPasses,
-    int tgtFramesPad, int mPad, int nSrcPairs, int nTasks, float outScale,
+    int tgtFramesPad, int mPad, int nSrcPairs, int nTasks, int taskChunk, float outScale,
     float *__restrict__ handoff, unsigned *__restrict__ taskCtr, float *__restrict__ cmat)
 {
     constexpr int REC = kFilterRecHalfs;
@@ -192,13 +193,17 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, 2) void dtw_filter_kerne
       const unsigned rangeLo = xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd;
       const unsigned rangeLen = qd + (xcd < rm ? 1u : 0u);
       for (;;) {
+        // tasks are taken kTaskChunk at a time: the counters are atomics in L2, and 2.6e5 single-task
+        // grabs on one cache line were a 3 ms floor under every launch (visible for short segments)
         unsigned got = 0;
         if (lane == 0)
-            got = atomicAdd(&taskCtr[xcd], 1u);
+            got = atomicAdd(&taskCtr[xcd * kTaskCtrStride], (unsigned)taskChunk);
         got = (unsigned)__builtin_amdgcn_readfirstlane((int)got);
         if (got >= rangeLen)
             break;
-        const unsigned lin = rangeLo + (rangeLen - 1u - got);
+        const unsigned gotEnd = min(got + (unsigned)taskChunk, rangeLen);
+       for (unsigned gi = got; gi < gotEnd; ++gi) {
+        const unsigned lin = rangeLo + (rangeLen - 1u - gi);
         const int tg = (int)(lin / (unsigned)nSrcPairs);
         const int sp = (int)(lin % (unsigned)nSrcPairs);    // source pair of this wave
 
@@ -349,6 +354,7 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, 2) void dtw_filter_kerne
             }
         }
         cmat[(size_t)(2 * sp + half) * mPad + 32 * tg + col] = res * outScale;
+       }
       }
     }
 }

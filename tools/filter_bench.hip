@@ -7,6 +7,7 @@
 #ifndef SSYM_TOOL_SQ
 #define SSYM_TOOL_SQ false
 #endif
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -32,7 +33,7 @@ int run(int N, int M, int F, int reps, int blocksPerCU)
     CK(hipMalloc(&ds, hs.size() * 2)); CK(hipMalloc(&dt, ht.size() * 2));
     CK(hipMalloc(&dc, (size_t)N * M * 4)); CK(hipMalloc(&dc2, (size_t)N * M * 4)); CK(hipMalloc(&dls, N * 4)); CK(hipMalloc(&dlt, M * 4));
     CK(hipMalloc(&dh, (size_t)grid * kFilterWavesPerBlock * F * 64 * 4));
-    CK(hipMalloc(&dctr, 8 * sizeof(unsigned)));
+    CK(hipMalloc(&dctr, 8 * kTaskCtrStride * sizeof(unsigned)));
     CK(hipMemcpy(ds, hs.data(), hs.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(dt, ht.data(), ht.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(dls, ls.data(), N * 4, hipMemcpyHostToDevice));
@@ -40,10 +41,12 @@ int run(int N, int M, int F, int reps, int blocksPerCU)
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int nSrcPairs = N / 2;
     const int nTasks = nSrcPairs * (M / 32);
+    int taskChunk = std::max(1, std::min(8, 8192 / (rows * F)));
+    taskChunk = std::max(1, std::min(taskChunk, nTasks / (grid * kFilterWavesPerBlock * 16)));
     auto launch = [&]() {
-        (void)hipMemsetAsync(dctr, 0, 8 * sizeof(unsigned), 0);
+        (void)hipMemsetAsync(dctr, 0, 8 * kTaskCtrStride * sizeof(unsigned), 0);
         dtw_filter_kernel<NT, SSYM_TOOL_SQ><<<grid, 64 * kFilterWavesPerBlock>>>(ds, dt, dls, dlt, rows, nPasses, F, M, nSrcPairs,
-                                                                         nTasks, 1.0f, dh, dctr, dc);
+                                                                         nTasks, taskChunk, 1.0f, dh, dctr, dc);
     };
     for (int w = 0; w < 2; ++w) launch();
     CK(hipDeviceSynchronize());
