@@ -83,3 +83,48 @@ def test_refcos_random_shapes(oracle, case):
     want_idx, want_val = oracle.refcos_match_all(sf, so, tf, to, dim, dist)
     assert np.array_equal(idx, want_idx) and np.array_equal(val, want_val), (case, dim, hi, n, m)
     e.close()
+
+
+@pytest.mark.parametrize("dim,band,use_dist", [(13, -1, False), (13, -1, True), (40, 32, False), (12, 8, False)])
+def test_dtw_medium_ragged(oracle, dim, band, use_dist):
+    # enough segments for several workgroups, task ranges and XCD counters; lengths from 1 frame to
+    # five row passes, targets beyond 128 frames (certificate column groups), slots reordered by length
+    st = synth.Stream(0x5EED2000 + dim + band)
+    n, m = 300, 96
+    src = _ragged(st, n, 1, 260, dim, 1.0)
+    tgt = _ragged(st, m, 1, 260, dim, 1.0)
+    for t in range(0, m, 3):                                 # near-copies, in scattered positions
+        s = (t * 7) % n
+        tgt[t] = src[s] + 0.01 * st.normal(src[s].size).reshape(src[s].shape)
+    src[211] = src[17].copy()                                # duplicate far apart in slot order
+    sf, so = pack_segments(src, dim, np.float32)
+    tf, to = pack_segments(tgt, dim, np.float32)
+    e = Engine(metric="dtw", dtype="f32", band=band)
+    d, q = e.dictionary(sf, so, dim), e.queries(tf, to, dim)
+    _, _, mat = oracle.dtw_match_all(sf.astype(np.float64), so, tf.astype(np.float64), to, dim, band=band,
+                                     want_matrix=True, nthreads=oracle.max_threads())
+    dist = None
+    if use_dist:
+        dist = np.nan_to_num(np.nanmedian(np.where(np.isfinite(mat), mat, np.nan), axis=0), nan=1.0)
+    key = np.abs(mat - (dist[None, :] if dist is not None else 0.0))
+    key = np.where(np.isnan(key), np.inf, key)
+    want_idx = np.where(np.isfinite(key).any(axis=0), key.argmin(axis=0), 0)
+    want_cost = np.where(np.isfinite(key).any(axis=0), mat[want_idx, np.arange(m)], np.inf)
+    idx, cost = e.match(d, q, distance=dist)
+    assert e.timings()["used_filter"] == 1
+    assert np.array_equal(idx, want_idx)
+    fin = np.isfinite(want_cost)
+    assert np.allclose(cost[fin], want_cost[fin], rtol=1e-12, atol=0) and np.isinf(cost[~fin]).all()
+    # the filter matrix, back in the caller's order, stays inside the derived bound of the exact one
+    fm = e.pair_matrix(d, q)
+    ok = np.isfinite(mat)
+    # (frames wider than 13 values are fed in ONE f16 piece: 2^-11 (|a| + |b|) absolute per cell)
+    lens = np.diff(so).astype(np.float64)[:, None] + np.diff(to).astype(np.float64)[None, :]
+    slack = 2e-3 * (1.0 + mat) + (0.0 if dim <= 13 else 2.0 ** -11 * 2 * 12.0 * lens)
+    assert np.all(np.abs(fm[ok] - mat[ok]) <= slack[ok])
+    # top-3 through the same path
+    ti, tc = e.match_topk(d, q, 3, dist)
+    o_idx, _ = oracle.topk(mat, 3, distance=dist, default_distance=0.0, fold_start=float("inf"))
+    from soundsym_amd._native import NO_MATCH
+    assert np.array_equal(np.where(ti == NO_MATCH, -1, ti.astype(np.int64)), o_idx)
+    e.close()
