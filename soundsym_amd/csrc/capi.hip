@@ -102,6 +102,8 @@ int32_t ssym_ctx_destroy(ssym_ctx *ctx)
         if (b->ptr)
             (void)hipFree(b->ptr);
     dev_cache_release(ctx);
+    if (ctx->stage)
+        (void)hipHostFree(ctx->stage);
     for (auto &ev : ctx->ev)
         if (ev)
             (void)hipEventDestroy(ev);
@@ -319,6 +321,7 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
                           const double *distance, uint32_t index_base, uint32_t k_top, uint32_t *out_idx,
                           double *out_cost, uint32_t flags, int phase = 0, double *bounds_dev = nullptr)
 {
+    StageScope stageScope(ctx);
     int32_t rc = check_match_args(ctx, dict, q);
     if (rc != SSYM_OK)
         return rc;
@@ -347,8 +350,9 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
         rc = ensure(ctx, ctx->dist, sizeof(double) * M);
         if (rc != SSYM_OK)
             return rc;
-        SSYM_HIP_CHECK(ctx, hipMemcpyAsync(ctx->dist.ptr, distance, sizeof(double) * M,
-                                           hipMemcpyHostToDevice, st));
+        rc = stage_h2d(ctx, ctx->dist.ptr, distance, sizeof(double) * M);
+        if (rc != SSYM_OK)
+            return rc;
         distDev = (const double *)ctx->dist.ptr;
     }
     uint32_t *idxDev = out_idx;
@@ -502,14 +506,15 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
     }
 
     if (!outDev) {
-        SSYM_HIP_CHECK(ctx, hipMemcpyAsync(out_idx, idxDev, sizeof(uint32_t) * (size_t)M * k_top,
-                                           hipMemcpyDeviceToHost, st));
-        if (out_cost)
-            SSYM_HIP_CHECK(ctx, hipMemcpyAsync(out_cost, costDev, sizeof(double) * (size_t)M * k_top,
-                                               hipMemcpyDeviceToHost, st));
+        rc = stage_d2h(ctx, out_idx, idxDev, sizeof(uint32_t) * (size_t)M * k_top);
+        if (rc == SSYM_OK && out_cost)
+            rc = stage_d2h(ctx, out_cost, costDev, sizeof(double) * (size_t)M * k_top);
+        if (rc != SSYM_OK)
+            return rc;
     }
     if (!outDev || ctx->metric == SSYM_METRIC_REFCOS)
         SSYM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    stage_finish(ctx);
     if (ctx->metric == SSYM_METRIC_REFCOS) {
         tm.main_ms = ev_ms(ev[0], ev[1]);
         tm.reduce_ms = ev_ms(ev[1], ev[2]);
@@ -613,6 +618,7 @@ int32_t ssym_match_batch(ssym_ctx *ctx, const ssym_dict *dict, const void *tgt_f
         ctx->err = "empty dictionary";
         return SSYM_E_EMPTY_DICT;
     }
+    StageScope stageScope(ctx);       // one staging window for the pack and the match
     ssym_queries *q = nullptr;
     hipEvent_t e0 = ctx->ev[6], e1 = ctx->ev[7];
     SSYM_HIP_CHECK(ctx, hipSetDevice(ctx->device));

@@ -142,6 +142,62 @@ void dev_cache_release(ssym_ctx *ctx)
     ctx->free_bytes = 0;
 }
 
+// ---- pinned staging ------------------------------------------------------------------------------
+constexpr size_t kStageBytes = (size_t)1 << 20, kStageMaxCopy = (size_t)256 << 10;
+
+static char *stage_take(ssym_ctx *ctx, size_t bytes)
+{
+    if (bytes > kStageMaxCopy)
+        return nullptr;
+    if (!ctx->stage) {
+        if (hipHostMalloc((void **)&ctx->stage, kStageBytes, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->stage = nullptr;
+            return nullptr;
+        }
+        ctx->stage_cap = kStageBytes;
+    }
+    const size_t at = (ctx->stage_cur + 63) & ~(size_t)63;
+    if (at + bytes > ctx->stage_cap)
+        return nullptr;
+    ctx->stage_cur = at + bytes;
+    return ctx->stage + at;
+}
+
+int32_t stage_h2d(ssym_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes)
+{
+    if (bytes == 0)
+        return SSYM_OK;
+    char *p = ctx->api_depth > 0 ? stage_take(ctx, bytes) : nullptr;
+    if (p) {
+        memcpy(p, src_host, bytes);
+        src_host = p;
+    }
+    SSYM_HIP_CHECK(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return SSYM_OK;
+}
+
+int32_t stage_d2h(ssym_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes)
+{
+    if (bytes == 0)
+        return SSYM_OK;
+    char *p = ctx->api_depth > 0 ? stage_take(ctx, bytes) : nullptr;
+    if (p) {
+        SSYM_HIP_CHECK(ctx, hipMemcpyAsync(p, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        ctx->pending_d2h.push_back({dst_host, p, bytes});
+        return SSYM_OK;
+    }
+    SSYM_HIP_CHECK(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return SSYM_OK;
+}
+
+void stage_finish(ssym_ctx *ctx)
+{
+    for (const auto &d : ctx->pending_d2h)
+        memcpy(d.user, d.pinned, d.bytes);
+    ctx->pending_d2h.clear();
+}
+
 void free_segments(ssym_ctx *ctx, SegmentSet &set)
 {
     dev_free(ctx, set.raw);
@@ -171,8 +227,7 @@ static int32_t build_derived(ssym_ctx *ctx, SegmentSet &set)
         set.max_frames = std::max<uint32_t>(set.max_frames, (uint32_t)(set.h_off[i + 1] - set.h_off[i]));
 
     { int32_t rca = dev_alloc(ctx, (void **)&set.off, sizeof(uint64_t) * (n + 1)); if (rca != SSYM_OK) return rca; }
-    SSYM_HIP_CHECK(ctx, hipMemcpyAsync(set.off, set.h_off.data(), sizeof(uint64_t) * (n + 1),
-                                       hipMemcpyHostToDevice, st));
+    { int32_t rcs = stage_h2d(ctx, set.off, set.h_off.data(), sizeof(uint64_t) * (n + 1)); if (rcs != SSYM_OK) return rcs; }
     if (n == 0) {
         SSYM_HIP_CHECK(ctx, hipStreamSynchronize(st));
         return SSYM_OK;
@@ -197,8 +252,7 @@ static int32_t build_derived(ssym_ctx *ctx, SegmentSet &set)
             return set.h_off[a + 1] - set.h_off[a] < set.h_off[b + 1] - set.h_off[b];
         });
         { int32_t rca = dev_alloc(ctx, (void **)&set.perm, sizeof(uint32_t) * set.n_pad); if (rca != SSYM_OK) return rca; }
-        SSYM_HIP_CHECK(ctx, hipMemcpyAsync(set.perm, set.h_perm.data(), sizeof(uint32_t) * set.n_pad,
-                                           hipMemcpyHostToDevice, st));
+        { int32_t rcs = stage_h2d(ctx, set.perm, set.h_perm.data(), sizeof(uint32_t) * set.n_pad); if (rcs != SSYM_OK) return rcs; }
         { int32_t rca = dev_alloc(ctx, (void **)&set.len, sizeof(int32_t) * set.n_pad); if (rca != SSYM_OK) return rca; }
         SSYM_HIP_CHECK(ctx, hipMemsetAsync(set.len, 0, sizeof(int32_t) * set.n_pad, st));
         { int32_t rca = dev_alloc(ctx, (void **)&set.max_sqnorm, sizeof(float) * (set.n_pad + 1)); if (rca != SSYM_OK) return rca; }
@@ -255,8 +309,13 @@ static int32_t upload_values(ssym_ctx *ctx, SegmentSet &set, size_t dst_val_offs
     hipStream_t st = ctx->stream;
     double *dst = set.raw + dst_val_offset;
     if (ctx->dtype == SSYM_DTYPE_F64) {
-        SSYM_HIP_CHECK(ctx, hipMemcpyAsync(dst, feats, count_vals * sizeof(double),
-                                           on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+        if (on_device) {
+            SSYM_HIP_CHECK(ctx, hipMemcpyAsync(dst, feats, count_vals * sizeof(double), hipMemcpyDeviceToDevice, st));
+        } else {
+            int32_t rcs = stage_h2d(ctx, dst, feats, count_vals * sizeof(double));
+            if (rcs != SSYM_OK)
+                return rcs;
+        }
         if (!ctx->defer_sync)      // the caller's buffer is free to go when this returns
             SSYM_HIP_CHECK(ctx, hipStreamSynchronize(st));
         return SSYM_OK;
@@ -265,11 +324,10 @@ static int32_t upload_values(ssym_ctx *ctx, SegmentSet &set, size_t dst_val_offs
     float *tmp = nullptr;
     if (!on_device) {
         { int32_t rca = dev_alloc(ctx, (void **)&tmp, count_vals * sizeof(float)); if (rca != SSYM_OK) return rca; }
-        hipError_t e = hipMemcpyAsync(tmp, feats, count_vals * sizeof(float), hipMemcpyHostToDevice, st);
-        if (e != hipSuccess) {
+        int32_t rcs = stage_h2d(ctx, tmp, feats, count_vals * sizeof(float));
+        if (rcs != SSYM_OK) {
             dev_free(ctx, tmp);
-            ctx->err = std::string("hipMemcpyAsync: ") + hipGetErrorString(e);
-            return SSYM_E_HIP;
+            return rcs;
         }
         src_dev = tmp;
     }

@@ -114,6 +114,15 @@ struct ssym_ctx {
         std::vector<double> dist_host;
         float main_ms = 0.f;
     } pending;
+    // pinned staging for the small transfers of one API call (a single-query match moves a few KB in
+    // four copies; from pageable memory every one of them blocks the host).  Uploads are copied here
+    // and sent asynchronously; results land here and reach the caller's buffers after the call's one
+    // synchronisation.  The cursor restarts when an outermost API call begins (api_depth).
+    char *stage = nullptr;
+    size_t stage_cap = 0, stage_cur = 0;
+    int api_depth = 0;
+    struct PendingD2H { void *user; const void *pinned; size_t bytes; };
+    std::vector<PendingD2H> pending_d2h;
     // small-block cache for per-call segment sets (ssym_match_one packs one query per call; going
     // to the driver for every hipMalloc / hipFree -- the latter synchronises the device -- cost more
     // than the match itself).  All users run on `stream`, so reuse is stream-ordered.
@@ -156,6 +165,21 @@ void free_segments(ssym_ctx *ctx, SegmentSet &set);
 int32_t dev_alloc(ssym_ctx *ctx, void **p, size_t bytes);
 void dev_free(ssym_ctx *ctx, void *p);
 void dev_cache_release(ssym_ctx *ctx);
+// staged host <-> device copies (pack.hip); fall back to plain hipMemcpyAsync when the transfer is large
+int32_t stage_h2d(ssym_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int32_t stage_d2h(ssym_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+void stage_finish(ssym_ctx *ctx);      // after the stream is synchronised: hand the staged results over
+struct StageScope {                    // one per public entry point that moves host data
+    ssym_ctx *c;
+    explicit StageScope(ssym_ctx *ctx) : c(ctx)
+    {
+        if (c && c->api_depth++ == 0) {
+            c->stage_cur = 0;
+            c->pending_d2h.clear();      // leftovers of a call that failed before its synchronisation
+        }
+    }
+    ~StageScope() { if (c) --c->api_depth; }
+};
 
 // dtw_filter.hip
 bool filter_supported(const ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt);
