@@ -90,7 +90,7 @@ typedef struct ssym_config {
 typedef struct ssym_timings {
     float pack_ms;      /* target packing (only when the call packed targets itself)             */
     float main_ms;      /* dtw: MFMA filter kernel / refcos: similarity tile kernel              */
-    float select_ms;    /* dtw: column min + candidate selection                                 */
+    float select_ms;    /* dtw: bounds, two-stage candidate selection, certificates              */
     float refine_ms;    /* dtw: exact f64 re-scoring of candidates (or of every pair)            */
     float reduce_ms;    /* final per-target argmin                                               */
     float total_ms;     /* first event to last event                                             */
