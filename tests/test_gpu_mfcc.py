@@ -73,3 +73,28 @@ def test_mfcc_rejects_bad_arguments(eng):
         eng.mfcc(np.zeros(2048), 44100.0, 0)
     with pytest.raises(SsymError):
         eng.mfcc(np.zeros(2048), 44100.0, 12, f_lo=500.0, f_hi=100.0)
+
+
+def test_mfcc_device_output_feeds_a_dictionary(eng, oracle):
+    # SSYM_OUT_DEVICE: features stay on the GPU and go straight into ssym_dict_create_device
+    import ctypes
+    torch = pytest.importorskip("torch")
+    from soundsym_amd import _native as nat
+    x = _signal(256 * 40 + 768, 44100.0, 77)
+    want = oracle.mfcc(x, 44100.0)
+    frames = want.shape[0]
+    out = torch.empty(frames * 12, dtype=torch.float64, device="cuda")
+    mean = np.zeros(12)
+    xs = np.ascontiguousarray(x)
+    rc = nat.lib().ssym_mfcc(eng.ctx, xs.ctypes.data, xs.size, 44100.0, 12, 100.0, 8000.0, nat.OUT_DEVICE,
+                             out.data_ptr(), mean.ctypes.data)
+    nat.check(rc, eng.ctx)
+    got = out.cpu().numpy().reshape(frames, 12)
+    assert np.all(np.abs(got - want) <= TOL * (1.0 + np.abs(want)))
+    assert np.allclose(mean, want.mean(axis=0), rtol=1e-10)
+    off = np.arange(0, frames + 1, 8, dtype=np.uint64)          # 8-frame segments of the stream
+    d = eng.dictionary(out, off, 12)
+    q = eng.queries(got[:8 * (off.size - 1)].reshape(-1), off, 12)
+    idx, _ = eng.match(d, q)
+    want_idx, _ = oracle.refcos_match_all(got.reshape(-1), off, got.reshape(-1), off, 12)
+    assert np.array_equal(idx, want_idx)
