@@ -167,3 +167,29 @@ def test_reconstruction_example_end_to_end(tmp_path, oracle):
         soff = np.concatenate([[0], np.cumsum([x.size for x in ssm])]).astype(np.uint64)
         ooff = np.concatenate([[0], np.cumsum([x.size for x in tsm])]).astype(np.uint64)
         assert np.array_equal(got, oracle.reconstruct(np.concatenate(ssm), soff, idx, ooff))
+
+
+def test_small_abi_entry_points():
+    # ssym_dict_size, ssym_ctx_synchronize, device-resident queries, a caller-provided stream
+    import ctypes
+    torch = pytest.importorskip("torch")
+    from soundsym_amd import Engine
+    from soundsym_amd import _native as nat
+    st = torch.cuda.Stream()
+    e = Engine(metric="refcos", dtype="f64", stream=st.cuda_stream)
+    rng = np.random.default_rng(5)
+    feats = rng.normal(size=(6, 4, 12))
+    off = np.arange(7, dtype=np.uint64) * 4
+    d = e.dictionary(feats.reshape(-1), off, 12)
+    n = ctypes.c_uint32(0)
+    nat.check(nat.lib().ssym_dict_size(d.ptr, ctypes.byref(n)), e.ctx)
+    assert n.value == 6
+    e.dictionary_append(d, feats[:2].reshape(-1), off[:3])
+    nat.check(nat.lib().ssym_dict_size(d.ptr, ctypes.byref(n)), e.ctx)
+    assert n.value == 8
+    qdev = torch.from_numpy(feats.reshape(-1)).cuda()
+    q = e.queries(qdev, off, 12)                       # ssym_queries_create_device
+    idx, val = e.match(d, q)
+    assert list(idx) == [0, 1, 2, 3, 4, 5]             # every segment finds itself, duplicates lose to the first
+    e.synchronize()
+    e.close()
