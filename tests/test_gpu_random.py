@@ -11,6 +11,10 @@ from soundsym_amd import Engine, synth
 from soundsym_amd.engine import pack_segments
 
 pytestmark = pytest.mark.gpu
+# SSYM_FUZZ_CASES=N widens the seeded sweeps (default 120 dtw / 24 refcos cases keep the suite short)
+import os
+_N_DTW = int(os.environ.get("SSYM_FUZZ_CASES", "120"))
+_N_REFCOS = max(24, _N_DTW // 5)
 
 
 def _ragged(st, n, lo, hi, dim, scale):
@@ -18,7 +22,7 @@ def _ragged(st, n, lo, hi, dim, scale):
     return [(st.normal(int(f) * dim).reshape(int(f), dim) * synth.sigma(dim) * scale) for f in lens]
 
 
-@pytest.mark.parametrize("case", range(120))
+@pytest.mark.parametrize("case", range(_N_DTW))
 def test_dtw_random_shapes(oracle, case):
     st = synth.Stream(0x5EED1000 + case)
     dim = int([1, 2, 5, 12, 13, 14, 20, 40, 42][st.integers(1, 9)[0]])
@@ -67,7 +71,7 @@ def test_dtw_random_shapes(oracle, case):
     e.close()
 
 
-@pytest.mark.parametrize("case", range(24))
+@pytest.mark.parametrize("case", range(_N_REFCOS))
 def test_refcos_random_shapes(oracle, case):
     st = synth.Stream(0x5EED2000 + case)
     dim = int([1, 3, 12, 13, 40][st.integers(1, 5)[0]])
