@@ -89,11 +89,15 @@ def test_refcos_random_shapes(oracle, case):
     e.close()
 
 
+_N_MEDIUM = int(os.environ.get("SSYM_FUZZ_MEDIUM", "1"))
+
+
+@pytest.mark.parametrize("seed", range(_N_MEDIUM))
 @pytest.mark.parametrize("dim,band,use_dist", [(13, -1, False), (13, -1, True), (40, 32, False), (12, 8, False)])
-def test_dtw_medium_ragged(oracle, dim, band, use_dist):
+def test_dtw_medium_ragged(oracle, dim, band, use_dist, seed):
     # enough segments for several workgroups, task ranges and XCD counters; lengths from 1 frame to
     # five row passes, targets beyond 128 frames (certificate column groups), slots reordered by length
-    st = synth.Stream(0x5EED2000 + dim + band)
+    st = synth.Stream(0x5EED2000 + dim + band + 7919 * seed)
     n, m = 300, 96
     src = _ragged(st, n, 1, 260, dim, 1.0)
     tgt = _ragged(st, m, 1, 260, dim, 1.0)
