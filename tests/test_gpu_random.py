@@ -136,3 +136,46 @@ def test_dtw_medium_ragged(oracle, dim, band, use_dist, seed):
     from soundsym_amd._native import NO_MATCH
     assert np.array_equal(np.where(ti == NO_MATCH, -1, ti.astype(np.int64)), o_idx)
     e.close()
+
+
+@pytest.mark.parametrize("case", range(max(30, _N_DTW // 4)))
+def test_topk_and_chain_random_shapes(oracle, case):
+    from soundsym_amd._native import NO_MATCH
+    st = synth.Stream(0x5EED3000 + case)
+    metric = ["refcos", "dtw"][int(st.integers(1, 2)[0])]
+    dim = int([2, 12, 13, 20][st.integers(1, 4)[0]])
+    hi = int([4, 18, 40, 70][st.integers(1, 4)[0]])
+    n, m = int(2 + st.integers(1, 40)[0]), int(1 + st.integers(1, 12)[0])
+    k = int(1 + st.integers(1, 8)[0])
+    src = _ragged(st, n, 1, hi, dim, 1.0)
+    tgt = _ragged(st, m, 1, hi, dim, 1.0)
+    if n > 5:
+        src[5] = src[1].copy()
+    tgt[0] = src[min(3, n - 1)].copy()
+    sf, so = pack_segments(src, dim, np.float64)
+    tf, to = pack_segments(tgt, dim, np.float64)
+    e = Engine(metric=metric, dtype="f64")
+    d, q = e.dictionary(sf, so, dim), e.queries(tf, to, dim)
+    if metric == "refcos":
+        mat = oracle.refcos_matrix(sf, so, tf, to, dim)
+        dist = 0.2 + 1.2 * (st.integers(m, 1000) / 1000.0)
+        want_idx, want_val = oracle.topk(mat, k, distance=dist)
+    else:
+        _, _, mat = oracle.dtw_match_all(sf, so, tf, to, dim, want_matrix=True)
+        dist = np.nanmedian(mat, axis=0) * (st.integers(m, 1000) / 500.0)
+        want_idx, _ = oracle.topk(mat, k, distance=dist, default_distance=0.0, fold_start=float("inf"))
+        want_val = np.where(want_idx >= 0, mat[np.maximum(want_idx, 0), np.arange(m)[:, None]], np.nan)
+    idx, val = e.match_topk(d, q, k, dist)
+    assert np.array_equal(np.where(idx == NO_MATCH, -1, idx.astype(np.int64)), want_idx)
+    have = want_idx >= 0
+    if metric == "refcos":
+        assert np.array_equal(val[have], want_val[have])
+    else:
+        assert np.allclose(val[have], want_val[have], rtol=1e-12, atol=0)
+    # the greedy chain from target 0 with the same distances as step sizes
+    steps = dist[: max(1, min(m, 6))]
+    ci, cv = e.chain(d, tgt[0].reshape(-1), steps)
+    wi, wv = oracle.chain(sf, so, dim, tgt[0].reshape(-1), steps, metric=metric)
+    assert np.array_equal(ci, wi)
+    assert np.array_equal(cv, wv) if metric == "refcos" else np.allclose(cv, wv, rtol=1e-12, atol=0)
+    e.close()
