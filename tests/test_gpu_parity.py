@@ -484,6 +484,12 @@ def test_dtw_candidate_overflow_is_redone_with_the_reported_size(dtw, oracle):
     want_idx, want_cost = oracle.dtw_match_all(src.reshape(-1).astype(np.float64), so,
                                                tgt.reshape(-1).astype(np.float64), to, 13)
     assert np.array_equal(idx, want_idx) and np.allclose(cost, want_cost, rtol=EXACT_RTOL, atol=0)
+    # the same through top-k: every source ties, so each row is the first k indices in order
+    d, q = dtw.dictionary(src.reshape(-1), so, 13), dtw.queries(tgt.reshape(-1), to, 13)
+    ti, tc = dtw.match_topk(d, q, 5)
+    assert dtw.timings()["n_refined"] == n * m
+    assert np.array_equal(ti, np.tile(np.arange(5, dtype=np.uint32), (m, 1)))
+    assert np.allclose(tc, want_cost[:, None], rtol=EXACT_RTOL, atol=0)
 
 
 def test_merge_shards_kernel(dtw):
