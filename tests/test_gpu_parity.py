@@ -535,3 +535,23 @@ def test_rows_f_golden_fixture(refcos):
     assert np.all(np.abs(m - f["mfcc"]) <= 1e-12 * (1 + np.abs(f["mfcc"])))
     ci, cv = refcos.chain(d, f["chain_start"], f["chain_dist"])
     assert np.array_equal(ci, f["chain_idx"]) and np.array_equal(cv, f["chain_val"])
+
+
+@pytest.mark.parametrize("dim,band", [(45, -1), (48, 6), (64, -1), (100, 3)])
+def test_dtw_wide_frames_run_on_the_exact_kernels(oracle, dim, band):
+    # frames wider than the filter's 42 values: <= 48 on the register variant of the exact kernel,
+    # beyond that on the generic one; results are still the oracle's
+    rng = np.random.default_rng(dim)
+    src = [rng.normal(size=(int(rng.integers(1, 90)), dim)).astype(np.float32) for _ in range(21)]
+    tgt = [rng.normal(size=(int(rng.integers(1, 90)), dim)).astype(np.float32) for _ in range(9)]
+    tgt[4] = src[8].copy()
+    sf, so = pack_segments(src, dim, np.float32)
+    tf, to = pack_segments(tgt, dim, np.float32)
+    e = Engine(metric="dtw", dtype="f32", band=band)
+    idx, cost = e.match(e.dictionary(sf, so, dim), e.queries(tf, to, dim))
+    assert e.timings()["used_filter"] == 0
+    want_idx, want_cost = oracle.dtw_match_all(sf.astype(np.float64), so, tf.astype(np.float64), to, dim, band=band)
+    assert np.array_equal(idx, want_idx)
+    fin = np.isfinite(want_cost)
+    assert np.allclose(cost[fin], want_cost[fin], rtol=EXACT_RTOL, atol=0) and np.isinf(cost[~fin]).all()
+    e.close()
