@@ -223,6 +223,13 @@ SSYM_API int32_t ssym_match_finish(ssym_ctx *ctx, const double *bounds_dev, uint
 SSYM_API int32_t ssym_merge_shards(ssym_ctx *ctx, uint32_t n_shards, uint32_t n_targets,
                           const double *costs_dev, const uint32_t *idx_dev, uint32_t *out_idx_dev,
                           double *out_cost_dev);
+/* The same for matches made with per-target distances (morph_to, src/sound.rs:440-446): the shards
+ * folded on |cost - distance|, so the merge does too.  `distance`: n_targets f64 in HOST memory, or
+ * NULL (= ssym_merge_shards).  dtw costs only: refcos shards report the key itself, which
+ * ssym_merge_shards already compares correctly. */
+SSYM_API int32_t ssym_merge_shards_at(ssym_ctx *ctx, uint32_t n_shards, uint32_t n_targets,
+                             const double *costs_dev, const uint32_t *idx_dev, const double *distance,
+                             uint32_t *out_idx_dev, double *out_cost_dev);
 
 /* Reconstruction tail (the step right after the hot path): the samples of every dictionary sound,
  * resident on the GPU (Sound::samples(), src/sound.rs:181; `sample_offsets` = n_sounds+1 SAMPLE

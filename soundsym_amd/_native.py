@@ -38,7 +38,7 @@ ABI_SYMBOLS = [
     "ssym_queries_create_device", "ssym_queries_destroy", "ssym_match_queries", "ssym_match_begin",
     "ssym_match_finish", "ssym_match_topk",
     "ssym_match_batch",
-    "ssym_match_one", "ssym_chain", "ssym_pair_matrix", "ssym_merge_shards", "ssym_samples_create",
+    "ssym_match_one", "ssym_chain", "ssym_pair_matrix", "ssym_merge_shards", "ssym_merge_shards_at", "ssym_samples_create",
     "ssym_samples_destroy", "ssym_reconstruct", "ssym_mfcc_num_frames", "ssym_mfcc",
 ]
 
@@ -173,6 +173,8 @@ def lib() -> ctypes.CDLL:
     L.ssym_match_one.argtypes = [vp, vp, vp, u64, f64, vp, vp]
     L.ssym_chain.restype = i32
     L.ssym_chain.argtypes = [vp, vp, vp, u64, vp, u32, vp, vp]
+    L.ssym_merge_shards_at.restype = i32
+    L.ssym_merge_shards_at.argtypes = [vp, u32, u32, vp, vp, vp, vp, vp]
     L.ssym_mfcc_num_frames.restype = i32
     L.ssym_mfcc_num_frames.argtypes = [u64, u32, vp]
     L.ssym_mfcc.restype = i32

@@ -796,8 +796,9 @@ int32_t ssym_pair_matrix(ssym_ctx *ctx, const ssym_dict *dict, const ssym_querie
     return SSYM_OK;
 }
 
-int32_t ssym_merge_shards(ssym_ctx *ctx, uint32_t n_shards, uint32_t n_targets, const double *costs_dev,
-                          const uint32_t *idx_dev, uint32_t *out_idx_dev, double *out_cost_dev)
+int32_t ssym_merge_shards_at(ssym_ctx *ctx, uint32_t n_shards, uint32_t n_targets, const double *costs_dev,
+                             const uint32_t *idx_dev, const double *distance, uint32_t *out_idx_dev,
+                             double *out_cost_dev)
 {
     if (!ctx)
         return SSYM_E_INVALID;
@@ -806,11 +807,27 @@ int32_t ssym_merge_shards(ssym_ctx *ctx, uint32_t n_shards, uint32_t n_targets, 
         return SSYM_E_INVALID;
     }
     SSYM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    int32_t rc = launch_merge_shards(ctx, n_shards, n_targets, costs_dev, idx_dev, out_idx_dev, out_cost_dev);
+    StageScope stageScope(ctx);
+    const double *distDev = nullptr;
+    if (distance && n_targets) {
+        int32_t rc = ensure(ctx, ctx->dist, sizeof(double) * n_targets);
+        if (rc == SSYM_OK)
+            rc = stage_h2d(ctx, ctx->dist.ptr, distance, sizeof(double) * n_targets);
+        if (rc != SSYM_OK)
+            return rc;
+        distDev = (const double *)ctx->dist.ptr;
+    }
+    int32_t rc = launch_merge_shards(ctx, n_shards, n_targets, costs_dev, idx_dev, distDev, out_idx_dev, out_cost_dev);
     if (rc != SSYM_OK)
         return rc;
     SSYM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return SSYM_OK;
+}
+
+int32_t ssym_merge_shards(ssym_ctx *ctx, uint32_t n_shards, uint32_t n_targets, const double *costs_dev,
+                          const uint32_t *idx_dev, uint32_t *out_idx_dev, double *out_cost_dev)
+{
+    return ssym_merge_shards_at(ctx, n_shards, n_targets, costs_dev, idx_dev, nullptr, out_idx_dev, out_cost_dev);
 }
 
 }  // extern "C"

@@ -518,19 +518,23 @@ __global__ __launch_bounds__(128) void fold_final_topk_kernel(const uint32_t *__
 // Source-sharded multi-GPU merge: smallest cost, lowest global index
 // on equal cost.  Shards are ordered by index, so this is the same first-minimum rule.
 __global__ void merge_shards_kernel(uint32_t nShards, uint32_t nTgt, const double *__restrict__ costs,
-                                    const uint32_t *__restrict__ idx, uint32_t *__restrict__ outIdx,
-                                    double *__restrict__ outCost)
+                                    const uint32_t *__restrict__ idx, const double *__restrict__ dist,
+                                    uint32_t *__restrict__ outIdx, double *__restrict__ outCost)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nTgt)
         return;
-    double bc = costs[t];
+    // key = |cost - distance| (distance NULL = 0, where key = cost): the same key every shard folded on
+    const double d = dist ? dist[t] : 0.0;
+    double bc = costs[t], bk = fabs(bc - d);
     uint32_t bi = idx[t];
     for (uint32_t g = 1; g < nShards; ++g) {
         const double c = costs[(size_t)g * nTgt + t];
+        const double k = fabs(c - d);
         const uint32_t i = idx[(size_t)g * nTgt + t];
-        if (c < bc || (c == bc && i < bi)) {
+        if (k < bk || (k == bk && i < bi)) {
             bc = c;
+            bk = k;
             bi = i;
         }
     }
@@ -772,12 +776,12 @@ int32_t launch_refcos_argmin(ssym_ctx *ctx, uint32_t n_src, uint32_t n_tgt, cons
 }
 
 int32_t launch_merge_shards(ssym_ctx *ctx, uint32_t n_shards, uint32_t n_targets, const double *costs,
-                            const uint32_t *idx, uint32_t *out_idx, double *out_cost)
+                            const uint32_t *idx, const double *dist_dev, uint32_t *out_idx, double *out_cost)
 {
     if (n_targets == 0)
         return SSYM_OK;
     merge_shards_kernel<<<(n_targets + 255) / 256, 256, 0, ctx->stream>>>(n_shards, n_targets, costs, idx,
-                                                                         out_idx, out_cost);
+                                                                         dist_dev, out_idx, out_cost);
     SSYM_HIP_CHECK(ctx, hipGetLastError());
     return SSYM_OK;
 }

@@ -214,8 +214,8 @@ int32_t launch_dtw_final_allpairs(ssym_ctx *ctx, uint32_t n_src, uint32_t n_tgt,
                                   uint32_t index_base, uint32_t k_top, uint32_t *out_idx_dev,
                                   double *out_cost_dev);
 int32_t launch_merge_shards(ssym_ctx *ctx, uint32_t n_shards, uint32_t n_targets,
-                            const double *costs, const uint32_t *idx, uint32_t *out_idx,
-                            double *out_cost);
+                            const double *costs, const uint32_t *idx, const double *dist_dev,
+                            uint32_t *out_idx, double *out_cost);
 
 // chain.hip
 int32_t launch_chain_argmin(ssym_ctx *ctx, const double *base, size_t row_stride, const uint32_t *row_sel,

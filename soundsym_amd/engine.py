@@ -281,11 +281,16 @@ class Engine:
                   self.ctx)
         return (out, pcm) if want_pcm32 else out
 
-    def merge_shards(self, costs, idx, out_idx, out_cost) -> None:
-        """costs [G, M] f64, idx [G, M] 32-bit, outputs [M]: torch CUDA tensors on this GPU."""
+    def merge_shards(self, costs, idx, out_idx, out_cost, distance=None) -> None:
+        """costs [G, M] f64, idx [G, M] 32-bit, outputs [M]: torch CUDA tensors on this GPU; distance:
+        the per-target distances the shards matched with (host array), or None."""
         g, m = costs.shape
-        nat.check(nat.lib().ssym_merge_shards(self.ctx, g, m, costs.data_ptr(), idx.data_ptr(),
-                                              out_idx.data_ptr(), out_cost.data_ptr()), self.ctx)
+        dist_p = None
+        if distance is not None:
+            dist = np.ascontiguousarray(distance, dtype=np.float64)
+            dist_p = dist.ctypes.data
+        nat.check(nat.lib().ssym_merge_shards_at(self.ctx, g, m, costs.data_ptr(), idx.data_ptr(), dist_p,
+                                                 out_idx.data_ptr(), out_cost.data_ptr()), self.ctx)
 
     def timings(self) -> dict:
         t = nat.Timings()

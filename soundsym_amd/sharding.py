@@ -75,21 +75,21 @@ def reduce_bounds(bounds, group=None):
     return bounds
 
 
-def match_sharded(engine, d, q, index_base, out_idx, out_cost, bounds, group=None):
+def match_sharded(engine, d, q, index_base, out_idx, out_cost, bounds, group=None, distance=None):
     """One rank's part of a source-sharded match: filter, agree on the per-target bound with the
     other ranks, select / re-score against it, gather every rank's winners and merge them.
     All tensors are CUDA tensors on this rank's GPU; returns (idx [M], cost [M])."""
     import torch
 
-    engine.match_begin(d, q, bounds, index_base=index_base)
+    engine.match_begin(d, q, bounds, distance=distance, index_base=index_base)
     reduce_bounds(bounds, group)
     torch.cuda.current_stream().synchronize()      # the library runs on its own stream
     engine.match_finish(bounds, out_idx, out_cost)
     costs, idxs = gather_candidates(out_cost, out_idx, group)
-    return merge_shards(engine, costs, idxs)
+    return merge_shards(engine, costs, idxs, distance)
 
 
-def merge_shards(engine, costs, idx):
+def merge_shards(engine, costs, idx, distance=None):
     """Final G-way reduce on the GPU (ssym_merge_shards).  Inputs must be CUDA tensors."""
     import torch
 
@@ -101,5 +101,5 @@ def merge_shards(engine, costs, idx):
     torch.cuda.current_stream(costs.device).synchronize()
     out_idx = torch.empty(m, dtype=idx.dtype, device=idx.device)
     out_cost = torch.empty(m, dtype=torch.float64, device=costs.device)
-    engine.merge_shards(costs.contiguous(), idx.contiguous(), out_idx, out_cost)
+    engine.merge_shards(costs.contiguous(), idx.contiguous(), out_idx, out_cost, distance)
     return out_idx, out_cost

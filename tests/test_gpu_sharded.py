@@ -100,3 +100,41 @@ def test_begin_finish_falls_back_where_the_filter_does_not_apply():
     assert np.array_equal(oi.cpu().numpy().astype(np.int64), want_idx.astype(np.int64))
     assert np.array_equal(oc.cpu().numpy(), want_val)
     e.close()
+
+
+def test_two_shards_with_per_target_distances():
+    # morph_to's per-target distances in a sharded run: the bound exchange and the merge both work on
+    # |cost - distance|
+    n, m, f, dim = 256, 64, 24, 13
+    g = synth.make_grid(n, m, f, dim, 0x5EED0902)
+    whole = Engine(metric="dtw", dtype="f32")
+    d, q = _sets(whole, g, 0, n, f, dim)
+    base_idx, base_cost = whole.match(d, q)
+    rng = np.random.default_rng(9)
+    dist = rng.uniform(0.5, 2.0, size=m) * np.median(whole.pair_matrix(d, q), axis=0)
+    want_idx, want_cost = whole.match(d, q, distance=dist)
+    assert not np.array_equal(want_idx, base_idx)         # the distances do change the answer
+    whole.close()
+    costs, idxs, engines = [], [], []
+    bounds = []
+    for r in range(2):
+        lo, hi = sharding.shard_range(n, 2, r)
+        e = Engine(metric="dtw", dtype="f32")
+        dd, qq = _sets(e, g, lo, hi, f, dim)
+        b = torch.empty(m, dtype=torch.float64, device="cuda")
+        e.match_begin(dd, qq, b, distance=dist, index_base=lo)
+        engines.append((e, dd, qq))
+        bounds.append(b)
+    agreed = torch.minimum(bounds[0], bounds[1])
+    for (e, dd, qq), b in zip(engines, bounds):
+        b.copy_(agreed)
+        oi = torch.empty(m, dtype=torch.int32, device="cuda")
+        oc = torch.empty(m, dtype=torch.float64, device="cuda")
+        e.match_finish(b, oi, oc)
+        costs.append(oc)
+        idxs.append(oi)
+    out_idx, out_cost = sharding.merge_shards(engines[0][0], torch.stack(costs), torch.stack(idxs), dist)
+    assert np.array_equal(out_idx.cpu().numpy().astype(np.int64), want_idx.astype(np.int64))
+    assert np.array_equal(out_cost.cpu().numpy(), want_cost)
+    for e, *_ in engines:
+        e.close()
