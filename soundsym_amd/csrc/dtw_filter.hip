@@ -167,6 +167,10 @@ template <int NT, bool SQ>
 static void launch_one(hipStream_t st, const SegmentSet &src, const SegmentSet &tgt, int nPasses,
                        int gridBlocks, float outScale, float *handoff, unsigned *taskCtr, float *cmat)
 {
+    // sources of at most 16 frames (one tile, one pass): three waves per SIMD, see filter_ring() -- 11 %
+    // faster there; at 32 frames the gain was within 3 % and cost spills
+    constexpr int OCC = NT == 1 ? 3 : 2;
+    gridBlocks = gridBlocks / 2 * OCC;
     const int nSrcPairs = (int)src.n_pad / 2;
     const int nTgtGroups = (int)tgt.n_pad / 32;
     const int nTasks = nSrcPairs * nTgtGroups;            // one wave's 64 pairs each
@@ -178,7 +182,7 @@ static void launch_one(hipStream_t st, const SegmentSet &src, const SegmentSet &
     const long cellsPerTask = (long)src.frames_pad * std::max<uint32_t>(tgt.max_frames, 1);
     int taskChunk = (int)std::max(1L, std::min(8L, 8192 / std::max(1L, cellsPerTask)));
     taskChunk = std::max(1, std::min(taskChunk, nTasks / (grid * kFilterWavesPerBlock * 16)));
-    dtw_filter_kernel<NT, SQ><<<dim3(grid), 64 * kFilterWavesPerBlock, 0, st>>>(
+    dtw_filter_kernel<NT, SQ, OCC><<<dim3(grid), 64 * kFilterWavesPerBlock, 0, st>>>(
         (const _Float16 *)src.rec, (const _Float16 *)tgt.rec, src.len, tgt.len, (int)src.frames_pad, nPasses,
         (int)tgt.frames_pad, (int)tgt.n_pad, nSrcPairs, nTasks, taskChunk, outScale, handoff, taskCtr, cmat);
 }
@@ -274,7 +278,8 @@ int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
     // task & 7 is the XCD group; one hand-off row of [target frames][64] floats per wave
     const int gridBlocks = std::max(8, ctx->num_cus * 2 / 8 * 8);
     // + 8 task counters behind the hand-off rows
-    const size_t handBytes = (size_t)gridBlocks * kFilterWavesPerBlock * ((tgt.frames_pad + 3) / 4) * 256 * sizeof(float);
+    // (sized for the three-workgroups-per-CU launch of the one-tile kernel too)
+    const size_t handBytes = (size_t)(gridBlocks / 2 * 3) * kFilterWavesPerBlock * ((tgt.frames_pad + 3) / 4) * 256 * sizeof(float);
     rc = ensure(ctx, ctx->handoff, handBytes + 8 * kTaskCtrStride * sizeof(unsigned));
     if (rc != SSYM_OK)
         return rc;

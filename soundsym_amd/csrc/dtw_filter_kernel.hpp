@@ -145,18 +145,20 @@ __device__ __forceinline__ float dp_column(const half8 (&A)[NT][kFilterKM], cons
 
 constexpr int kFilterWavesPerBlock = 4;
 constexpr int kTaskCtrStride = 64;      // the 8 task counters sit in separate 256-byte lines (separate L2 channels)
-constexpr int kFilterRing = 4;                                  // target columns staged in LDS per wave
+// Target columns staged in LDS per wave: 4 at two waves per SIMD (three columns of lead); the single-pass
+// kernels for short sources (NT <= 2) can run three waves per SIMD with a ring of 2 (one column of
+// lead, latency covered by occupancy) so that three workgroups fit the LDS.
+constexpr int filter_ring(int occ) { return occ >= 3 ? 2 : 4; }
 constexpr int kFilterSlotBytes = kFilterKM * 1024;              // 64 lanes x 3 x 16 B operands of one column
 constexpr int kFilterTopBytes = 2 * 1024;                       // hand-off values of 2 groups of 4 columns
-constexpr int kFilterWaveLds = kFilterRing * kFilterSlotBytes + kFilterTopBytes;
+constexpr int filter_wave_lds(int occ) { return filter_ring(occ) * kFilterSlotBytes + kFilterTopBytes; }
+constexpr int wait_vmcnt(int n) { return 0x0F70 | (n & 15) | ((n >> 4) << 14); }   // s_waitcnt vmcnt(n), nothing else
 // s_waitcnt immediates (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14])
-constexpr int kWaitVm6 = 0x0F76;                                // vmcnt(6), nothing else
-constexpr int kWaitVm9 = 0x0F79;                                // vmcnt(9)
 
 // Persistent kernel: every wave keeps taking (source pair, target group) tasks of 64 pairs until
 // none is left (taskCtr: 8 counters, zeroed by the host before the launch).
-template <int NT, bool SQ>
-__global__ __launch_bounds__(64 * kFilterWavesPerBlock, 2) void dtw_filter_kernel(
+template <int NT, bool SQ, int OCC = 2>
+__global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_kernel(
     const _Float16 *__restrict__ srcRec, const _Float16 *__restrict__ tgtRec,
     const int *__restrict__ srcLen, const int *__restrict__ tgtLen, int srcRows, int nPasses,
     int tgtFramesPad, int mPad, int nSrcPairs, int nTasks, int taskChunk, float outScale,
@@ -175,7 +177,11 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, 2) void dtw_filter_kerne
     const size_t handGroups = ((size_t)tgtFramesPad + 3) / 4;
     char *const handRow = reinterpret_cast<char *>(handoff + ((size_t)blockIdx.x * kFilterWavesPerBlock + wave) * handGroups * 256);
     const uint32_t laneOff16 = lane * 16;
-    __shared__ __attribute__((aligned(16))) char ring[kFilterWavesPerBlock][kFilterWaveLds];
+    // OCC >= 3 is only instantiated for single-pass shapes: no hand-off traffic is in flight, so the waits
+    // below count column groups of exactly three DMAs
+    constexpr int kFilterRing = filter_ring(OCC);
+    constexpr int kWaitLead = wait_vmcnt(3 * (kFilterRing - 2)), kWaitFirst = wait_vmcnt(3 * (kFilterRing - 1));
+    __shared__ __attribute__((aligned(16))) char ring[kFilterWavesPerBlock][filter_wave_lds(OCC)];
     char *const myRing = ring[wave];
     char *const myTop = myRing + kFilterRing * kFilterSlotBytes;
 
@@ -302,7 +308,7 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, 2) void dtw_filter_kerne
             float topN = INF;                                       // D(rowBase-1, j) for the coming column
             // everything issued so far except the last kFilterRing - 1 column groups has landed
             // (a group is 3 or 4 DMAs; the A loads are older): column 0 is in its slot
-            __builtin_amdgcn_s_waitcnt(kWaitVm9);
+            __builtin_amdgcn_s_waitcnt(kWaitFirst);
             asm volatile("" ::: "memory");
             fetch(0, B0, topN);
             f32x16 acc = mfma_tile<kFilterKM>(A[0], B0);
@@ -319,7 +325,7 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, 2) void dtw_filter_kerne
                         // column j+1 was staged kFilterRing - 1 columns ago; at least the two
                         // groups after it (>= 6 DMAs) are younger, so vmcnt(6) covers it -- and the
                         // hand-off group it may open, which was requested four columns ago
-                        __builtin_amdgcn_s_waitcnt(kWaitVm6);
+                        __builtin_amdgcn_s_waitcnt(kWaitLead);
                         asm volatile("" ::: "memory");
                         if ((q & 1) == 0)
                             fetch(j + 1, B1, topN);

@@ -14,8 +14,8 @@
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
-template <int NT>
-int run(int N, int M, int F, int reps, int blocksPerCU)
+template <int NT, int OCC>
+int run(int N, int M, int F, int reps)
 {
     using namespace ssym;
     constexpr int REC = kFilterRecHalfs;
@@ -29,6 +29,7 @@ int run(int N, int M, int F, int reps, int blocksPerCU)
     std::vector<int> ls(N, F), lt(M, F);
     _Float16 *ds, *dt; float *dc, *dc2, *dh; int *dls, *dlt; unsigned *dctr;
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+    const int blocksPerCU = OCC;
     const int grid = prop.multiProcessorCount * blocksPerCU / 8 * 8;
     CK(hipMalloc(&ds, hs.size() * 2)); CK(hipMalloc(&dt, ht.size() * 2));
     CK(hipMalloc(&dc, (size_t)N * M * 4)); CK(hipMalloc(&dc2, (size_t)N * M * 4)); CK(hipMalloc(&dls, N * 4)); CK(hipMalloc(&dlt, M * 4));
@@ -45,7 +46,7 @@ int run(int N, int M, int F, int reps, int blocksPerCU)
     taskChunk = std::max(1, std::min(taskChunk, nTasks / (grid * kFilterWavesPerBlock * 16)));
     auto launch = [&]() {
         (void)hipMemsetAsync(dctr, 0, 8 * kTaskCtrStride * sizeof(unsigned), 0);
-        dtw_filter_kernel<NT, SSYM_TOOL_SQ><<<grid, 64 * kFilterWavesPerBlock>>>(ds, dt, dls, dlt, rows, nPasses, F, M, nSrcPairs,
+        dtw_filter_kernel<NT, SSYM_TOOL_SQ, OCC><<<grid, 64 * kFilterWavesPerBlock>>>(ds, dt, dls, dlt, rows, nPasses, F, M, nSrcPairs,
                                                                          nTasks, taskChunk, 1.0f, dh, dctr, dc);
     };
     for (int w = 0; w < 2; ++w) launch();
@@ -73,15 +74,17 @@ int main(int argc, char **argv)
     int reps = argc > 3 ? atoi(argv[3]) : 5;
     int only = argc > 4 ? atoi(argv[4]) : -1;   // run a single variant (for rocprofv3 --pmc)
     int v = 0;
-#define VARIANT(NT, F, BPC) do { if (only < 0 || only == v) { if (run<NT>(N, M, F, reps, BPC)) return 1; } ++v; } while (0)
+#define VARIANT(NT, F, BPC) do { if (only < 0 || only == v) { if (run<NT, BPC>(N, M, F, reps)) return 1; } ++v; } while (0)
     VARIANT(4, 128, 2);     // 0: BASELINE shape: 128 frames = 2 passes of 64 rows
     VARIANT(4, 64, 2);      // 1: one pass
     VARIANT(3, 128, 2);     // 2: 3 passes of 48 rows (144 padded)
-    VARIANT(2, 128, 3);     // 3: 4 passes of 32 rows, 3 waves/SIMD
+    VARIANT(2, 128, 2);     // 3: (was three workgroups per CU; multi-pass shapes need the ring of 4)
     VARIANT(2, 128, 2);     // 4: same, 2 waves/SIMD
     VARIANT(4, 256, 2);     // 5: 256 frames = 4 passes
     VARIANT(3, 48, 2);      // 6: 48 frames, one pass
     VARIANT(2, 32, 2);      // 7: 32 frames, one pass
     VARIANT(1, 16, 2);      // 8: 16 frames, one pass
+    VARIANT(2, 32, 3);      // 9: 32 frames, three waves per SIMD, ring of 2
+    VARIANT(1, 16, 3);      // 10: 16 frames, three waves per SIMD
     return 0;
 }
