@@ -3,9 +3,10 @@
 Same names, argument meaning and error behaviour as the reference for the hot path
 (upstream src/sound.rs), so callers and tests read like the reference's own:
 
-    SoundDictionary.new / from_segments / add_segments      src/sound.rs:296, 323, 330
+    Sound.from_samples / from_path / write_file             src/sound.rs:92, 114, 129
+    SoundDictionary.new / from_path / from_segments / add_segments   src/sound.rs:296, 304, 323, 330
     SoundDictionary.match_sound / at_distance               src/sound.rs:346, 351
-    SoundSequence.new / morph_to / clone_from_dictionary    src/sound.rs:392, 440, 451
+    SoundSequence.new / from_timestamps / morph_to / clone_from_dictionary   src/sound.rs:392, 419, 440, 451
     SoundSequence.from_distances / to_sound                 src/sound.rs:405, 475
 
 Every comparison runs on the GPU through the C ABI (`engine.Engine`); this module only keeps the
@@ -65,6 +66,22 @@ class Sound:
             mfccs = e.mfcc(samples, sample_rate, ncoeffs).reshape(-1)
         return Sound(samples, sample_rate, mfccs, name, ncoeffs)
 
+    @staticmethod
+    def from_path(path, engine: Optional[Engine] = None) -> "Sound":
+        """Sound::from_path (src/sound.rs:114-127): read a WAV (integer PCM scaled by
+        i32::MAX >> (32 - bits), :116-119), name = file stem, features analysed (mfccs = None)."""
+        import os
+        from . import io as sio
+        samples, rate = sio.read_wav(str(path))
+        stem = os.path.splitext(os.path.basename(str(path)))[0]
+        return Sound.from_samples(samples, float(rate), None, stem, engine=engine)
+
+    def write_file(self, path) -> None:
+        """Sound::write_file (src/sound.rs:129-143): mono 32-bit integer WAV,
+        sample -> (i32::MAX as f64 * sample) as i32."""
+        from . import io as sio
+        sio.write_wav32(str(path), self._samples, int(self._sample_rate))
+
     def mean_mfccs(self) -> np.ndarray:       # src/sound.rs:205, analyze_mean_mfccs :271-286
         m = self.mfccs().reshape(-1, self.ncoeffs)
         acc = np.zeros(self.ncoeffs)
@@ -103,6 +120,18 @@ class SoundDictionary:
     @staticmethod
     def new(engine: Optional[Engine] = None) -> "SoundDictionary":     # src/sound.rs:296
         return SoundDictionary(engine)
+
+    @staticmethod
+    def from_path(path, engine: Optional[Engine] = None) -> "SoundDictionary":
+        """SoundDictionary::from_path (src/sound.rs:304-321): every *.wav of a directory, in directory
+        order (sorted here, so that indices do not depend on the file system), features analysed."""
+        import os
+        d = SoundDictionary(engine)
+        for name in sorted(os.listdir(str(path))):
+            if os.path.splitext(name)[1] != ".wav":
+                continue
+            d.sounds.append(Sound.from_path(os.path.join(str(path), name), engine=engine))
+        return d
 
     @staticmethod
     def from_segments(sound: Sound, segments: Sequence[int],
@@ -212,6 +241,17 @@ class SoundSequence:
 
     def sounds(self) -> List[Sound]:                                    # src/sound.rs:432
         return self._sounds
+
+    @staticmethod
+    def from_timestamps(sound: Sound, timestamps, engine: Optional[Engine] = None) -> "SoundSequence":
+        """SoundSequence::from_timestamps (src/sound.rs:419-430): one Sound per (start s, end s, label),
+        samples [round(start * rate), round(end * rate)] INCLUSIVE (:422-424), features analysed."""
+        out = []
+        smp, rate = sound.samples(), sound.sample_rate()
+        for start, end, label in timestamps:
+            a, b = int(round(start * rate)), int(round(end * rate))
+            out.append(Sound.from_samples(smp[a:b + 1].copy(), rate, None, label, sound.ncoeffs, engine=engine))
+        return SoundSequence(out)
 
     @staticmethod
     def from_distances(distances: Sequence[float], start: Sound,

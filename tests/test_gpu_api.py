@@ -193,3 +193,36 @@ def test_small_abi_entry_points():
     assert list(idx) == [0, 1, 2, 3, 4, 5]             # every segment finds itself, duplicates lose to the first
     e.synchronize()
     e.close()
+
+
+def test_sound_from_path_write_file_from_timestamps(tmp_path, oracle):
+    # the constructors around the path: Sound::from_path / write_file (src/sound.rs:114-143),
+    # SoundDictionary::from_path (:304-321), SoundSequence::from_timestamps (:419-430)
+    from soundsym_amd import Engine, api
+    from soundsym_amd import io as sio
+    eng = Engine(metric="refcos", dtype="f64")
+    rate = 22050
+    t = np.arange(rate) / rate
+    a = 0.4 * np.sin(2 * np.pi * 330 * t) + 0.1 * np.sin(2 * np.pi * 2100 * t)
+    s = api.Sound(a, rate, None, "tone")
+    s.write_file(tmp_path / "tone.wav")
+    back = api.Sound.from_path(tmp_path / "tone.wav", engine=eng)
+    assert back.name == "tone" and back.sample_rate() == rate
+    assert np.array_equal(back.samples(), sio.pcm32(a).astype(np.float64) / 2147483647.0)   # 32-bit round trip
+    want = oracle.mfcc(back.samples(), float(rate))
+    assert back.num_frames() == want.shape[0]
+    assert np.all(np.abs(back.mfccs().reshape(want.shape) - want) <= 1e-12 * (1 + np.abs(want)))
+    # a directory of sounds
+    for k, f0 in enumerate((220.0, 440.0, 880.0)):
+        api.Sound(0.3 * np.sin(2 * np.pi * f0 * t[:8192]), rate, None).write_file(tmp_path / f"s{k}.wav")
+    (tmp_path / "notes.txt").write_text("not a sound")
+    d = api.SoundDictionary.from_path(tmp_path, engine=eng)
+    assert [x.name for x in d.sounds] == ["s0", "s1", "s2", "tone"]
+    assert d.match_sound(d.sounds[1]) is d.sounds[1]
+    # timestamps: inclusive end sample (src/sound.rs:422-424)
+    seq = api.SoundSequence.from_timestamps(back, [(0.0, 0.25, "a"), (0.25, 0.6, None)], engine=eng)
+    n0 = int(round(0.25 * rate)) + 1
+    assert [x.samples().size for x in seq.sounds()] == [n0, int(round(0.6 * rate)) - int(round(0.25 * rate)) + 1]
+    assert seq.sounds()[0].name == "a" and np.array_equal(seq.sounds()[0].samples(), back.samples()[:n0])
+    assert seq.sounds()[0].num_frames() == (n0 - 1024) // 256 + 1
+    eng.close()
