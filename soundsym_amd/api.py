@@ -82,6 +82,10 @@ class Sound:
         from . import io as sio
         sio.write_wav32(str(path), self._samples, int(self._sample_rate))
 
+    def max_power(self) -> float:             # src/sound.rs:197, analyze_max_power :244-256 (host side)
+        from . import io as sio
+        return sio.max_power(self._samples)
+
     def mean_mfccs(self) -> np.ndarray:       # src/sound.rs:205, analyze_mean_mfccs :271-286
         m = self.mfccs().reshape(-1, self.ncoeffs)
         acc = np.zeros(self.ncoeffs)

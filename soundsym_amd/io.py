@@ -70,6 +70,28 @@ def write_wav32(path: str, samples=None, sample_rate: float = 44100.0, pcm: Opti
         f.write(hdr + body)
 
 
+def write_wav16(path: str, pcm16, sample_rate: float = 44100.0) -> None:
+    """Mono 16-bit integer PCM, the spec examples/matcher.rs writes (:22-27)."""
+    q = np.asarray(pcm16, dtype="<i2")
+    rate = int(sample_rate)
+    body = q.tobytes()
+    hdr = b"RIFF" + struct.pack("<I", 36 + len(body)) + b"WAVE" + b"fmt " + struct.pack(
+        "<IHHIIHH", 16, 1, 1, rate, rate * 2, 2, 16) + b"data" + struct.pack("<I", len(body))
+    with open(path, "wb") as f:
+        f.write(hdr + body)
+
+
+def max_power(samples) -> float:
+    """analyze_max_power (src/sound.rs:244-256): the largest RMS over 128-sample rectangular windows
+    hopped by 64 (full windows only, like the Windower; 0.0 when the sound is shorter than one)."""
+    x = np.asarray(samples, dtype=np.float64).reshape(-1)
+    if x.size < 128:
+        return 0.0
+    n = (x.size - 128) // 64 + 1
+    idx = np.arange(n)[:, None] * 64 + np.arange(128)[None, :]
+    return float(np.sqrt((x[idx] ** 2).sum(axis=1) / 128.0).max())
+
+
 def audacity_labels_to_timestamps(path: str) -> List[Tuple[float, float, Optional[str]]]:
     """src/sound.rs:510-532: one Timestamp(start, end, label) per line of a tab-separated file;
     a missing or unparsable number becomes 0.0, a missing label None."""

@@ -226,3 +226,36 @@ def test_sound_from_path_write_file_from_timestamps(tmp_path, oracle):
     assert seq.sounds()[0].name == "a" and np.array_equal(seq.sounds()[0].samples(), back.samples()[:n0])
     assert seq.sounds()[0].num_frames() == (n0 - 1024) // 256 + 1
     eng.close()
+
+
+def test_matcher_example_end_to_end(tmp_path, oracle):
+    """examples/matcher.py (the flow of examples/matcher.rs) on synthetic WAV directories."""
+    import importlib.util
+    import os
+    from soundsym_amd import api
+    from soundsym_amd import io as sio
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("matcher", os.path.join(here, "examples", "matcher.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rate = 22050
+    t = np.arange(6000) / rate
+    ddir, pdir = tmp_path / "dict", tmp_path / "phon"
+    ddir.mkdir(); pdir.mkdir()
+    tones = [0.5 * np.sin(2 * np.pi * f0 * t) * np.hanning(t.size) for f0 in (200.0, 500.0, 1300.0, 3100.0)]
+    for k, x in enumerate(tones):
+        api.Sound(x, rate, None).write_file(ddir / f"d{k}.wav")
+    api.Sound(tones[2][:5000] * 0.9, rate, None).write_file(pdir / "a.wav")        # nearest: d2, shorter
+    api.Sound(np.zeros(3000), rate, None).write_file(pdir / "b.wav")               # silence: max_power < 0.03
+    api.Sound(np.concatenate([tones[0], np.zeros(1500)]), rate, None).write_file(pdir / "c.wav")   # longer than its match
+    pcm = mod.main(["-d", str(ddir), "-p", str(pdir), "-o", str(tmp_path / "out.wav")])
+    assert pcm.size == 5000 + 3000 + 7500
+    assert not pcm[5000:8000].any()                                                  # the silent phoneme
+    back, r = sio.read_wav(str(tmp_path / "out.wav"))
+    assert r == rate and back.size == pcm.size
+    # first phoneme: dictionary entry d2 truncated to 5000 samples and scaled by 4^max_power
+    a = api.Sound.from_path(pdir / "a.wav")
+    d2, _ = sio.read_wav(str(ddir / "d2.wav"))
+    want = np.trunc(np.clip(d2[:5000] * 32767.0 * 4.0 ** a.max_power(), -32768, 32767)).astype(np.int16)
+    assert np.array_equal(pcm[:5000], want)
+    assert not pcm[8000 + 6000:].any()                                               # zero padding past the match
