@@ -48,3 +48,17 @@ def test_write_wav32_roundtrip_and_conversion(tmp_path, oracle):
     back, rate = sio.read_wav(p)
     assert rate == 22050.0
     assert np.array_equal(back, sio.pcm32(x).astype(np.float64) / 2147483647.0)
+
+
+def test_max_power_and_wav16(tmp_path):
+    # analyze_max_power (src/sound.rs:244-256): largest RMS over 128-sample windows hopped by 64
+    from soundsym_amd import io as sio
+    x = np.zeros(1000)
+    x[300:428] = 0.5                       # exactly one window (start 320 is not a hop multiple: 256 and 320 straddle it)
+    rms = [np.sqrt(np.mean(x[s:s + 128] ** 2)) for s in range(0, 1000 - 128 + 1, 64)]
+    assert sio.max_power(x) == max(rms) and 0.4 < sio.max_power(x) <= 0.5
+    assert sio.max_power(np.ones(100)) == 0.0          # shorter than one window: no frame at all
+    q = np.array([0, 1, -1, 32767, -32768], dtype=np.int16)
+    sio.write_wav16(str(tmp_path / "a.wav"), q, 8000)
+    back, rate = sio.read_wav(str(tmp_path / "a.wav"))
+    assert rate == 8000 and np.array_equal(back, q.astype(np.float64) / 32767.0)
