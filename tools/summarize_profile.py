@@ -72,6 +72,20 @@ def main():
         if "SQ_VALU_MFMA_BUSY_CYCLES" in p and "SQ_BUSY_CYCLES" in p:
             lines.append("MFMA busy cycles per launch = %.4g; SQ busy cycles = %.4g." %
                          (p["SQ_VALU_MFMA_BUSY_CYCLES"]["mean_per_launch"], p["SQ_BUSY_CYCLES"]["mean_per_launch"]))
+    if "GRBM_GUI_ACTIVE" in p and "SQ_ACTIVE_INST_VALU" in p:
+        # GRBM_GUI_ACTIVE sums the 8 XCDs' busy cycles; 1024 SIMDs; SQ counters are in quad-cycles
+        k = [k for k in out["kernels"] if "dtw_filter_kernel" in k["name"]]
+        cyc = p["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8.0
+        busy = 4.0 * p["SQ_ACTIVE_INST_VALU"]["mean_per_launch"] / (cyc * 1024.0)
+        out["valu_busy_fraction"] = busy
+        line = "Per-SIMD VALU busy fraction of the dominant kernel = %.3f (4 x SQ_ACTIVE_INST_VALU / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs))" % busy
+        if k:
+            ghz = cyc / (k[0]["avg_ms"] * 1e6)
+            out["clock_ghz_under_load"] = ghz
+            cells = 4096.0 * 4096.0 * 128.0 * 128.0 / 64.0
+            line += "; clock under load %.2f GHz; %.2f VALU-busy cycles and %.2f elapsed SIMD cycles per wave-cell (floor: 16)" % (
+                ghz, 4.0 * p["SQ_ACTIVE_INST_VALU"]["mean_per_launch"] / cells, cyc * 1024.0 / cells)
+        lines += ["", line + "."]
     os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
     open(dst + ".md", "w").write("\n".join(lines) + "\n")
     json.dump(out, open(dst + ".json", "w"), indent=1)
