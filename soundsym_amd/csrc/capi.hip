@@ -385,7 +385,11 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
         SSYM_HIP_CHECK(ctx, hipEventRecord(ev[2], st));
         tm.main_launches = 1;          // event times are read after the one synchronisation below
     } else {
-        const bool useFilter = !(flags & SSYM_DTW_FORCE_EXACT) && filter_supported(ctx, src, tgt);
+        // frames wider than the filter's 42 values: the filter scores the first 42 and bounds the cost from
+        // below; that supports the plain first-minimum search (no per-target distances, k = 1)
+        const bool wide = (int)src.dim > filter_dim_used((int)src.dim);
+        const bool useFilter = !(flags & SSYM_DTW_FORCE_EXACT) && filter_supported(ctx, src, tgt) &&
+                               (!wide || (k_top == 1 && !(phase == 2 ? ctx->pending.has_dist : distance != nullptr)));
         tm.used_filter = useFilter ? 1 : 0;
         if (useFilter) {
             rc = ensure(ctx, ctx->cmat, sizeof(float) * (size_t)src.n_pad * tgt.n_pad);
@@ -398,7 +402,8 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
                 if (rc != SSYM_OK)
                     return rc;
                 SSYM_HIP_CHECK(ctx, hipEventRecord(ev[1], st));
-                rc = launch_dtw_bounds(ctx, src, tgt, cmat, distDev, k_top);
+                rc = wide ? launch_dtw_bounds_partial(ctx, src, tgt, cmat)
+                          : launch_dtw_bounds(ctx, src, tgt, cmat, distDev, k_top);
                 if (rc != SSYM_OK)
                     return rc;
             }
@@ -441,7 +446,7 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
                 if (rc != SSYM_OK)
                     return rc;
                 rc = launch_dtw_select2(ctx, src, tgt, cmat, (const float *)ctx->cand_xmin.ptr, distDev,
-                                        (uint32_t)cap, k_top);                                  // stage 2
+                                        (uint32_t)cap, k_top, wide);                            // stage 2
                 if (rc != SSYM_OK)
                     return rc;
                 SSYM_HIP_CHECK(ctx, hipEventRecord(ev[3], st));
@@ -462,6 +467,8 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
                 SSYM_HIP_CHECK(ctx, hipMemcpyAsync(h1, hdr1, sizeof(h1), hipMemcpyDeviceToHost, st));
                 SSYM_HIP_CHECK(ctx, hipMemcpyAsync(h2, hdr2, sizeof(h2), hipMemcpyDeviceToHost, st));
                 SSYM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+                if (attempt == 0 && phase != 2)
+                    sel_ms += ev_ms(ev[1], ev[2]);      // the per-target threshold (bounds) belongs to selection
                 sel_ms += ev_ms(ev[2], ev[3]);
                 ref_ms += ev_ms(ev[3], ev[4]);
                 red_ms += ev_ms(ev[4], ev[5]);
@@ -566,7 +573,9 @@ int32_t ssym_match_begin(ssym_ctx *ctx, const ssym_dict *dict, const ssym_querie
     const uint32_t M = q->set.n;
     if (distance)
         pd.dist_host.assign(distance, distance + M);
-    pd.filter = ctx->metric == SSYM_METRIC_DTW && M > 0 && filter_supported(ctx, dict->set, q->set);
+    const bool wideFrames = (int)dict->set.dim > filter_dim_used((int)dict->set.dim);
+    pd.filter = ctx->metric == SSYM_METRIC_DTW && M > 0 && filter_supported(ctx, dict->set, q->set) &&
+                (!wideFrames || !distance);
     if (pd.filter) {
         rc = match_impl(ctx, dict, q, distance, index_base, 1, nullptr, nullptr, 0, 1, bounds_dev);
         if (rc != SSYM_OK)

@@ -138,15 +138,20 @@ __global__ __launch_bounds__(64) void dtw_exact_kernel(
                         double acc = 0.0;
                         uint32_t e = 0;
                         for (; e + 8 <= dim; e += 8) {
-                            double sq[8];
+                            // all sixteen loads of the block first, then the arithmetic: left alone the
+                            // compiler waits on LDS after every two values
+                            double av[8], bw[8];
 #pragma unroll
                             for (int v = 0; v < 8; ++v) {
-                                const double df = __dsub_rn(arow[e + v], bj[e + v]);
-                                sq[v] = __dmul_rn(df, df);
+                                av[v] = arow[e + v];
+                                bw[v] = bj[e + v];
                             }
+                            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                            for (int v = 0; v < 8; ++v)
-                                acc = __dadd_rn(acc, sq[v]);
+                            for (int v = 0; v < 8; ++v) {
+                                const double df = __dsub_rn(av[v], bw[v]);
+                                acc = __dadd_rn(acc, __dmul_rn(df, df));
+                            }
                         }
                         for (; e < dim; ++e) {
                             const double df = __dsub_rn(arow[e], bj[e]);

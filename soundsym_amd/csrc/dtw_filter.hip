@@ -27,7 +27,7 @@ namespace ssym {
 // their DP cells stay at +inf; empty target slots are all-zero records.
 __global__ void build_filter_records_kernel(const double *__restrict__ raw, const uint64_t *__restrict__ off,
                                             const uint32_t *__restrict__ perm, uint32_t n, uint32_t dim,
-                                            uint32_t frames_pad, int is_source,
+                                            uint32_t dimUse, uint32_t frames_pad, int is_source,
                                             int lead, int pieces, double scale, _Float16 *__restrict__ rec)
 {
     const uint32_t s = blockIdx.y;                              // record slot of the segment, < n_pad
@@ -44,11 +44,11 @@ __global__ void build_filter_records_kernel(const double *__restrict__ raw, cons
     const bool real = slot >= first && slot < first + nf;
     const uint32_t f = slot - first;
     if (!real && is_source)
-        out[filter_slot_offset((pieces == 2 ? 3 : 1) * (int)dim)] = (_Float16)__builtin_inff();   // |a|^2 = +inf
+        out[filter_slot_offset((pieces == 2 ? 3 : 1) * (int)dimUse)] = (_Float16)__builtin_inff();   // |a|^2 = +inf
     if (real) {
         const double *p = raw + (off[seg] + f) * dim;
         double nrm = 0.0;
-        for (uint32_t e = 0; e < dim; ++e) {
+        for (uint32_t e = 0; e < dimUse; ++e) {                  // frames wider than 42 values: the first 42
             const double v = p[e] * scale;                       // exact: scale is a power of two
             const _Float16 h1 = (_Float16)v;
             const _Float16 h2 = pieces == 2 ? (_Float16)(v - (double)h1) : (_Float16)0.0f;
@@ -66,7 +66,7 @@ __global__ void build_filter_records_kernel(const double *__restrict__ raw, cons
         const _Float16 p1 = (_Float16)nrm;
         const _Float16 p2 = (_Float16)(nrm - (double)p1);
         const _Float16 p3 = (_Float16)(nrm - (double)p1 - (double)p2);
-        const int nbase = (pieces == 2 ? 3 : 1) * (int)dim;
+        const int nbase = (pieces == 2 ? 3 : 1) * (int)dimUse;
         const int mine = nbase + (is_source ? 0 : 3), other = nbase + (is_source ? 3 : 0);
         out[filter_slot_offset(mine + 0)] = p1;
         out[filter_slot_offset(mine + 1)] = p2;
@@ -107,8 +107,8 @@ static size_t band_lds_bytes(int radius, const SegmentSet &src, const SegmentSet
 
 bool filter_supported(const ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt)
 {
-    if (src.dim != tgt.dim || (int)src.dim > kFilterMaxDim1)
-        return false;
+    if (src.dim != tgt.dim)
+        return false;   // (frames wider than 42 values: capi.hip decides, the filter is then a lower bound only)
     if (ctx->band >= 0) {
         // banded kernel: 2r+1 diagonals in registers (<= 6 tiles) and the source pair in LDS
         if (2 * ctx->band + 1 > 6 * 16)
@@ -152,9 +152,10 @@ static int32_t ensure_records(ssym_ctx *ctx, const SegmentSet &set, double scale
     }
     set.rec_bytes = bytes;
     dim3 grid((slots + 63) / 64, set.n_pad);
-    build_filter_records_kernel<<<grid, 64, 0, ctx->stream>>>(set.raw, set.off, set.perm, set.n, set.dim, slots,
-                                                              set.is_source ? 1 : 0, lead,
-                                                              filter_pieces((int)set.dim), scale,
+    const int dimUse = filter_dim_used((int)set.dim);
+    build_filter_records_kernel<<<grid, 64, 0, ctx->stream>>>(set.raw, set.off, set.perm, set.n, set.dim,
+                                                              (uint32_t)dimUse, slots, set.is_source ? 1 : 0, lead,
+                                                              filter_pieces(dimUse), scale,
                                                               (_Float16 *)set.rec);
     SSYM_HIP_CHECK(ctx, hipGetLastError());
     set.rec_scale = scale;

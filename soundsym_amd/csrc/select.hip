@@ -550,7 +550,7 @@ static MarginParams margin_params(const ssym_ctx *ctx, const SegmentSet &src)
 {
     MarginParams mp;
     mp.inv_scale2 = src.rec_scale > 0.0 ? 1.0 / (src.rec_scale * src.rec_scale) : 1.0;
-    mp.in_round = filter_pieces((int)src.dim) == 2 ? 2.384185791015625e-07 : 4.8828125e-04;
+    mp.in_round = filter_pieces(filter_dim_used((int)src.dim)) == 2 ? 2.384185791015625e-07 : 4.8828125e-04;
     mp.squared = ctx->squared;
     return mp;
 }
@@ -567,7 +567,8 @@ static int32_t topk_scratch(ssym_ctx *ctx, uint32_t m, unsigned long long **prev
 }
 
 int32_t launch_dtw_select2(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, const float *cmat,
-                           const float *xmin, const double *dist_dev, uint32_t cap, uint32_t k_top)
+                           const float *xmin, const double *dist_dev, uint32_t cap, uint32_t k_top,
+                           bool lower_bound_only)
 {
     hipStream_t st = ctx->stream;
     const MarginParams mp = margin_params(ctx, src);
@@ -587,7 +588,10 @@ int32_t launch_dtw_select2(ssym_ctx *ctx, const SegmentSet &src, const SegmentSe
     fill_u64_kernel<<<tb, 256, 0, st>>>(ub, kInfBits, tgt.n);
     SSYM_HIP_CHECK(ctx, hipMemsetAsync(hdr2, 0, sizeof(uint32_t) * 2, st));
     const unsigned blocks = std::max(1u, std::min((cap + 255) / 256, 2048u));
-    if (k_top <= 1) {
+    if (lower_bound_only) {
+        // wide frames: a filter cost bounds the pair from below only, so no new upper bound comes out of
+        // list 1; the certificates still sharpen every pair's LOWER end against the stage-1 threshold
+    } else if (k_top <= 1) {
         dtw_stage2_ub_kernel<<<blocks, 256, 0, st>>>(hdr1, pairs1, xmin, cap, cmat, tgt.n_pad, dist_dev, src.len,
                                                      src.max_sqnorm, tgt.len, tgt.max_sqnorm, mp, tgt.perm, nullptr, ub);
     } else {
@@ -638,6 +642,70 @@ int32_t launch_dtw_bounds(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
             topk_advance_kernel<<<(tgt.n + 255) / 256, 256, 0, st>>>(ub, prev, tgt.n, (int)r, r + 1 == k_top);
         }
     }
+    SSYM_HIP_CHECK(ctx, hipGetLastError());
+    return SSYM_OK;
+}
+
+// ---- wide frames (more values per frame than the filter takes in) -------------------------------
+// The filter then scores pairs on their first 42 values only: every local cost shrinks, DTW is
+// monotone in the local costs, so its result is a LOWER bound of the pair's cost.  An upper bound per
+// target comes from one exact evaluation: the pair the filter likes best.  Every pair whose lower
+// bound (minus the filter's own error) does not exceed that exact cost may still win and is
+// re-scored; the true first minimum is among them because its cost is <= the evaluated pair's.
+__global__ __launch_bounds__(256) void dtw_partial_argmin_kernel(const float *__restrict__ cmat, uint32_t nSrc,
+                                                                 uint32_t nTgt, uint32_t mPad,
+                                                                 const uint32_t *__restrict__ permS,
+                                                                 const uint32_t *__restrict__ permT,
+                                                                 uint32_t *__restrict__ hdr,
+                                                                 uint2 *__restrict__ pairs)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;      // target slot
+    if (t == 0)
+        hdr[0] = nTgt, hdr[1] = 0;
+    if (t >= nTgt)
+        return;
+    float best = __builtin_inff();
+    uint32_t bs = 0;
+    for (uint32_t s = 0; s < nSrc; ++s) {
+        const float c = cmat[(size_t)s * mPad + t];
+        if (c < best) {
+            best = c;
+            bs = s;
+        }
+    }
+    pairs[t] = make_uint2(permS[bs], permT[t]);                    // exact kernel: the caller's indices
+}
+
+__global__ void dtw_partial_threshold_kernel(const double *__restrict__ exact, uint32_t nTgt,
+                                             unsigned long long *__restrict__ ub)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nTgt)
+        return;
+    const double c = exact[t];
+    ub[t] = c == c ? (unsigned long long)__double_as_longlong(c < 0.0 ? 0.0 : c) : kInfBits;   // NaN: nothing can win
+}
+
+int32_t launch_dtw_bounds_partial(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, const float *cmat)
+{
+    hipStream_t st = ctx->stream;
+    int32_t rc = ensure(ctx, ctx->tmin, sizeof(unsigned long long) * tgt.n);
+    if (rc == SSYM_OK)
+        rc = ensure(ctx, ctx->cand2, sizeof(uint32_t) * 2 + sizeof(uint2) * (size_t)tgt.n);
+    if (rc == SSYM_OK)
+        rc = ensure(ctx, ctx->cand_cost, sizeof(double) * tgt.n);
+    if (rc != SSYM_OK)
+        return rc;
+    uint32_t *hdr = (uint32_t *)ctx->cand2.ptr;
+    uint2 *pairs = (uint2 *)(hdr + 2);
+    const unsigned tb = (tgt.n + 255) / 256;
+    dtw_partial_argmin_kernel<<<tb, 256, 0, st>>>(cmat, src.n, tgt.n, tgt.n_pad, src.perm, tgt.perm, hdr, pairs);
+    SSYM_HIP_CHECK(ctx, hipGetLastError());
+    rc = launch_dtw_exact(ctx, src, tgt, pairs, hdr, tgt.n, (double *)ctx->cand_cost.ptr);
+    if (rc != SSYM_OK)
+        return rc;
+    dtw_partial_threshold_kernel<<<tb, 256, 0, st>>>((const double *)ctx->cand_cost.ptr, tgt.n,
+                                                     (unsigned long long *)ctx->tmin.ptr);
     SSYM_HIP_CHECK(ctx, hipGetLastError());
     return SSYM_OK;
 }

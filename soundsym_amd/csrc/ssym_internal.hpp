@@ -31,6 +31,9 @@ inline FilterShape filter_shape(int max_frames)
 
 // f16 pieces per value in the filter records: two up to 13 dims, one up to 42 (dtw_filter_kernel.hpp)
 inline int filter_pieces(int dim) { return dim <= 13 ? 2 : 1; }
+// values per frame the filter sees: frames wider than 42 values enter with their first 42 only, which
+// makes the filter's cost a LOWER bound of the pair's cost ("wide frames")
+inline int filter_dim_used(int dim) { return dim <= 42 ? dim : 42; }
 
 struct DeviceBuf {
     void *ptr = nullptr;
@@ -201,11 +204,15 @@ int32_t launch_dtw_exact(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet 
 // stage 1: worst-case margin over the whole filter matrix -> ctx->cand (list 1)
 int32_t launch_dtw_bounds(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, const float *cmat,
                           const double *dist_dev, uint32_t k_top);      // threshold per target -> ctx->tmin
+// wide frames: the filter cost is only a lower bound; the threshold is the EXACT cost of the pair the
+// filter likes best per target (one exact evaluation per target) -> ctx->tmin
+int32_t launch_dtw_bounds_partial(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, const float *cmat);
 int32_t launch_dtw_select(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt,
                           const float *cmat, const double *dist_dev, uint32_t cap);
 // stage 2: per-pair intervals from the certificates of list 1 -> ctx->cand2 (list 2, same capacity)
 int32_t launch_dtw_select2(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, const float *cmat,
-                           const float *xmin, const double *dist_dev, uint32_t cap, uint32_t k_top);
+                           const float *xmin, const double *dist_dev, uint32_t cap, uint32_t k_top,
+                           bool lower_bound_only = false);
 int32_t launch_dtw_final(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt,
                          const double *dist_dev, uint32_t cap, uint32_t index_base, uint32_t k_top,
                          uint32_t *out_idx_dev, double *out_cost_dev);

@@ -345,15 +345,16 @@ def test_dtw_banded_ragged_lengths(oracle):
         e.close()
 
 
-def test_dtw_very_wide_bands_and_frames_use_the_exact_kernel(oracle):
-    # more than 42 values per frame, or a band wider than 6 tiles of diagonals, are outside the MFMA
-    # filter: exact f64 kernel on every pair, including its own 64-row chunking (150 frames = 3 chunks)
+def test_dtw_very_wide_bands_use_the_exact_kernel_and_wide_frames_the_bound(oracle):
+    # more than 42 values per frame: the filter bounds the cost from below (its first 42 values); a band
+    # wider than 6 tiles of diagonals is outside the filter: exact f64 kernel on every pair, including
+    # its own 64-row chunking (150 frames = 3 chunks)
     g = synth.make_grid(5, 4, 20, 50, 0x5EED0323)
     sf, so = g.flat("sources")
     tf, to = g.flat("targets")
     ew = Engine(metric="dtw", dtype="f32")
     idx, cost = ew.match(ew.dictionary(sf, so, 50), ew.queries(tf, to, 50))
-    assert ew.timings()["used_filter"] == 0
+    assert ew.timings()["used_filter"] == 1
     want_idx, want_cost = oracle.dtw_match_all(sf.astype(np.float64), so, tf.astype(np.float64), to, 50)
     assert np.array_equal(idx, want_idx) and np.allclose(cost, want_cost, rtol=EXACT_RTOL, atol=0)
     ew.close()
@@ -537,21 +538,55 @@ def test_rows_f_golden_fixture(refcos):
     assert np.array_equal(ci, f["chain_idx"]) and np.array_equal(cv, f["chain_val"])
 
 
-@pytest.mark.parametrize("dim,band", [(45, -1), (48, 6), (64, -1), (100, 3)])
-def test_dtw_wide_frames_run_on_the_exact_kernels(oracle, dim, band):
-    # frames wider than the filter's 42 values: <= 48 on the register variant of the exact kernel,
-    # beyond that on the generic one; results are still the oracle's
+@pytest.mark.parametrize("dim,band", [(45, -1), (48, 6), (64, -1), (100, 3), (64, 40)])
+def test_dtw_wide_frames_use_the_filter_as_a_lower_bound(oracle, dim, band):
+    # frames wider than the filter's 42 values: the filter scores the first 42 (a lower bound of the
+    # cost), one exact evaluation per target gives the upper bound, the survivors are re-scored
     rng = np.random.default_rng(dim)
-    src = [rng.normal(size=(int(rng.integers(1, 90)), dim)).astype(np.float32) for _ in range(21)]
-    tgt = [rng.normal(size=(int(rng.integers(1, 90)), dim)).astype(np.float32) for _ in range(9)]
+    sig = synth.sigma(dim)
+    src = [(rng.normal(size=(int(rng.integers(1, 90)), dim)) * sig).astype(np.float32) for _ in range(61)]
+    tgt = [(rng.normal(size=(int(rng.integers(1, 90)), dim)) * sig).astype(np.float32) for _ in range(19)]
     tgt[4] = src[8].copy()
+    src[30] = src[8].copy()                                  # duplicate: the lower index wins
     sf, so = pack_segments(src, dim, np.float32)
     tf, to = pack_segments(tgt, dim, np.float32)
     e = Engine(metric="dtw", dtype="f32", band=band)
-    idx, cost = e.match(e.dictionary(sf, so, dim), e.queries(tf, to, dim))
-    assert e.timings()["used_filter"] == 0
-    want_idx, want_cost = oracle.dtw_match_all(sf.astype(np.float64), so, tf.astype(np.float64), to, dim, band=band)
+    d, q = e.dictionary(sf, so, dim), e.queries(tf, to, dim)
+    idx, cost = e.match(d, q)
+    tm = e.timings()
+    want_idx, want_cost, mat = oracle.dtw_match_all(sf.astype(np.float64), so, tf.astype(np.float64), to, dim,
+                                                    band=band, want_matrix=True)
     assert np.array_equal(idx, want_idx)
     fin = np.isfinite(want_cost)
     assert np.allclose(cost[fin], want_cost[fin], rtol=EXACT_RTOL, atol=0) and np.isinf(cost[~fin]).all()
+    if band <= 47:
+        assert tm["used_filter"] == 1 and tm["n_refined"] < len(src) * len(tgt) // 2
+        # the filter matrix never exceeds the exact cost by more than its own error
+        fm = e.pair_matrix(d, q)
+        ok = np.isfinite(mat)
+        lens = np.diff(so).astype(np.float64)[:, None] + np.diff(to).astype(np.float64)[None, :]
+        assert np.all(fm[ok] <= mat[ok] + 2e-3 * (1.0 + mat[ok]) + 2.0 ** -11 * 2 * 12.0 * lens[ok])
+    else:
+        assert tm["used_filter"] == 0                        # band beyond the filter's reach: exact kernel
+    # per-target distances and top-k on wide frames go through the exact kernel on every pair
+    dist = np.nanmedian(np.where(np.isfinite(mat), mat, np.nan), axis=0)
+    dist = np.nan_to_num(dist, nan=1.0)
+    i2, c2 = e.match(d, q, distance=dist)
+    assert e.timings()["used_filter"] == 0
+    key = np.where(np.isfinite(mat), np.abs(mat - dist[None, :]), np.inf)
+    assert np.array_equal(i2, np.where(np.isfinite(key).any(axis=0), key.argmin(axis=0), 0))
+    e.close()
+
+
+def test_dtw_very_wide_frames_generic_exact_kernel(oracle):
+    # wider than 48 values with per-target distances: the generic exact kernel on every pair
+    rng = np.random.default_rng(100)
+    src = [rng.normal(size=(int(rng.integers(1, 40)), 100)).astype(np.float32) for _ in range(15)]
+    tgt = [rng.normal(size=(int(rng.integers(1, 40)), 100)).astype(np.float32) for _ in range(6)]
+    sf, so = pack_segments(src, 100, np.float32)
+    tf, to = pack_segments(tgt, 100, np.float32)
+    e = Engine(metric="dtw", dtype="f32")
+    idx, cost = e.match(e.dictionary(sf, so, 100), e.queries(tf, to, 100), force_exact=True)
+    want_idx, want_cost = oracle.dtw_match_all(sf.astype(np.float64), so, tf.astype(np.float64), to, 100)
+    assert np.array_equal(idx, want_idx) and np.allclose(cost, want_cost, rtol=EXACT_RTOL, atol=0)
     e.close()
