@@ -1,7 +1,8 @@
 """Seeded random differential tests: small ragged problems of every shape class against the oracle.
 
 Covers what the hand-written cases may miss: empty segments anywhere, 1-frame segments, lengths
-straddling tile / pass / chunk boundaries (16, 48, 64, 128), dims 1..42 (both record layouts), bands
+straddling tile / pass / chunk boundaries (16, 48, 64, 128), dims 1..90 (both record layouts and the
+lower-bound cascade for frames wider than 42 values), bands
 from 0 to beyond the filter's reach, squared local cost, f32 and f64 inputs, per-target distances.
 """
 import numpy as np
@@ -25,7 +26,7 @@ def _ragged(st, n, lo, hi, dim, scale):
 @pytest.mark.parametrize("case", range(_N_DTW))
 def test_dtw_random_shapes(oracle, case):
     st = synth.Stream(0x5EED1000 + case)
-    dim = int([1, 2, 5, 12, 13, 14, 20, 40, 42][st.integers(1, 9)[0]])
+    dim = int([1, 2, 5, 12, 13, 14, 20, 40, 42, 43, 64, 90][st.integers(1, 12)[0]])
     hi = int([3, 17, 33, 50, 66, 130, 150][st.integers(1, 7)[0]])
     lo = int(st.integers(1, 2)[0])                      # 0 or 1: empty segments allowed
     n, m = int(2 + st.integers(1, 30)[0]), int(1 + st.integers(1, 40)[0])
