@@ -188,7 +188,7 @@ __global__ __launch_bounds__(64) void dtw_exact_kernel(
 //     every two values -- and the loads of step tau + 1 are in flight while step tau computes;
 //   * (0 - 0)^2 = +0.0 added to a non-negative sum leaves it unchanged bit for bit, so the padding
 //     does not alter the result.
-template <int DIMR>
+template <int DIMR, int PARTS = 1>
 __global__ __launch_bounds__(64) void dtw_exact_reg_kernel(
     const double *__restrict__ srcRaw, const uint64_t *__restrict__ srcOff,
     const double *__restrict__ tgtRaw, const uint64_t *__restrict__ tgtOff, uint32_t nSrc,
@@ -274,24 +274,26 @@ __global__ __launch_bounds__(64) void dtw_exact_reg_kernel(
             double diagReg = INF;   // D(r-1, j-1)
             const int tauEnd = jhi + rowsHere;     // exclusive: lane l works on column tau - l
             typedef double d2 __attribute__((ext_vector_type(2)));
-            d2 bv[DIMR / 2], bn[DIMR / 2];
-            {
+            constexpr int PW = DIMR / PARTS;              // values fetched at a time
+            d2 bv[PW / 2], bn[PARTS == 1 ? PW / 2 : 1];
+            if (PARTS == 1) {
                 const int jc = min(max(jlo - lane, wlo), whi) - wlo;
                 const d2 *bp = reinterpret_cast<const d2 *>(ldsB + (size_t)jc * LD);
 #pragma unroll
-                for (int e = 0; e < DIMR / 2; ++e)
+                for (int e = 0; e < PW / 2; ++e)
                     bn[e] = bp[e];
             }
             for (int tau = jlo; tau < tauEnd; ++tau) {
                 const int j = tau - lane;
+                if (PARTS == 1) {
 #pragma unroll
-                for (int e = 0; e < DIMR / 2; ++e)
-                    bv[e] = bn[e];
-                {   // next step's frame (clamped to a valid row; unused when out of range)
+                    for (int e = 0; e < PW / 2; ++e)
+                        bv[e] = bn[e];
+                    // next step's frame (clamped to a valid row; unused when out of range)
                     const int jc = min(max(j + 1, wlo), whi) - wlo;
                     const d2 *bp = reinterpret_cast<const d2 *>(ldsB + (size_t)jc * LD);
 #pragma unroll
-                    for (int e = 0; e < DIMR / 2; ++e)
+                    for (int e = 0; e < PW / 2; ++e)
                         bn[e] = bp[e];
                 }
                 double fromAbove = shfl_up1(mine);        // D(r-1, j) for lanes >= 1
@@ -307,10 +309,27 @@ __global__ __launch_bounds__(64) void dtw_exact_reg_kernel(
                 }
                 // sum_k (a_k - b_k)^2, k ascending, sub / mul / add rounded separately (the oracle's order)
                 double acc = 0.0;
+                if (PARTS == 1) {
 #pragma unroll
-                for (int e = 0; e < DIMR; ++e) {
-                    const double df = __dsub_rn(ar[e], bv[e >> 1][e & 1]);
-                    acc = __dadd_rn(acc, __dmul_rn(df, df));
+                    for (int e = 0; e < DIMR; ++e) {
+                        const double df = __dsub_rn(ar[e], bv[e >> 1][e & 1]);
+                        acc = __dadd_rn(acc, __dmul_rn(df, df));
+                    }
+                } else {
+                    // frames too wide to double-buffer in registers: this step's frame in PARTS fetches
+                    const int jc = min(max(j, wlo), whi) - wlo;
+#pragma unroll
+                    for (int h = 0; h < PARTS; ++h) {
+                        const d2 *bp = reinterpret_cast<const d2 *>(ldsB + (size_t)jc * LD + h * PW);
+#pragma unroll
+                        for (int e = 0; e < PW / 2; ++e)
+                            bv[e] = bp[e];
+#pragma unroll
+                        for (int e = 0; e < PW; ++e) {
+                            const double df = __dsub_rn(ar[h * PW + e], bv[e >> 1][e & 1]);
+                            acc = __dadd_rn(acc, __dmul_rn(df, df));
+                        }
+                    }
                 }
                 const double c = squared ? acc : sqrt(acc);
                 const bool active = rowValid && j >= 0 && j < Fb;
@@ -361,22 +380,28 @@ int32_t launch_dtw_exact(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet 
     hipStream_t st = ctx->stream;
     // frames of up to 48 values: source frame in registers, target frames zero-padded in LDS
     const uint32_t fbEven = (fbCap + 1) & ~1u;
-    const int dimr = dim <= 12 ? 12 : dim <= 14 ? 14 : dim <= 16 ? 16 : dim <= 40 ? 40 : dim <= 48 ? 48 : 0;
+    const int dimr = dim <= 12 ? 12 : dim <= 14 ? 14 : dim <= 16 ? 16 : dim <= 40 ? 40 : dim <= 48 ? 48 : dim <= 64 ? 64 : 0;
     const int ldr = (dimr % 4 == 2) ? dimr : dimr + 2;
     // staged target rows: all of them, or (banded) the widest window a 64-row chunk can reach
     const uint32_t winRows = ctx->band >= 0 ? std::min<uint32_t>(fbEven, 64 + 2 * (uint32_t)ctx->band + 2) : fbEven;
     const size_t regLds = 2 * (size_t)fbEven * sizeof(double) + (size_t)winRows * ldr * sizeof(double);
-    if (dimr && regLds <= 64 * 1024) {
-#define SSYM_EXACT_REG(D_)                                                                                     \
-    dtw_exact_reg_kernel<D_><<<grid, 64, regLds, st>>>(src.raw, src.off, tgt.raw, tgt.off, src.n, tgt.n, dim,   \
-                                                       ctx->band, ctx->squared, pairs, count_dev, max_pairs,   \
-                                                       fbEven, out)
+    if (dimr && regLds <= (size_t)(dimr == 64 ? 150 : 64) * 1024) {
+#define SSYM_EXACT_REG(...)                                                                                    \
+    do {                                                                                                       \
+        auto kern = dtw_exact_reg_kernel<__VA_ARGS__>;                                                         \
+        if (regLds > 64 * 1024)                                                                                \
+            SSYM_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                                    (int)regLds));                                             \
+        kern<<<grid, 64, regLds, st>>>(src.raw, src.off, tgt.raw, tgt.off, src.n, tgt.n, dim, ctx->band,      \
+                                       ctx->squared, pairs, count_dev, max_pairs, fbEven, out);                \
+    } while (0)
         switch (dimr) {
         case 12: SSYM_EXACT_REG(12); break;
         case 14: SSYM_EXACT_REG(14); break;
         case 16: SSYM_EXACT_REG(16); break;
         case 40: SSYM_EXACT_REG(40); break;
-        default: SSYM_EXACT_REG(48); break;
+        case 48: SSYM_EXACT_REG(48); break;
+        default: SSYM_EXACT_REG(64, 2); break;      // 49..64 values: the frame is fetched in two halves
         }
 #undef SSYM_EXACT_REG
         SSYM_HIP_CHECK(ctx, hipGetLastError());
