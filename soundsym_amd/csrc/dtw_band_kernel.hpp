@@ -98,13 +98,18 @@ __global__ __launch_bounds__(64 * WB, OCC) void dtw_band_kernel(
             B0[m] = half8{0, 0, 0, 0, 0, 0, 0, 0};
         if (nCols > 0)
             load_tgt_rec(bbase, 0, B0);
-        // software pipeline as in dtw_filter_kernel.hpp: the MFMA chain of the NEXT tile (next
-        // column's first tile after the last one) is in flight while this tile's cells run
+        // Software pipeline: while the cells of tile T run on the VALU, the three chained MFMAs of the NEXT
+        // step (next tile; after the last tile, tile 0 of the next column) are issued BETWEEN the cells --
+        // issued back to back at the top of a tile each waited for its predecessor and kept the wave off
+        // the VALU for ~80 cycles per tile -- and the operands of the step AFTER that are on their way
+        // from LDS (An).  Steps run column-major: (j, 0), ..., (j, NTB-1), (j+1, 0), ...
         f32x16 acc;
+        half8 An[kFilterKM];
         {
             half8 A[kFilterKM];
             load_rec(aLane, A);                        // column 0, tile 0
             acc = mfma_tile<kFilterKM>(A, B0);
+            load_rec(aLane + (size_t)(1 / NTB) * REC + (size_t)(1 % NTB) * 16 * REC, An);     // the step after it
         }
 
         for (int j0 = 0; j0 < nCols; j0 += 2) {
@@ -122,19 +127,25 @@ __global__ __launch_bounds__(64 * WB, OCC) void dtw_band_kernel(
                     float up = INF;
 #pragma unroll
                     for (int T = 0; T < NTB; ++T) {
-                        f32x16 accn;
-                        {
-                            half8 A[kFilterKM];
-                            if (T + 1 < NTB) {
-                                load_rec(aCol + (size_t)(T + 1) * 16 * REC, A);
-                                accn = (par == 0) ? mfma_tile<kFilterKM>(A, B0) : mfma_tile<kFilterKM>(A, B1);
-                            } else {
-                                load_rec(aCol + REC, A);   // column j+1, tile 0 (slots stay inside the window)
-                                accn = (par == 0) ? mfma_tile<kFilterKM>(A, B1) : mfma_tile<kFilterKM>(A, B0);
-                            }
-                        }
+                        // this step's MFMA operands (loaded during the previous tile) ...
+                        half8 Ac[kFilterKM];
+#pragma unroll
+                        for (int m = 0; m < kFilterKM; ++m)
+                            Ac[m] = An[m];
+                        // ... and the next one's (slots stay inside the staged window)
+                        load_rec(aCol + (size_t)((T + 2) / NTB) * REC + (size_t)((T + 2) % NTB) * 16 * REC, An);
+                        const bool sameCol = T + 1 < NTB;      // the step being issued belongs to column j
+                        f32x16 accn = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                        const int nCells = (T == NTB - 1) ? LASTN : 16;
 #pragma unroll
                         for (int r = 0; r < (T == NTB - 1 ? LASTN : 16); ++r) {
+                            // one MFMA of the chain every few cells (all three at once when the tile has one cell)
+#pragma unroll
+                            for (int m = 0; m < kFilterKM; ++m)
+                                if (r == (nCells >= 11 ? 5 * m : 0)) {
+                                    const half8 &b = ((par == 0) == sameCol) ? B0[m] : B1[m];
+                                    accn = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ac[m], b, accn, 0, 0, 0);
+                                }
                             const int k = T * 16 + r;
                             const float x = acc[r];
                             float c = SQ ? __builtin_fabsf(x) : __builtin_amdgcn_sqrtf(__builtin_fabsf(x));
