@@ -169,12 +169,18 @@ def main():
     n_src_total = args.src_per_gpu * n_gpus
     m = args.targets
 
-    # synthetic workload (seeded; every rank builds the same grid and keeps its source shard)
+    # synthetic workload (seeded; the generator is counter-based, so each rank materialises only its
+    # own source shard of the one global grid -- the targets and planted indices are the same on all)
     DIM_ = args.dim
-    grid = synth.make_grid(n_src_total, m, args.frames, DIM_, SEED)
     lo, hi = sharding.shard_range(n_src_total, n_gpus, rank)
+    if n_gpus > 1:
+        grid = synth.make_grid(n_src_total, m, args.frames, DIM_, SEED, src_range=(lo, hi))
+        shard = grid.sources
+    else:
+        grid = synth.make_grid(n_src_total, m, args.frames, DIM_, SEED)
+        shard = grid.sources[lo:hi]
     eng = Engine(metric="dtw", dtype="f32", device=local_rank, band=args.band)
-    src_dev = torch.from_numpy(np.ascontiguousarray(grid.sources[lo:hi]).reshape(-1)).cuda()
+    src_dev = torch.from_numpy(np.ascontiguousarray(shard).reshape(-1)).cuda()
     tgt_dev = torch.from_numpy(np.ascontiguousarray(grid.targets).reshape(-1)).cuda()
     so = np.arange(hi - lo + 1, dtype=np.uint64) * args.frames
     to = np.arange(m + 1, dtype=np.uint64) * args.frames

@@ -73,17 +73,56 @@ def sigma(dim: int) -> np.ndarray:
     return 4.0 / (1.0 + np.arange(dim, dtype=np.float64))
 
 
+def _normal_at(seed: int, pos0: int, n_total: int, idx: np.ndarray) -> np.ndarray:
+    """Elements `idx` of the array Stream(seed).normal(n_total) would return when drawn at stream
+    position pos0, without drawing the rest (splitmix64 is counter-based)."""
+    m = (n_total + 1) // 2
+    k = idx % m
+    with np.errstate(over="ignore"):
+        def u_at(p):
+            z = np.uint64(seed) + (p.astype(np.uint64) + np.uint64(pos0 + 1)) * np.uint64(0x9E3779B97F4A7C15)
+            z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+            z = z ^ (z >> np.uint64(31))
+            return ((z >> np.uint64(40)).astype(np.float64) + 0.5) / 16777216.0
+        r = np.sqrt(-2.0 * np.log(u_at(k)))
+        th = 2.0 * np.pi * u_at(k + m)
+    return np.where(idx < m, r * np.cos(th), r * np.sin(th))
+
+
 def make_grid(n_src: int, n_tgt: int, frames: int, dim: int, seed: int,
-              noise: float = 0.05, warp: float = 0.10) -> Grid:
-    """Seed convention: 0x5EED0000 + config number."""
+              noise: float = 0.05, warp: float = 0.10, src_range=None) -> Grid:
+    """Seed convention: 0x5EED0000 + config number.
+
+    src_range=(lo, hi): materialise only sources [lo, hi) (what one rank of a source-sharded run
+    holds; `sources` then has hi - lo rows) -- targets and planted indices are those of the full grid,
+    value for value, because the generator is counter-based."""
     st = Stream(seed)
     sig = sigma(dim)
-    x = st.normal(n_src * frames * dim).reshape(n_src, frames, dim) * sig
-    # slowly varying per-segment offset: a random level plus a random slope across the segment
-    lvl = st.normal(n_src * dim).reshape(n_src, 1, dim) * (0.5 * sig)
-    slope = st.normal(n_src * dim).reshape(n_src, 1, dim) * (0.25 * sig)
     ramp = np.linspace(-1.0, 1.0, frames).reshape(1, frames, 1)
-    x = x + lvl + slope * ramp
+    fd = frames * dim
+    n_x = n_src * fd
+    pos_lvl = 2 * ((n_x + 1) // 2)                       # stream position after the sources' normals
+    n_l = n_src * dim
+    pos_slope = pos_lvl + 2 * ((n_l + 1) // 2)
+
+    def source_rows(rows: np.ndarray) -> np.ndarray:
+        rows = np.asarray(rows, dtype=np.int64)
+        base = _normal_at(seed, 0, n_x, (rows[:, None] * fd + np.arange(fd)[None, :]).reshape(-1))
+        lvl_ = _normal_at(seed, pos_lvl, n_l, (rows[:, None] * dim + np.arange(dim)[None, :]).reshape(-1))
+        slp_ = _normal_at(seed, pos_slope, n_l, (rows[:, None] * dim + np.arange(dim)[None, :]).reshape(-1))
+        out = base.reshape(rows.size, frames, dim) * sig
+        return out + lvl_.reshape(rows.size, 1, dim) * (0.5 * sig) + slp_.reshape(rows.size, 1, dim) * (0.25 * sig) * ramp
+
+    if src_range is None:
+        x = st.normal(n_x).reshape(n_src, frames, dim) * sig
+        # slowly varying per-segment offset: a random level plus a random slope across the segment
+        lvl = st.normal(n_l).reshape(n_src, 1, dim) * (0.5 * sig)
+        slope = st.normal(n_l).reshape(n_src, 1, dim) * (0.25 * sig)
+        x = x + lvl + slope * ramp
+    else:
+        st.pos = pos_slope + 2 * ((n_l + 1) // 2)        # skip what the full grid would have drawn
+        x = None
 
     # seeded injection target -> source (a permutation prefix when n_tgt <= n_src)
     if n_tgt <= n_src:
@@ -106,7 +145,13 @@ def make_grid(n_src: int, n_tgt: int, frames: int, dim: int, seed: int,
             if m.size < frames:
                 m = np.concatenate([m, np.full(frames - m.size, frames - 1)])
             idx[t] = m[:frames]
-    y = x[planted[:, None], idx, :]
+    if x is None:
+        px = source_rows(planted)                         # the planted sources only
+        y = px[np.arange(n_tgt)[:, None], idx, :]
+        lo, hi = src_range
+        x = source_rows(np.arange(lo, hi))
+    else:
+        y = x[planted[:, None], idx, :]
     y = y + st.normal(n_tgt * frames * dim).reshape(n_tgt, frames, dim) * (noise * sig)
     return Grid(x.astype(np.float32), y.astype(np.float32), planted.astype(np.int64), frames, dim)
 

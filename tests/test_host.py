@@ -32,6 +32,17 @@ def test_grid_is_deterministic_and_planted():
     assert not np.array_equal(a.sources, c.sources)
 
 
+def test_grid_shard_rows_equal_the_full_grid():
+    # what bench.py builds per rank at N > 1: only its source rows, same targets / planted indices
+    for (n, m, f, d, seed) in [(40, 16, 20, 13, 0x5EED0001), (7, 9, 5, 3, 11), (33, 33, 3, 2, 5)]:
+        full = synth.make_grid(n, m, f, d, seed)
+        for lo, hi in [(0, n), (n // 3, 2 * n // 3), (n - 1, n)]:
+            part = synth.make_grid(n, m, f, d, seed, src_range=(lo, hi))
+            assert np.array_equal(part.sources, full.sources[lo:hi])
+            assert np.array_equal(part.targets, full.targets)
+            assert np.array_equal(part.planted, full.planted)
+
+
 def test_add_segments_slices_like_the_reference():
     # src/sound.rs:330-343: seg samples and seg / HOP * NCOEFFS feature values per segment
     samples = np.arange(256 * 5, dtype=np.float64)
