@@ -72,7 +72,12 @@ enum { SSYM_DTYPE_F64 = 0, SSYM_DTYPE_F32 = 1 };
 /* flags for ssym_match_queries */
 enum {
     SSYM_OUT_DEVICE = 1u,      /* out_idx / out_cost are device pointers on ctx's GPU            */
-    SSYM_DTW_FORCE_EXACT = 2u  /* skip the f32 MFMA filter: exact f64 kernel on every pair       */
+    SSYM_DTW_FORCE_EXACT = 2u, /* skip the f32 MFMA filter: exact f64 kernel on every pair       */
+    SSYM_DTW_PRUNE = 4u        /* dtw first-minimum search (no distances, unbanded, frames of at
+                                  most 42 values): one candidate pair per target is scored first
+                                  and the filter abandons pairs that are provably above it; same
+                                  indices and costs, the time then depends on the data; ignored
+                                  where it does not apply                                         */
 };
 
 typedef struct ssym_config {
@@ -98,6 +103,9 @@ typedef struct ssym_timings {
     uint64_t n_refined; /* dtw: pairs re-scored exactly                                          */
     int32_t main_launches; /* kernel launches that made up main_ms                               */
     int32_t used_filter;   /* dtw: 1 = MFMA filter + refine, 0 = exact kernel on every pair      */
+    float prune_ms;        /* SSYM_DTW_PRUNE: candidate search + exact scores + thresholds        */
+    int32_t pruned;        /* 1 = the filter ran with early abandoning                           */
+    uint64_t n_filter_cells; /* pruned runs: DP cells the filter evaluated (padding included)    */
 } ssym_timings;
 
 SSYM_API int32_t ssym_abi_version(void);

@@ -29,6 +29,7 @@ DTYPE_F32 = 1
 
 OUT_DEVICE = 1
 DTW_FORCE_EXACT = 2
+DTW_PRUNE = 4
 
 # every symbol include/soundsym_amd.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
@@ -82,6 +83,9 @@ class Timings(ctypes.Structure):
         ("n_refined", ctypes.c_uint64),
         ("main_launches", ctypes.c_int32),
         ("used_filter", ctypes.c_int32),
+        ("prune_ms", ctypes.c_float),
+        ("pruned", ctypes.c_int32),
+        ("n_filter_cells", ctypes.c_uint64),
     ]
 
     def as_dict(self):

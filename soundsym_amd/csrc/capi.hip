@@ -97,7 +97,7 @@ int32_t ssym_ctx_destroy(ssym_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     DeviceBuf *bufs[] = {&ctx->handoff, &ctx->cmat, &ctx->tmin, &ctx->cand, &ctx->cand2, &ctx->cand_xmin,
                          &ctx->cand_cost, &ctx->best, &ctx->selmask, &ctx->selcnt, &ctx->topk,
-                         &ctx->dist, &ctx->part, &ctx->out_idx, &ctx->out_cost};
+                         &ctx->abandon, &ctx->dist, &ctx->part, &ctx->out_idx, &ctx->out_cost};
     for (DeviceBuf *b : bufs)
         if (b->ptr)
             (void)hipFree(b->ptr);
@@ -396,12 +396,29 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
             if (rc != SSYM_OK)
                 return rc;
             float *cmat = (float *)ctx->cmat.ptr;
+            // early abandoning applies to the plain first-minimum search of one unsharded call
+            const bool prune = (flags & SSYM_DTW_PRUNE) && phase == 0 && !wide && ctx->band < 0 && k_top == 1 &&
+                               !distDev;
             if (phase != 2) {
                 SSYM_HIP_CHECK(ctx, hipEventRecord(ev[0], st));
-                rc = launch_dtw_filter(ctx, src, tgt, cmat);
+                const float *abandon = nullptr;
+                unsigned long long *colCtr = nullptr;
+                if (prune) {
+                    rc = launch_dtw_prune_thresholds(ctx, src, tgt, &abandon);
+                    if (rc != SSYM_OK)
+                        return rc;
+                    colCtr = (unsigned long long *)((char *)ctx->abandon.ptr + ctx->abandon.bytes) - 1;
+                    SSYM_HIP_CHECK(ctx, hipMemsetAsync(colCtr, 0, sizeof(*colCtr), st));
+                }
+                SSYM_HIP_CHECK(ctx, hipEventRecord(ev[6], st));
+                rc = launch_dtw_filter(ctx, src, tgt, cmat, abandon, colCtr);
                 if (rc != SSYM_OK)
                     return rc;
                 SSYM_HIP_CHECK(ctx, hipEventRecord(ev[1], st));
+                if (prune)
+                    SSYM_HIP_CHECK(ctx, hipMemcpyAsync(&ctx->pruned_cells, colCtr, sizeof(*colCtr),
+                                                       hipMemcpyDeviceToHost, st));
+                tm.pruned = prune ? 1 : 0;
                 rc = wide ? launch_dtw_bounds_partial(ctx, src, tgt, cmat)
                           : launch_dtw_bounds(ctx, src, tgt, cmat, distDev, k_top);
                 if (rc != SSYM_OK)
@@ -414,7 +431,7 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
                                                                          bounds_dev);
                 SSYM_HIP_CHECK(ctx, hipGetLastError());
                 SSYM_HIP_CHECK(ctx, hipStreamSynchronize(st));
-                ctx->pending.main_ms = ev_ms(ev[0], ev[1]);
+                ctx->pending.main_ms = ev_ms(ev[6], ev[1]);
                 tm.main_ms = ctx->pending.main_ms;
                 ctx->timings = tm;
                 return SSYM_OK;
@@ -485,7 +502,11 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
                     return SSYM_E_UNSUPPORTED;
                 }
             }
-            tm.main_ms = phase == 2 ? ctx->pending.main_ms : ev_ms(ev[0], ev[1]);
+            tm.main_ms = phase == 2 ? ctx->pending.main_ms : ev_ms(ev[6], ev[1]);
+            if (tm.pruned) {
+                tm.prune_ms = ev_ms(ev[0], ev[6]);
+                tm.n_filter_cells = ctx->pruned_cells * 64ull;
+            }
             tm.select_ms = sel_ms;
             tm.refine_ms = ref_ms;
             tm.reduce_ms = red_ms;

@@ -166,7 +166,8 @@ static int32_t ensure_records(ssym_ctx *ctx, const SegmentSet &set, double scale
 
 template <int NT, bool SQ>
 static void launch_one(hipStream_t st, const SegmentSet &src, const SegmentSet &tgt, int nPasses,
-                       int gridBlocks, float outScale, float *handoff, unsigned *taskCtr, float *cmat)
+                       int gridBlocks, float outScale, float *handoff, unsigned *taskCtr, float *cmat,
+                       const float *abandon, unsigned long long *colCtr)
 {
     // sources of at most 16 frames (one tile, one pass): three waves per SIMD, see filter_ring() -- 11 %
     // faster there; at 32 frames the gain was within 3 % and cost spills
@@ -183,9 +184,16 @@ static void launch_one(hipStream_t st, const SegmentSet &src, const SegmentSet &
     const long cellsPerTask = (long)src.frames_pad * std::max<uint32_t>(tgt.max_frames, 1);
     int taskChunk = (int)std::max(1L, std::min(8L, 8192 / std::max(1L, cellsPerTask)));
     taskChunk = std::max(1, std::min(taskChunk, nTasks / (grid * kFilterWavesPerBlock * 16)));
-    dtw_filter_kernel<NT, SQ, OCC><<<dim3(grid), 64 * kFilterWavesPerBlock, 0, st>>>(
-        (const _Float16 *)src.rec, (const _Float16 *)tgt.rec, src.len, tgt.len, (int)src.frames_pad, nPasses,
-        (int)tgt.frames_pad, (int)tgt.n_pad, nSrcPairs, nTasks, taskChunk, outScale, handoff, taskCtr, cmat);
+    if (abandon)
+        dtw_filter_kernel<NT, SQ, OCC, true><<<dim3(grid), 64 * kFilterWavesPerBlock, 0, st>>>(
+            (const _Float16 *)src.rec, (const _Float16 *)tgt.rec, src.len, tgt.len, (int)src.frames_pad, nPasses,
+            (int)tgt.frames_pad, (int)tgt.n_pad, nSrcPairs, nTasks, taskChunk, outScale, handoff, taskCtr, cmat,
+            abandon, colCtr);
+    else
+        dtw_filter_kernel<NT, SQ, OCC, false><<<dim3(grid), 64 * kFilterWavesPerBlock, 0, st>>>(
+            (const _Float16 *)src.rec, (const _Float16 *)tgt.rec, src.len, tgt.len, (int)src.frames_pad, nPasses,
+            (int)tgt.frames_pad, (int)tgt.n_pad, nSrcPairs, nTasks, taskChunk, outScale, handoff, taskCtr, cmat,
+            nullptr, nullptr);
 }
 
 template <int NTB, int WB, int OCC, bool SQ, int LASTN>
@@ -259,7 +267,19 @@ static int32_t launch_dtw_filter_banded(ssym_ctx *ctx, const SegmentSet &src, co
 #undef SSYM_BCASE
 }
 
-int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, float *cmat)
+int32_t ensure_filter_records(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, double *scale_out)
+{
+    const double scale = common_scale(src, tgt);
+    int32_t rc = ensure_records(ctx, src, scale, src.frames_pad, -1);
+    if (rc == SSYM_OK)
+        rc = ensure_records(ctx, tgt, scale, tgt.frames_pad, 0);
+    if (scale_out)
+        *scale_out = scale;
+    return rc;
+}
+
+int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, float *cmat,
+                          const float *abandon, unsigned long long *colCtr)
 {
     if (ctx->band >= 0)
         return launch_dtw_filter_banded(ctx, src, tgt, cmat);
@@ -292,8 +312,8 @@ int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
     float *hand = (float *)ctx->handoff.ptr;
 #define SSYM_CASE(NT_)                                                                          \
     case NT_:                                                                                   \
-        if (sq) launch_one<NT_, true>(st, src, tgt, shape.rb, gridBlocks, outScale, hand, taskCtr, cmat);  \
-        else launch_one<NT_, false>(st, src, tgt, shape.rb, gridBlocks, outScale, hand, taskCtr, cmat);    \
+        if (sq) launch_one<NT_, true>(st, src, tgt, shape.rb, gridBlocks, outScale, hand, taskCtr, cmat, abandon, colCtr);  \
+        else launch_one<NT_, false>(st, src, tgt, shape.rb, gridBlocks, outScale, hand, taskCtr, cmat, abandon, colCtr);    \
         break;
     switch (shape.nt) {
         SSYM_CASE(1) SSYM_CASE(2) SSYM_CASE(3) SSYM_CASE(4)

@@ -144,6 +144,7 @@ __device__ __forceinline__ float dp_column(const half8 (&A)[NT][kFilterKM], cons
 }
 
 constexpr int kFilterWavesPerBlock = 4;
+constexpr int kPruneEvery = 8;          // PRUNE: columns between two abandon tests (a test is BR/2 v_min3 + a vote)
 constexpr int kTaskCtrStride = 64;      // the 8 task counters sit in separate 256-byte lines (separate L2 channels)
 // Target columns staged in LDS per wave: 4 at two waves per SIMD (three columns of lead); the single-pass
 // kernels for short sources (NT <= 2) can run three waves per SIMD with a ring of 2 (one column of
@@ -157,12 +158,25 @@ constexpr int wait_vmcnt(int n) { return 0x0F70 | (n & 15) | ((n >> 4) << 14); }
 
 // Persistent kernel: every wave keeps taking (source pair, target group) tasks of 64 pairs until
 // none is left (taskCtr: 8 counters, zeroed by the host before the launch).
-template <int NT, bool SQ, int OCC = 2>
+//
+// PRUNE (early abandoning, SSYM_DTW_PRUNE): abandon[t] is a per-target value, in the accumulator's
+// units, that no pair of interest can exceed (prune.hip derives it from the exact cost of one
+// candidate pair per target plus the filter's worst-case error).  Costs are non-negative, so the
+// cost of a pair is at least the D value of any cell its optimal path visits; after column j of pass p
+// the path's last cell in column j lies in this pass's rows (>= the column's minimum), or the path
+// has already left through the pass's bottom row at a column <= j (>= the running minimum of the
+// bottoms), or it is still above and will enter through the top row later (>= the minimum over the
+// previous pass's bottoms).  When that bound exceeds abandon[t] for every lane of the wave -- lanes
+// whose result is already captured count as done, lanes whose source only begins in a later pass
+// count as undecided -- the rest of the task is skipped and the unfinished lanes report +inf, which
+// selection treats as "never a candidate".
+template <int NT, bool SQ, int OCC = 2, bool PRUNE = false>
 __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_kernel(
     const _Float16 *__restrict__ srcRec, const _Float16 *__restrict__ tgtRec,
     const int *__restrict__ srcLen, const int *__restrict__ tgtLen, int srcRows, int nPasses,
     int tgtFramesPad, int mPad, int nSrcPairs, int nTasks, int taskChunk, float outScale,
-    float *__restrict__ handoff, unsigned *__restrict__ taskCtr, float *__restrict__ cmat)
+    float *__restrict__ handoff, unsigned *__restrict__ taskCtr, float *__restrict__ cmat,
+    const float *__restrict__ abandon = nullptr, unsigned long long *__restrict__ colCtr = nullptr)
 {
     constexpr int REC = kFilterRecHalfs;
     constexpr int BR = NT * 16;            // rows per pass
@@ -193,6 +207,7 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_ker
     // ones fill the tail (with ragged segment lengths a static assignment left most of the chip
     // waiting for the workgroup that held the longest sources).  A wave whose range is exhausted
     // helps the next XCD's range, so every wave leaves only when all counters are spent.
+    unsigned colSteps = 0;      // PRUNE: columns this wave swept (wave-uniform), reported once at the end
     const unsigned qd = (unsigned)nTasks >> 3, rm = (unsigned)nTasks & 7u;
     for (unsigned hop = 0; hop < 8; ++hop) {
       const unsigned xcd = (blockIdx.x + hop) & 7u;
@@ -230,9 +245,14 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_ker
         const int firstPass = min(max(r0min - 1, 0) / BR, nPasses - 1);
 
         float res = INF;
+        float thr = INF, allBotPrev = INF;     // PRUNE: threshold of the lane's target; min over the previous pass's bottoms
+        bool dropped = false;                  // wave-uniform
+        if (PRUNE)
+            thr = abandon[32 * tg + col];
+        const bool dead = fa == 0 || fb_m1 < 0;   // PRUNE: an empty side, the result is +inf whatever happens
         const char *const tgtGroup = reinterpret_cast<const char *>(tgtRec) + (size_t)tg * tgtFramesPad * (kTgtFrameHalfs * 2);
 
-        for (int pass = nCols > 0 ? firstPass : nPasses; pass < nPasses; ++pass) {
+        for (int pass = nCols > 0 ? firstPass : nPasses; pass < nPasses && !dropped; ++pass) {
             const int rowBase = pass * BR;
 #ifdef SSYM_ABL_NOHAND
             const bool haveTop = false;
@@ -240,6 +260,7 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_ker
             const bool haveTop = pass > firstPass;      // wave-uniform
 #endif
             const bool lastPass = pass == nPasses - 1;
+            const bool started = r0 < rowBase + BR;     // PRUNE: the lane's source has rows in this pass or above
 
             // Target records (and the hand-off row above this row block) travel global -> LDS by
             // DMA, kFilterRing - 1 columns ahead of their use, and LDS -> registers one column
@@ -314,7 +335,10 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_ker
             f32x16 acc = mfma_tile<kFilterKM>(A[0], B0);
 
             float bq[4] = {INF, INF, INF, INF};                     // bottoms of the current group of 4 columns
-            for (int j0 = 0; j0 < nCols; j0 += 4) {
+            float runBot = INF;                                     // PRUNE: min of this pass's bottoms so far
+            for (int j0 = 0; j0 < nCols && !dropped; j0 += 4) {
+                if (PRUNE)
+                    colSteps += (unsigned)min(4, nCols - j0);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int j = j0 + q;
@@ -355,14 +379,36 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_ker
                         } else {
                             res = (j == fb_m1) ? bottom : res;      // D(fa-1, fb-1)
                         }
+                        if (PRUNE) {
+                            runBot = __builtin_fminf(runBot, bottom);
+                            if (q == 3 && (j & (kPruneEvery - 1)) == kPruneEvery - 1) {
+                                // q == 3: the column just written is L0
+                                float lb = haveTop ? allBotPrev : INF;
+                                if (!lastPass)
+                                    lb = __builtin_fminf(lb, runBot);
+#pragma unroll
+                                for (int i = 0; i < BR; i += 2)
+                                    lb = __builtin_fminf(__builtin_fminf(lb, L0[i]), L0[i + 1]);
+                                // (a source that begins below this pass has no cell here yet: its lane waits)
+                                const bool gone = (started && !(lb <= thr)) || (lastPass && j >= fb_m1) || dead;
+                                dropped = __all(gone);
+                            }
+                        }
                     }
                 }
+            }
+            if (PRUNE && !lastPass && !dropped) {
+                // every path still has to cross this pass's bottom row
+                allBotPrev = runBot;
+                dropped = __all((started && !(runBot <= thr)) || dead);
             }
         }
         cmat[(size_t)(2 * sp + half) * mPad + 32 * tg + col] = res * outScale;
        }
       }
     }
+    if (PRUNE && colCtr && lane == 0)
+        atomicAdd(colCtr, (unsigned long long)colSteps * BR);
 }
 
 }  // namespace ssym

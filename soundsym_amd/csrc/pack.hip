@@ -208,6 +208,7 @@ void free_segments(ssym_ctx *ctx, SegmentSet &set)
     dev_free(ctx, set.len);
     dev_free(ctx, set.max_sqnorm);
     dev_free(ctx, set.perm);
+    dev_free(ctx, set.centroid);
     set = SegmentSet{};
 }
 
@@ -221,6 +222,7 @@ static int32_t build_derived(ssym_ctx *ctx, SegmentSet &set)
     dev_free(ctx, set.len); set.len = nullptr;
     dev_free(ctx, set.max_sqnorm); set.max_sqnorm = nullptr;
     dev_free(ctx, set.perm); set.perm = nullptr;
+    dev_free(ctx, set.centroid); set.centroid = nullptr; set.centroid_n = 0;
 
     set.max_frames = 0;
     for (uint32_t i = 0; i < n; ++i)

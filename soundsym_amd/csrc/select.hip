@@ -9,6 +9,7 @@
 //   1. candidate selection on the f32 filter costs with a rigorous margin (derivation below),
 //   2. final first-minimum over the exactly re-scored candidates.
 #include "ssym_internal.hpp"
+#include "dtw_margin.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -48,41 +49,6 @@ namespace ssym {
 //      err (m = 0) and keeps list 1; certify.hip computes m for list 1; stage 2 applies it again
 //      inside list 1 with the per-pair err and keeps list 2, which is re-scored exactly.
 // ---------------------------------------------------------------------------------------------
-struct MarginParams {
-    double inv_scale2;  // 1 / s^2
-    double in_round;    // relative rounding of the operands the filter sees: 2^-22 (two f16 pieces) or 2^-11
-    int squared;
-};
-
-__device__ __forceinline__ void dtw_key_interval(const MarginParams &mp, double cst, double xmin,
-                                                 double na, double nb, int fa, int fb, double delta,
-                                                 double &key_lo, double &key_hi)
-{
-    const double INF = __builtin_inf();
-    if (!(cst < INF)) {          // unreachable / empty / NaN: never a candidate
-        key_lo = INF;
-        key_hi = INF;
-        return;
-    }
-    const double u = 5.9604644775390625e-8;   // 2^-24
-    const double E = 256.0 * u * (na + nb) + 0.000244140625 * mp.inv_scale2;
-    double cell;
-    // operands rounded to their f16 piece(s) move every frame by <= in_round * |frame|, hence c by
-    // <= in_round (|a| + |b|) and c^2 by <= 2.05 in_round (|a| + |b|)^2 <= 4.1 in_round (|a|^2 + |b|^2)
-    if (mp.squared)
-        cell = E + 4.1 * mp.in_round * (na + nb);
-    else
-        cell = (xmin > 6.0 * E ? E / (2.0 * sqrt(xmin - 2.0 * E)) : sqrt(E)) + 1.001 * mp.in_round * (sqrt(na) + sqrt(nb));
-    // f16 pieces below 2^-14 are subnormal: their absolute rounding 2^-25 (scaled units) per value,
-    // over at most 42 values of both frames
-    cell += 9.5367431640625e-07 * sqrt(mp.inv_scale2);
-    const double L = (double)(fa + fb - 1);
-    const double err = 1.02 * L * cell + (L + 6.0) * u * cst + 1e-300;
-    const double lo = fmax(cst - err, 0.0), hi = cst + err;
-    key_lo = fmax(fmax(lo - delta, delta - hi), 0.0);
-    key_hi = fmax(fabs(lo - delta), fabs(hi - delta));
-}
-
 __global__ void fill_u64_kernel(unsigned long long *p, unsigned long long v, uint32_t n)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -546,15 +512,6 @@ __global__ void merge_shards_kernel(uint32_t nShards, uint32_t nTgt, const doubl
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-static MarginParams margin_params(const ssym_ctx *ctx, const SegmentSet &src)
-{
-    MarginParams mp;
-    mp.inv_scale2 = src.rec_scale > 0.0 ? 1.0 / (src.rec_scale * src.rec_scale) : 1.0;
-    mp.in_round = filter_pieces(filter_dim_used((int)src.dim)) == 2 ? 2.384185791015625e-07 : 4.8828125e-04;
-    mp.squared = ctx->squared;
-    return mp;
-}
-
 // scratch for top-k rounds: [M] u64 previous bound / key bits, [M] u32 previous index
 static int32_t topk_scratch(ssym_ctx *ctx, uint32_t m, unsigned long long **prevKey, uint32_t **prevIdx)
 {

@@ -73,6 +73,9 @@ struct SegmentSet {
     mutable uint32_t rec_slots = 0;   // record slots per segment in `rec`
     mutable int rec_lead = 0;         // slot of frame 0 (-1: end-aligned)
     size_t raw_capacity_vals = 0;
+    // SSYM_DTW_PRUNE: mean frame per segment [n][dim] (caller order), built on first use (prune.hip)
+    mutable float *centroid = nullptr;
+    mutable uint32_t centroid_n = 0;
 };
 
 }  // namespace ssym
@@ -101,10 +104,12 @@ struct ssym_ctx {
     ssym::DeviceBuf cand_cost;  // exact f64 cost per candidate
     ssym::DeviceBuf best;       // per-target best bits / idx
     ssym::DeviceBuf topk;       // top-k rounds: previous round's key bits / index per target
+    ssym::DeviceBuf abandon;    // SSYM_DTW_PRUNE: per-target-slot thresholds (f32, accumulator units) + cell counter
     ssym::DeviceBuf dist;       // per-target distance (f64)
     ssym::DeviceBuf part;       // refcos partial argmin
     ssym::DeviceBuf out_idx, out_cost;  // staging for host outputs
     hipEvent_t ev[8]{};
+    unsigned long long pruned_cells = 0;   // SSYM_DTW_PRUNE: the filter's counter of the last call (host copy)
     // set by ssym_match_batch / ssym_match_one around their internal pack: the call synchronises
     // once at its end, so the pack stages need not wait for their copies individually
     bool defer_sync = false;
@@ -186,8 +191,15 @@ struct StageScope {                    // one per public entry point that moves 
 
 // dtw_filter.hip
 bool filter_supported(const ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt);
+// abandon != NULL: early abandoning against per-target-slot thresholds in accumulator units (prune.hip)
 int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt,
-                          float *cmat /*[src.n_pad][tgt.n_pad]*/);
+                          float *cmat /*[src.n_pad][tgt.n_pad]*/, const float *abandon = nullptr,
+                          unsigned long long *colCtr = nullptr /* PRUNE: += column steps x rows per pass */);
+// prune.hip: candidate per target -> exact cost -> thresholds in ctx->abandon
+int32_t launch_dtw_prune_thresholds(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt,
+                                    const float **abandon_out);
+// the common scale the (unbanded) filter runs the two sets with; builds the records if needed
+int32_t ensure_filter_records(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, double *scale_out);
 
 // certify.hip: smallest cell of every listed pair (per-pair error certificate)
 int32_t launch_certify(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, const uint32_t *candHdr,

@@ -133,10 +133,11 @@ class Engine:
 
     # -- the hot path ------------------------------------------------------------------------
     def match(self, d: _Handle, q: _Handle, distance=None, index_base: int = 0,
-              force_exact: bool = False, out_idx=None, out_cost=None
+              force_exact: bool = False, out_idx=None, out_cost=None, prune: bool = False
               ) -> Tuple[np.ndarray, np.ndarray]:
         """argmin per target.  With torch CUDA tensors in out_idx (int32/uint32 storage, n
-        entries) and out_cost (float64) the results stay on the device."""
+        entries) and out_cost (float64) the results stay on the device.  prune=True asks for
+        early abandoning (SSYM_DTW_PRUNE): same results, data-dependent time."""
         L = nat.lib()
         m = q.n
         dist_p = None
@@ -145,7 +146,7 @@ class Engine:
             if dist.size != m:
                 raise ValueError("distance must have one entry per target")
             dist_p = dist.ctypes.data
-        flags = nat.DTW_FORCE_EXACT if force_exact else 0
+        flags = (nat.DTW_FORCE_EXACT if force_exact else 0) | (nat.DTW_PRUNE if prune else 0)
         if out_idx is not None and _is_device_tensor(out_idx):
             flags |= nat.OUT_DEVICE
             rc = L.ssym_match_queries(self.ctx, d.ptr, q.ptr, dist_p, index_base, out_idx.data_ptr(),
