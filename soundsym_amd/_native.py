@@ -11,7 +11,8 @@ import subprocess
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsoundsym_amd.so")
+# SSYM_LIB: tuning experiments load a differently built library (tools/); the product path is the in-tree one
+LIB_PATH = os.environ.get("SSYM_LIB") or os.path.join(_HERE, "libsoundsym_amd.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 SSYM_OK = 0

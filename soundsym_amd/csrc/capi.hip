@@ -97,7 +97,7 @@ int32_t ssym_ctx_destroy(ssym_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     DeviceBuf *bufs[] = {&ctx->handoff, &ctx->cmat, &ctx->tmin, &ctx->cand, &ctx->cand2, &ctx->cand_xmin,
                          &ctx->cand_cost, &ctx->best, &ctx->selmask, &ctx->selcnt, &ctx->topk,
-                         &ctx->abandon, &ctx->dist, &ctx->part, &ctx->out_idx, &ctx->out_cost};
+                         &ctx->abandon, &ctx->prune_pairs, &ctx->prune_cost, &ctx->dist, &ctx->part, &ctx->out_idx, &ctx->out_cost};
     for (DeviceBuf *b : bufs)
         if (b->ptr)
             (void)hipFree(b->ptr);
@@ -462,12 +462,14 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
                                     (float *)ctx->cand_xmin.ptr);                               // certificates
                 if (rc != SSYM_OK)
                     return rc;
+                const uint32_t *knownSrc =
+                    prune ? (const uint32_t *)((const uint2 *)((const uint32_t *)ctx->prune_pairs.ptr + 2) + M) : nullptr;
                 rc = launch_dtw_select2(ctx, src, tgt, cmat, (const float *)ctx->cand_xmin.ptr, distDev,
-                                        (uint32_t)cap, k_top, wide);                            // stage 2
+                                        (uint32_t)cap, k_top, wide, knownSrc);                  // stage 2
                 if (rc != SSYM_OK)
                     return rc;
                 SSYM_HIP_CHECK(ctx, hipEventRecord(ev[3], st));
-                rc = ensure(ctx, ctx->cand_cost, sizeof(double) * cap);
+                rc = ensure(ctx, ctx->cand_cost, sizeof(double) * (cap + M));
                 if (rc != SSYM_OK)
                     return rc;
                 uint32_t *hdr2 = (uint32_t *)ctx->cand2.ptr;
@@ -475,8 +477,14 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
                                       (double *)ctx->cand_cost.ptr);
                 if (rc != SSYM_OK)
                     return rc;
+                if (prune) {
+                    rc = launch_prune_append_known(ctx, M);
+                    if (rc != SSYM_OK)
+                        return rc;
+                }
                 SSYM_HIP_CHECK(ctx, hipEventRecord(ev[4], st));
-                rc = launch_dtw_final(ctx, src, tgt, distDev, (uint32_t)cap, index_base, k_top, idxDev, costDev);
+                rc = launch_dtw_final(ctx, src, tgt, distDev, (uint32_t)(cap + (prune ? M : 0)), index_base, k_top,
+                                      idxDev, costDev);
                 if (rc != SSYM_OK)
                     return rc;
                 SSYM_HIP_CHECK(ctx, hipEventRecord(ev[5], st));

@@ -144,7 +144,10 @@ __device__ __forceinline__ float dp_column(const half8 (&A)[NT][kFilterKM], cons
 }
 
 constexpr int kFilterWavesPerBlock = 4;
-constexpr int kPruneEvery = 8;          // PRUNE: columns between two abandon tests (a test is BR/2 v_min3 + a vote)
+#ifndef SSYM_PRUNE_EVERY
+#define SSYM_PRUNE_EVERY 8
+#endif
+constexpr int kPruneEvery = SSYM_PRUNE_EVERY;   // PRUNE: columns between two abandon tests (a test is BR/2 v_min3 + a vote)
 constexpr int kTaskCtrStride = 64;      // the 8 task counters sit in separate 256-byte lines (separate L2 channels)
 // Target columns staged in LDS per wave: 4 at two waves per SIMD (three columns of lead); the single-pass
 // kernels for short sources (NT <= 2) can run three waves per SIMD with a ring of 2 (one column of

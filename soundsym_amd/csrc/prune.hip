@@ -55,7 +55,8 @@ __global__ __launch_bounds__(256) void prune_candidate_kernel(const float *__res
                                                               const float *__restrict__ cenT,
                                                               const uint32_t *__restrict__ permT, uint32_t nTgt,
                                                               uint32_t dim, uint32_t *__restrict__ hdr,
-                                                              uint2 *__restrict__ pairs)
+                                                              uint2 *__restrict__ pairs,
+                                                              uint32_t *__restrict__ knownSrc)
 {
     extern __shared__ float tm[];                       // [dim][kCandTargets]
     __shared__ float redD[4][kCandTargets];
@@ -121,8 +122,11 @@ __global__ __launch_bounds__(256) void prune_candidate_kernel(const float *__res
             b = take ? ob : b;
             i = take ? oi : i;
         }
-        if (slot < nTgt)
-            pairs[slot] = make_uint2(i == 0xffffffffu ? 0u : i, permT[slot]);   // all sources empty: cost +inf anyway
+        if (slot < nTgt) {
+            const uint32_t s = i == 0xffffffffu ? 0u : i;          // all sources empty: cost +inf anyway
+            pairs[slot] = make_uint2(s, permT[slot]);
+            knownSrc[permT[slot]] = s;
+        }
     }
 }
 
@@ -154,6 +158,33 @@ __global__ void prune_threshold_kernel(const double *__restrict__ exact, uint32_
     abandon[t] = thr;
 }
 
+// The candidates' exact costs are final: stage 2 leaves them out of list 2 (select.hip, knownSrc) and they
+// join the re-scored pairs here, behind the entries the exact kernel has just filled in.
+__global__ void prune_append_known_kernel(const uint2 *__restrict__ pairsK, const double *__restrict__ costK,
+                                          uint32_t n, const uint32_t *__restrict__ hdr2, uint2 *__restrict__ pairs2,
+                                          double *__restrict__ costs2)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n)
+        return;
+    const uint32_t base = hdr2[0];
+    pairs2[base + t] = pairsK[t];
+    costs2[base + t] = costK[t];
+}
+__global__ void prune_bump_kernel(uint32_t *hdr2, uint32_t n) { hdr2[0] += n; }
+
+int32_t launch_prune_append_known(ssym_ctx *ctx, uint32_t n_tgt)
+{
+    const uint32_t *hdrK = (const uint32_t *)ctx->prune_pairs.ptr;
+    uint32_t *hdr2 = (uint32_t *)ctx->cand2.ptr;
+    prune_append_known_kernel<<<(n_tgt + 255) / 256, 256, 0, ctx->stream>>>(
+        (const uint2 *)(hdrK + 2), (const double *)ctx->prune_cost.ptr, n_tgt, hdr2, (uint2 *)(hdr2 + 2),
+        (double *)ctx->cand_cost.ptr);
+    prune_bump_kernel<<<1, 1, 0, ctx->stream>>>(hdr2, n_tgt);
+    SSYM_HIP_CHECK(ctx, hipGetLastError());
+    return SSYM_OK;
+}
+
 static int32_t ensure_centroids(ssym_ctx *ctx, const SegmentSet &set)
 {
     if (set.centroid && set.centroid_n == set.n)
@@ -183,26 +214,26 @@ int32_t launch_dtw_prune_thresholds(ssym_ctx *ctx, const SegmentSet &src, const 
     if (rc == SSYM_OK)
         rc = ensure_centroids(ctx, tgt);
     if (rc == SSYM_OK)
-        rc = ensure(ctx, ctx->cand2, sizeof(uint32_t) * 2 + sizeof(uint2) * (size_t)tgt.n);
+        rc = ensure(ctx, ctx->prune_pairs, sizeof(uint32_t) * 2 + (sizeof(uint2) + sizeof(uint32_t)) * (size_t)tgt.n);
     if (rc == SSYM_OK)
-        rc = ensure(ctx, ctx->cand_cost, sizeof(double) * tgt.n);
+        rc = ensure(ctx, ctx->prune_cost, sizeof(double) * tgt.n);
     if (rc == SSYM_OK)
         rc = ensure(ctx, ctx->abandon, (sizeof(float) * tgt.n_pad + 15) / 8 * 8 + sizeof(unsigned long long));
     if (rc != SSYM_OK)
         return rc;
-    uint32_t *hdr = (uint32_t *)ctx->cand2.ptr;
+    uint32_t *hdr = (uint32_t *)ctx->prune_pairs.ptr;
     uint2 *pairs = (uint2 *)(hdr + 2);
     const unsigned nb = (tgt.n + kCandTargets - 1) / kCandTargets;
     prune_candidate_kernel<<<nb, 256, sizeof(float) * src.dim * kCandTargets, st>>>(
-        src.centroid, src.off, src.n, tgt.centroid, tgt.perm, tgt.n, src.dim, hdr, pairs);
+        src.centroid, src.off, src.n, tgt.centroid, tgt.perm, tgt.n, src.dim, hdr, pairs, (uint32_t *)(pairs + tgt.n));
     SSYM_HIP_CHECK(ctx, hipGetLastError());
-    rc = launch_dtw_exact(ctx, src, tgt, pairs, hdr, tgt.n, (double *)ctx->cand_cost.ptr);
+    rc = launch_dtw_exact(ctx, src, tgt, pairs, hdr, tgt.n, (double *)ctx->prune_cost.ptr);
     if (rc != SSYM_OK)
         return rc;
     const MarginParams mp = margin_params(ctx, src);
     const double outScale = ctx->squared ? 1.0 / (scale * scale) : 1.0 / scale;
     prune_threshold_kernel<<<(tgt.n_pad + 255) / 256, 256, 0, st>>>(
-        (const double *)ctx->cand_cost.ptr, tgt.n, tgt.n_pad, tgt.len, tgt.max_sqnorm, src.max_sqnorm_all,
+        (const double *)ctx->prune_cost.ptr, tgt.n, tgt.n_pad, tgt.len, tgt.max_sqnorm, src.max_sqnorm_all,
         (int)src.max_frames, mp, outScale, (float *)ctx->abandon.ptr);
     SSYM_HIP_CHECK(ctx, hipGetLastError());
     *abandon_out = (const float *)ctx->abandon.ptr;

@@ -227,7 +227,8 @@ __global__ void dtw_stage2_keep_kernel(const uint32_t *__restrict__ hdr1, const 
                                        const float *__restrict__ tgtMaxSq, MarginParams mp,
                                        const uint32_t *__restrict__ permS, const uint32_t *__restrict__ permT,
                                        const unsigned long long *__restrict__ ub,
-                                       const unsigned long long *__restrict__ ub1, uint32_t *__restrict__ hdr2,
+                                       const unsigned long long *__restrict__ ub1,
+                                       const uint32_t *__restrict__ knownSrc, uint32_t *__restrict__ hdr2,
                                        uint2 *__restrict__ pairs2)
 {
     const uint32_t n = hdr1[1] ? 0u : min(hdr1[0], cap);     // overflowed list 1: the host redoes stage 1
@@ -239,8 +240,11 @@ __global__ void dtw_stage2_keep_kernel(const uint32_t *__restrict__ hdr1, const 
         // ub1 = the stage-1 threshold: never above ub on one GPU, but in a source-sharded run it is
         // the minimum over ALL ranks (ssym_match_begin / _finish) and may undercut this shard's best
         const double thr = fmin(__longlong_as_double((long long)ub[p.y]), __longlong_as_double((long long)ub1[p.y]));
-        if (klo <= thr)      // list 2 leaves the filter's slot coordinates: (segment, segment) as the caller counts them
-            pairs2[atomicAdd(&hdr2[0], 1u)] = make_uint2(permS[p.x], permT[p.y]);   // list 1's capacity: cannot overflow
+        if (klo <= thr) {    // list 2 leaves the filter's slot coordinates: (segment, segment) as the caller counts them
+            const uint2 o = make_uint2(permS[p.x], permT[p.y]);
+            if (!knownSrc || knownSrc[o.y] != o.x)      // (early abandoning: the candidate pair has its exact cost already)
+                pairs2[atomicAdd(&hdr2[0], 1u)] = o;    // list 1's capacity: cannot overflow
+        }
     }
 }
 
@@ -307,7 +311,9 @@ __global__ void dtw_final_idx_kernel(const uint32_t *__restrict__ candHdr, const
     for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
         const uint2 p = pairs[k];
         const double key = fabs(costs[k] - (dist ? dist[p.y] : 0.0));
-        if ((unsigned long long)__double_as_longlong(key) == bestKey[p.y] &&
+        // (an infinite key equals the fold's start value but never wins: early abandoning appends its
+        // candidate pairs whatever their cost, e.g. for an empty target)
+        if (key < __builtin_inf() && (unsigned long long)__double_as_longlong(key) == bestKey[p.y] &&
             above_prev(key, p.x, prevKey, prevIdx, p.y))
             atomicMin(&bestIdx[p.y], p.x);
     }
@@ -525,11 +531,12 @@ static int32_t topk_scratch(ssym_ctx *ctx, uint32_t m, unsigned long long **prev
 
 int32_t launch_dtw_select2(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, const float *cmat,
                            const float *xmin, const double *dist_dev, uint32_t cap, uint32_t k_top,
-                           bool lower_bound_only)
+                           bool lower_bound_only, const uint32_t *known_src)
 {
     hipStream_t st = ctx->stream;
     const MarginParams mp = margin_params(ctx, src);
-    int32_t rc = ensure(ctx, ctx->cand2, sizeof(uint32_t) * 2 + sizeof(uint2) * (size_t)cap);
+    // (+ tgt.n: room for the early-abandoning candidates that join after the exact kernel)
+    int32_t rc = ensure(ctx, ctx->cand2, sizeof(uint32_t) * 2 + sizeof(uint2) * ((size_t)cap + tgt.n));
     if (rc != SSYM_OK)
         return rc;
     rc = ensure(ctx, ctx->tmin2, sizeof(unsigned long long) * tgt.n);
@@ -565,8 +572,8 @@ int32_t launch_dtw_select2(ssym_ctx *ctx, const SegmentSet &src, const SegmentSe
         }
     }
     dtw_stage2_keep_kernel<<<blocks, 256, 0, st>>>(hdr1, pairs1, xmin, cap, cmat, tgt.n_pad, dist_dev, src.len,
-                                                   src.max_sqnorm, tgt.len, tgt.max_sqnorm, mp, src.perm, tgt.perm, ub, ub1, hdr2,
-                                                   pairs2);
+                                                   src.max_sqnorm, tgt.len, tgt.max_sqnorm, mp, src.perm, tgt.perm, ub, ub1,
+                                                   known_src, hdr2, pairs2);
     SSYM_HIP_CHECK(ctx, hipGetLastError());
     return SSYM_OK;
 }

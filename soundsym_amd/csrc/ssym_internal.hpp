@@ -104,6 +104,7 @@ struct ssym_ctx {
     ssym::DeviceBuf cand_cost;  // exact f64 cost per candidate
     ssym::DeviceBuf best;       // per-target best bits / idx
     ssym::DeviceBuf topk;       // top-k rounds: previous round's key bits / index per target
+    ssym::DeviceBuf prune_pairs, prune_cost;   // SSYM_DTW_PRUNE: candidate pair per target (+ source by target), exact costs
     ssym::DeviceBuf abandon;    // SSYM_DTW_PRUNE: per-target-slot thresholds (f32, accumulator units) + cell counter
     ssym::DeviceBuf dist;       // per-target distance (f64)
     ssym::DeviceBuf part;       // refcos partial argmin
@@ -198,6 +199,8 @@ int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
 // prune.hip: candidate per target -> exact cost -> thresholds in ctx->abandon
 int32_t launch_dtw_prune_thresholds(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt,
                                     const float **abandon_out);
+// the candidates (pairs + exact costs) join list 2 behind the entries dtw_exact has filled in
+int32_t launch_prune_append_known(ssym_ctx *ctx, uint32_t n_tgt);
 // the common scale the (unbanded) filter runs the two sets with; builds the records if needed
 int32_t ensure_filter_records(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, double *scale_out);
 
@@ -224,7 +227,8 @@ int32_t launch_dtw_select(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
 // stage 2: per-pair intervals from the certificates of list 1 -> ctx->cand2 (list 2, same capacity)
 int32_t launch_dtw_select2(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, const float *cmat,
                            const float *xmin, const double *dist_dev, uint32_t cap, uint32_t k_top,
-                           bool lower_bound_only = false);
+                           bool lower_bound_only = false,
+                           const uint32_t *known_src = nullptr /* per target: a pair scored already, kept out */);
 int32_t launch_dtw_final(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt,
                          const double *dist_dev, uint32_t cap, uint32_t index_base, uint32_t k_top,
                          uint32_t *out_idx_dev, double *out_cost_dev);
