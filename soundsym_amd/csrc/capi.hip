@@ -397,8 +397,7 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
                 return rc;
             float *cmat = (float *)ctx->cmat.ptr;
             // early abandoning applies to the plain first-minimum search of one unsharded call
-            const bool prune = (flags & SSYM_DTW_PRUNE) && phase == 0 && !wide && ctx->band < 0 && k_top == 1 &&
-                               !distDev;
+            const bool prune = (flags & SSYM_DTW_PRUNE) && phase == 0 && !wide && k_top == 1 && !distDev;
             if (phase != 2) {
                 SSYM_HIP_CHECK(ctx, hipEventRecord(ev[0], st));
                 const float *abandon = nullptr;

@@ -25,12 +25,18 @@ constexpr int kBandTgtQuantum = 256;   // targets are padded to this (8 groups o
 // LASTN = diagonals of the last tile that get a DP cell: 16, or 1 when 2r+1 = 16(NTB-1) + 1 (every
 // radius that is a multiple of 8, r = 32 included) -- the matrix pipe still produces the whole tile,
 // but the VALU, which sets the pace, skips the 15 cells that lie outside the band.
-template <int NTB, int WB, int OCC, bool SQ, int LASTN>
+// PRUNE (early abandoning, SSYM_DTW_PRUNE, see dtw_filter_kernel.hpp): the whole in-band column of a
+// pair is in the lane's registers, every path crosses every column inside the band, so the smallest
+// L[k] after column j bounds the pair's cost from below; a wave drops its task when that exceeds the
+// target's threshold on all 64 lanes.  Tasks then differ in length by an order of magnitude, so the
+// waves of a workgroup take target groups from an LDS counter instead of owning one group per block.
+template <int NTB, int WB, int OCC, bool SQ, int LASTN, bool PRUNE = false>
 __global__ __launch_bounds__(64 * WB, OCC) void dtw_band_kernel(
     const _Float16 *__restrict__ srcRec, const _Float16 *__restrict__ tgtRec,
     const int *__restrict__ srcLen, const int *__restrict__ tgtLen, int srcSlots, int radius,
     int tgtFramesPad, int mPad, int nTgtBlocks, int nTasks, unsigned *__restrict__ taskCtr, float outScale,
-    float *__restrict__ cmat)
+    float *__restrict__ cmat, const float *__restrict__ abandon = nullptr,
+    unsigned long long *__restrict__ colCtr = nullptr)
 {
     constexpr int REC = kFilterRecHalfs;
     constexpr int KB = (NTB - 1) * 16 + LASTN;   // diagonals held in registers (>= 2r+1)
@@ -53,12 +59,15 @@ __global__ __launch_bounds__(64 * WB, OCC) void dtw_band_kernel(
     // length, so the list is walked from its end), and sweep all target blocks against the pair while
     // it sits in LDS.  (Handing out single (pair, target block) tasks instead cost 8 % at r = 32: the
     // pair was re-staged for every task.)
-    __shared__ unsigned sTask;
+    __shared__ unsigned sTask, sGroup;
     const int nPairs = nTasks / nTgtBlocks;
+    unsigned colSteps = 0;                             // PRUNE: columns this wave swept
     for (;;) {
         __syncthreads();                               // everyone has read the previous sTask and left LDS
-        if (threadIdx.x == 0)
+        if (threadIdx.x == 0) {
             sTask = atomicAdd(taskCtr, 1u);
+            sGroup = 0;
+        }
         __syncthreads();
         const unsigned got = sTask;
         if (got >= (unsigned)nPairs)
@@ -72,8 +81,21 @@ __global__ __launch_bounds__(64 * WB, OCC) void dtw_band_kernel(
                 l[i] = g[i];
             __syncthreads();
         }
-      for (int tb = nTgtBlocks - 1; tb >= 0; --tb) {
-        const int tg = tb * WB + wave;
+      for (int tb = nTgtBlocks - 1;; --tb) {
+        int tg;
+        if (PRUNE) {                                   // next target group of this source pair, longest first
+            unsigned g = 0;
+            if (lane == 0)
+                g = atomicAdd(&sGroup, 1u);
+            g = (unsigned)__builtin_amdgcn_readfirstlane((int)g);
+            if (g >= (unsigned)(nTgtBlocks * WB))
+                break;
+            tg = nTgtBlocks * WB - 1 - (int)g;
+        } else {
+            if (tb < 0)
+                break;
+            tg = tb * WB + wave;
+        }
 
         const int fa = srcLen[2 * sp + half];
         const int fb_m1 = tgtLen[32 * tg + col] - 1;
@@ -90,6 +112,11 @@ __global__ __launch_bounds__(64 * WB, OCC) void dtw_band_kernel(
             L[k] = (k == radius) ? 0.0f : INF;
         float res = INF;
         const int kstar = fa - 1 - fb_m1 + radius;     // diagonal of the end cell (fa-1, fb-1)
+        float thr = INF;
+        if (PRUNE)
+            thr = abandon[32 * tg + col];
+        const bool dead = fa == 0 || fb_m1 < 0;        // an empty side: +inf whatever happens
+        bool dropped = false;                          // wave-uniform
 
         const _Float16 *bbase = tgtRec + tgt_rec_offset(32 * tg + col, tgtFramesPad, 0, 0, half);
         half8 B0[kFilterKM], B1[kFilterKM];
@@ -112,7 +139,9 @@ __global__ __launch_bounds__(64 * WB, OCC) void dtw_band_kernel(
             load_rec(aLane + (size_t)(1 / NTB) * REC + (size_t)(1 % NTB) * 16 * REC, An);     // the step after it
         }
 
-        for (int j0 = 0; j0 < nCols; j0 += 2) {
+        for (int j0 = 0; j0 < nCols && !dropped; j0 += 2) {
+            if (PRUNE)
+                colSteps += (unsigned)min(2, nCols - j0);
 #pragma unroll
             for (int par = 0; par < 2; ++par) {
                 const int j = j0 + par;
@@ -167,12 +196,23 @@ __global__ __launch_bounds__(64 * WB, OCC) void dtw_band_kernel(
                         for (int k = 0; k < KB; ++k)
                             res = (mine && k == kstar) ? L[k] : res;
                     }
+                    if (PRUNE && par == 1 && (j & (kPruneEvery - 1)) == kPruneEvery - 1) {
+                        float lb = L[0];
+#pragma unroll
+                        for (int k = 1; k + 1 < KB; k += 2)
+                            lb = __builtin_fminf(__builtin_fminf(lb, L[k]), L[k + 1]);
+                        if ((KB & 1) == 0)
+                            lb = __builtin_fminf(lb, L[KB - 1]);
+                        dropped = __all(!(lb <= thr) || j >= fb_m1 || dead);
+                    }
                 }
             }
         }
         cmat[(size_t)(2 * sp + half) * mPad + 32 * tg + col] = res * outScale;
       }
     }
+    if (PRUNE && colCtr && lane == 0)
+        atomicAdd(colCtr, (unsigned long long)colSteps * KB);
 }
 
 }  // namespace ssym

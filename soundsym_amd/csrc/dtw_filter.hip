@@ -196,9 +196,10 @@ static void launch_one(hipStream_t st, const SegmentSet &src, const SegmentSet &
             nullptr, nullptr);
 }
 
-template <int NTB, int WB, int OCC, bool SQ, int LASTN>
-static int32_t launch_band_cfg(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, uint32_t slots,
-                               size_t lds, float outScale, float *cmat)
+template <int NTB, int WB, int OCC, bool SQ, int LASTN, bool PRUNE>
+static int32_t launch_band_cfg2(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, uint32_t slots,
+                                size_t lds, float outScale, float *cmat, const float *abandon,
+                                unsigned long long *colCtr)
 {
     const int nTgtBlocks = (int)tgt.n_pad / (32 * WB);
     const int nTasks = ((int)src.n_pad / 2) * nTgtBlocks;
@@ -208,14 +209,23 @@ static int32_t launch_band_cfg(ssym_ctx *ctx, const SegmentSet &src, const Segme
         return rc;
     unsigned *taskCtr = (unsigned *)ctx->handoff.ptr;
     SSYM_HIP_CHECK(ctx, hipMemsetAsync(taskCtr, 0, sizeof(unsigned), ctx->stream));
-    auto kern = dtw_band_kernel<NTB, WB, OCC, SQ, LASTN>;
+    auto kern = dtw_band_kernel<NTB, WB, OCC, SQ, LASTN, PRUNE>;
     if (lds > 64 * 1024)
         SSYM_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     kern<<<dim3(grid), 64 * WB, lds, ctx->stream>>>(
         (const _Float16 *)src.rec, (const _Float16 *)tgt.rec, src.len, tgt.len, (int)slots, ctx->band,
-        (int)tgt.frames_pad, (int)tgt.n_pad, nTgtBlocks, nTasks, taskCtr, outScale, cmat);
+        (int)tgt.frames_pad, (int)tgt.n_pad, nTgtBlocks, nTasks, taskCtr, outScale, cmat, abandon, colCtr);
     SSYM_HIP_CHECK(ctx, hipGetLastError());
     return SSYM_OK;
+}
+
+template <int NTB, int WB, int OCC, bool SQ, int LASTN>
+static int32_t launch_band_cfg(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, uint32_t slots,
+                               size_t lds, float outScale, float *cmat, const float *abandon,
+                               unsigned long long *colCtr)
+{
+    return abandon ? launch_band_cfg2<NTB, WB, OCC, SQ, LASTN, true>(ctx, src, tgt, slots, lds, outScale, cmat, abandon, colCtr)
+                   : launch_band_cfg2<NTB, WB, OCC, SQ, LASTN, false>(ctx, src, tgt, slots, lds, outScale, cmat, nullptr, nullptr);
 }
 
 // Up to 5 tiles of diagonals (r <= 39) run two waves per SIMD (8-wave workgroups); at 4 and 5 tiles
@@ -224,19 +234,20 @@ static int32_t launch_band_cfg(ssym_ctx *ctx, const SegmentSet &src, const Segme
 // SSYM_BAND_OCC1=1 forces the one-wave variant for tuning experiments.
 template <int NTB, bool SQ>
 static int32_t launch_band(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, uint32_t slots,
-                           size_t lds, float outScale, float *cmat)
+                           size_t lds, float outScale, float *cmat, const float *abandon, unsigned long long *colCtr)
 {
     static const bool forceOcc1 = getenv("SSYM_BAND_OCC1") != nullptr;
     // radii that are multiples of 8 end exactly one diagonal into their last tile
     const bool last1 = 2 * ctx->band + 1 == 16 * (NTB - 1) + 1;
     if (NTB <= 5 && !forceOcc1)
-        return last1 ? launch_band_cfg<NTB, 8, 2, SQ, 1>(ctx, src, tgt, slots, lds, outScale, cmat)
-                     : launch_band_cfg<NTB, 8, 2, SQ, 16>(ctx, src, tgt, slots, lds, outScale, cmat);
-    return last1 ? launch_band_cfg<NTB, 4, 1, SQ, 1>(ctx, src, tgt, slots, lds, outScale, cmat)
-                 : launch_band_cfg<NTB, 4, 1, SQ, 16>(ctx, src, tgt, slots, lds, outScale, cmat);
+        return last1 ? launch_band_cfg<NTB, 8, 2, SQ, 1>(ctx, src, tgt, slots, lds, outScale, cmat, abandon, colCtr)
+                     : launch_band_cfg<NTB, 8, 2, SQ, 16>(ctx, src, tgt, slots, lds, outScale, cmat, abandon, colCtr);
+    return last1 ? launch_band_cfg<NTB, 4, 1, SQ, 1>(ctx, src, tgt, slots, lds, outScale, cmat, abandon, colCtr)
+                 : launch_band_cfg<NTB, 4, 1, SQ, 16>(ctx, src, tgt, slots, lds, outScale, cmat, abandon, colCtr);
 }
 
-static int32_t launch_dtw_filter_banded(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, float *cmat)
+static int32_t launch_dtw_filter_banded(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, float *cmat,
+                                        const float *abandon, unsigned long long *colCtr)
 {
     if (tgt.n_pad % kBandTgtQuantum != 0 || src.n_pad % 2 != 0) {
         ctx->err = "dtw band filter: segment set not padded for the banded kernel";
@@ -256,8 +267,8 @@ static int32_t launch_dtw_filter_banded(ssym_ctx *ctx, const SegmentSet &src, co
     const int ntb = (2 * ctx->band + 1 + 15) / 16;
 #define SSYM_BCASE(N_)                                                                                  \
     case N_:                                                                                            \
-        return sq ? launch_band<N_, true>(ctx, src, tgt, slots, lds, outScale, cmat)   \
-                  : launch_band<N_, false>(ctx, src, tgt, slots, lds, outScale, cmat);
+        return sq ? launch_band<N_, true>(ctx, src, tgt, slots, lds, outScale, cmat, abandon, colCtr)   \
+                  : launch_band<N_, false>(ctx, src, tgt, slots, lds, outScale, cmat, abandon, colCtr);
     switch (ntb) {
         SSYM_BCASE(1) SSYM_BCASE(2) SSYM_BCASE(3) SSYM_BCASE(4) SSYM_BCASE(5) SSYM_BCASE(6)
     default:
@@ -270,7 +281,8 @@ static int32_t launch_dtw_filter_banded(ssym_ctx *ctx, const SegmentSet &src, co
 int32_t ensure_filter_records(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, double *scale_out)
 {
     const double scale = common_scale(src, tgt);
-    int32_t rc = ensure_records(ctx, src, scale, src.frames_pad, -1);
+    int32_t rc = ctx->band >= 0 ? ensure_records(ctx, src, scale, band_slots(ctx->band, src, tgt), ctx->band)
+                                : ensure_records(ctx, src, scale, src.frames_pad, -1);
     if (rc == SSYM_OK)
         rc = ensure_records(ctx, tgt, scale, tgt.frames_pad, 0);
     if (scale_out)
@@ -282,7 +294,7 @@ int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
                           const float *abandon, unsigned long long *colCtr)
 {
     if (ctx->band >= 0)
-        return launch_dtw_filter_banded(ctx, src, tgt, cmat);
+        return launch_dtw_filter_banded(ctx, src, tgt, cmat, abandon, colCtr);
     const FilterShape shape = filter_shape((int)src.max_frames);
     if (shape.nt == 0 || (int)src.frames_pad != shape.rows() || src.n_pad % 8 != 0 || tgt.n_pad % 32 != 0) {
         ctx->err = "dtw filter: segment set not padded for the filter kernel";

@@ -53,14 +53,16 @@ constexpr int kCandTargets = 16;   // targets per workgroup of the candidate sea
 __global__ __launch_bounds__(256) void prune_candidate_kernel(const float *__restrict__ cenS,
                                                               const uint64_t *__restrict__ offS, uint32_t nSrc,
                                                               const float *__restrict__ cenT,
+                                                              const uint64_t *__restrict__ offT,
                                                               const uint32_t *__restrict__ permT, uint32_t nTgt,
-                                                              uint32_t dim, uint32_t *__restrict__ hdr,
+                                                              uint32_t dim, int band, uint32_t *__restrict__ hdr,
                                                               uint2 *__restrict__ pairs,
                                                               uint32_t *__restrict__ knownSrc)
 {
     extern __shared__ float tm[];                       // [dim][kCandTargets]
     __shared__ float redD[4][kCandTargets];
     __shared__ uint32_t redI[4][kCandTargets];
+    __shared__ int lenT[kCandTargets];
     const uint32_t t0 = blockIdx.x * kCandTargets;
     if (blockIdx.x == 0 && threadIdx.x == 0)
         hdr[0] = nTgt, hdr[1] = 0;
@@ -69,6 +71,10 @@ __global__ __launch_bounds__(256) void prune_candidate_kernel(const float *__res
         const uint32_t slot = t0 + tt;
         tm[i] = slot < nTgt ? cenT[(size_t)permT[slot] * dim + k] : 0.0f;
     }
+    if (threadIdx.x < kCandTargets) {
+        const uint32_t slot = t0 + threadIdx.x;
+        lenT[threadIdx.x] = slot < nTgt ? (int)(offT[permT[slot] + 1] - offT[permT[slot]]) : 0;
+    }
     __syncthreads();
     float best[kCandTargets];
     uint32_t bi[kCandTargets];
@@ -76,7 +82,8 @@ __global__ __launch_bounds__(256) void prune_candidate_kernel(const float *__res
     for (int tt = 0; tt < kCandTargets; ++tt)
         best[tt] = __builtin_inff(), bi[tt] = 0xffffffffu;
     for (uint32_t s = threadIdx.x; s < nSrc; s += 256) {
-        if (offS[s + 1] == offS[s])
+        const int ls = (int)(offS[s + 1] - offS[s]);
+        if (ls == 0)
             continue;                                   // an empty source matches nothing
         float d[kCandTargets];
 #pragma unroll
@@ -91,9 +98,12 @@ __global__ __launch_bounds__(256) void prune_candidate_kernel(const float *__res
             }
         }
 #pragma unroll
-        for (int tt = 0; tt < kCandTargets; ++tt)
-            if (d[tt] < best[tt] || bi[tt] == 0xffffffffu)      // (also takes a NaN distance when nothing else came)
-                best[tt] = d[tt], bi[tt] = s;
+        for (int tt = 0; tt < kCandTargets; ++tt) {
+            // inside a Sakoe-Chiba band a pair whose lengths differ by more than r has no path at all
+            const float dd = (band >= 0 && abs(ls - lenT[tt]) > band) ? __builtin_inff() : d[tt];
+            if (dd < best[tt] || bi[tt] == 0xffffffffu)        // (also takes a NaN distance when nothing else came)
+                best[tt] = dd, bi[tt] = s;
+        }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -225,7 +235,8 @@ int32_t launch_dtw_prune_thresholds(ssym_ctx *ctx, const SegmentSet &src, const 
     uint2 *pairs = (uint2 *)(hdr + 2);
     const unsigned nb = (tgt.n + kCandTargets - 1) / kCandTargets;
     prune_candidate_kernel<<<nb, 256, sizeof(float) * src.dim * kCandTargets, st>>>(
-        src.centroid, src.off, src.n, tgt.centroid, tgt.perm, tgt.n, src.dim, hdr, pairs, (uint32_t *)(pairs + tgt.n));
+        src.centroid, src.off, src.n, tgt.centroid, tgt.off, tgt.perm, tgt.n, src.dim, ctx->band, hdr, pairs,
+        (uint32_t *)(pairs + tgt.n));
     SSYM_HIP_CHECK(ctx, hipGetLastError());
     rc = launch_dtw_exact(ctx, src, tgt, pairs, hdr, tgt.n, (double *)ctx->prune_cost.ptr);
     if (rc != SSYM_OK)

@@ -81,6 +81,58 @@ def test_prune_random_shapes(oracle, case):
     e.close()
 
 
+@pytest.mark.parametrize("n,m,f,d,band", [(192, 256, 96, 13, 8), (128, 256, 128, 40, 32), (96, 256, 64, 13, 20),
+                                           (64, 256, 150, 20, 47)])
+def test_prune_banded_planted_grid(oracle, n, m, f, d, band):
+    g = synth.make_grid(n, m, f, d, 0x5EED0500 + band)
+    sf, so = g.flat("sources")
+    tf, to = g.flat("targets")
+    e = Engine(metric="dtw", dtype="f32", band=band)
+    dd, q = e.dictionary(sf, so, d), e.queries(tf, to, d)
+    idx, cost, t0, t1 = _both(e, dd, q)
+    assert t0["pruned"] == 0 and t1["pruned"] == 1 and t1["used_filter"] == 1
+    want_idx, want_cost = oracle.dtw_match_all(sf.astype(np.float64), so, tf.astype(np.float64), to, d, band=band,
+                                               nthreads=oracle.max_threads())
+    assert np.array_equal(idx, want_idx) and np.allclose(cost, want_cost, rtol=1e-12, atol=0)
+    assert t1["n_filter_cells"] > 0
+    e.close()
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_prune_banded_random_shapes(oracle, case):
+    st = synth.Stream(0x5EED4200 + case)
+    dim = int([2, 13, 14, 40][st.integers(1, 4)[0]])
+    hi = int([17, 50, 66, 130][st.integers(1, 4)[0]])
+    lo = int(st.integers(1, 2)[0])
+    band = int([0, 1, 5, 8, 20, 32, 47][st.integers(1, 7)[0]])
+    n, m = int(2 + st.integers(1, 40)[0]), int(1 + st.integers(1, 70)[0])
+    squared = bool(st.integers(1, 4)[0] == 0)
+    lens_s = lo + st.integers(n, hi - lo + 1)
+    lens_t = lo + st.integers(m, hi - lo + 1)
+    src = [st.normal(int(f) * dim).reshape(int(f), dim) * synth.sigma(dim) for f in lens_s]
+    tgt = [st.normal(int(f) * dim).reshape(int(f), dim) * synth.sigma(dim) for f in lens_t]
+    for t in range(0, m, 2):
+        s = (5 * t + 1) % n
+        if src[s].shape[0] > 0:
+            tgt[t] = src[s] + 0.02 * st.normal(src[s].size).reshape(src[s].shape)
+    if n > 6:
+        src[6] = src[2].copy()
+    sf, so = pack_segments(src, dim, np.float32)
+    tf, to = pack_segments(tgt, dim, np.float32)
+    e = Engine(metric="dtw", dtype="f32", band=band, squared=squared)
+    d, q = e.dictionary(sf, so, dim), e.queries(tf, to, dim)
+    idx, cost, _, t1 = _both(e, d, q)
+    want_idx, want_cost = oracle.dtw_match_all(sf.astype(np.float64), so, tf.astype(np.float64), to, dim, band=band,
+                                               squared=squared, nthreads=4)
+    info = dict(case=case, dim=dim, hi=hi, n=n, m=m, band=band, squared=squared, filter=t1["used_filter"])
+    assert t1["pruned"] == t1["used_filter"], info
+    assert np.array_equal(idx, want_idx), info
+    assert np.array_equal(np.isinf(cost), np.isinf(want_cost)), info
+    fin = np.isfinite(want_cost)
+    assert np.allclose(cost[fin], want_cost[fin], rtol=1e-12, atol=0), info
+    e.close()
+
+
 def test_prune_without_close_pairs_and_index_base(oracle):
     st = synth.Stream(0x5EED4100)
     dim, n, m = 13, 200, 70
@@ -109,12 +161,11 @@ def test_prune_is_ignored_where_it_does_not_apply(oracle):
     i1, c1 = e.match(d, q, distance=dist, prune=True)
     assert e.timings()["pruned"] == 0 and np.array_equal(i0, i1) and np.array_equal(c0, c1)
     e.close()
-    # banded
-    e = Engine(metric="dtw", dtype="f32", band=8)
+    # top-k
+    e = Engine(metric="dtw", dtype="f32")
     d, q = e.dictionary(sf, so, 13), e.queries(tf, to, 13)
-    i0, c0 = e.match(d, q)
-    i1, c1 = e.match(d, q, prune=True)
-    assert e.timings()["pruned"] == 0 and np.array_equal(i0, i1) and np.array_equal(c0, c1)
+    e.match_topk(d, q, 3)
+    assert e.timings()["pruned"] == 0
     e.close()
     # refcos: the flag means nothing
     r = Engine(metric="refcos", dtype="f64")

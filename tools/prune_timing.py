@@ -7,11 +7,11 @@ import torch
 from soundsym_amd import Engine, synth
 
 
-def run(n, m, f, d, seed, planted=True, reps=5):
+def run(n, m, f, d, seed, planted=True, reps=5, band=-1):
     g = synth.make_grid(n, m, f, d, seed)
     src = g.sources
     tgt = g.targets if planted else synth.make_grid(m, 1, f, d, seed + 77).sources
-    e = Engine(metric="dtw", dtype="f32", device=0)
+    e = Engine(metric="dtw", dtype="f32", device=0, band=band)
     sd = torch.from_numpy(np.ascontiguousarray(src).reshape(-1)).cuda()
     td = torch.from_numpy(np.ascontiguousarray(tgt).reshape(-1)).cuda()
     so = np.arange(n + 1, dtype=np.uint64) * f
@@ -30,8 +30,8 @@ def run(n, m, f, d, seed, planted=True, reps=5):
         out[prune] = (best, e.timings())
     same = bool(torch.equal(oi, pi) and torch.equal(oc, pc))
     tm = out[True][1]
-    full_cells = n * m * f * f
-    print(f"{n}x{m}x{f}f x{d}d planted={planted}: full {out[False][0]:.2f} ms  pruned {out[True][0]:.2f} ms "
+    full_cells = n * m * (f * f if band < 0 else f * (2 * band + 1))
+    print(f"{n}x{m}x{f}f x{d}d band={band} planted={planted}: full {out[False][0]:.2f} ms  pruned {out[True][0]:.2f} ms "
           f"(thresholds {tm['prune_ms']:.2f}, filter {tm['main_ms']:.2f}, select {tm['select_ms']:.2f}, refine {tm['refine_ms']:.2f}, "
           f"refined {tm['n_refined']})  cells swept {tm['n_filter_cells'] / full_cells:.3f} of full  identical={same}", flush=True)
     assert same
@@ -46,3 +46,5 @@ if __name__ == "__main__":
     run(4096, 4096, 128, 13, 0x5EED0003, planted=False)
     run(2048, 2048, 256, 13, 0x5EED0013)
     run(4096, 4096, 40, 13, 0x5EED0023)
+    run(4096, 4096, 256, 40, 0x5EED0005, band=32, reps=3)
+    run(4096, 4096, 256, 40, 0x5EED0005, band=32, reps=3, planted=False)
