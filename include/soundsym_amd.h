@@ -225,6 +225,22 @@ SSYM_API int32_t ssym_match_begin(ssym_ctx *ctx, const ssym_dict *dict, const ss
 SSYM_API int32_t ssym_match_finish(ssym_ctx *ctx, const double *bounds_dev, uint32_t *out_idx,
                           double *out_cost, uint32_t flags);
 
+/* Early abandoning (SSYM_DTW_PRUNE) in a source-sharded run: only the rank that holds a target's
+ * neighbour knows a tight bound before the filter, so the candidates' costs are exchanged first.
+ *   ssym_match_candidates    scores this shard's candidate pair per target exactly and writes the costs
+ *                            to cost_dev (n_targets f64, DEVICE memory; +inf where pruning does not
+ *                            apply: refcos, frames wider than 42 values, shapes outside the filter)
+ *   (caller)                 all-reduce(MIN) of cost_dev over the ranks
+ *   ssym_match_begin_pruned  ssym_match_begin (no per-target distances) whose filter abandons pairs
+ *                            that are provably above the reduced costs; then the all-reduce of the
+ *                            bounds and ssym_match_finish as before.  Without a preceding
+ *                            ssym_match_candidates on the same (dict, q) it is a plain ssym_match_begin.
+ * Results are those of the unpruned sequence, bit for bit. */
+SSYM_API int32_t ssym_match_candidates(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queries *q,
+                                       double *cost_dev);
+SSYM_API int32_t ssym_match_begin_pruned(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queries *q,
+                                         uint32_t index_base, const double *cost_dev, double *bounds_dev);
+
 /* Source-sharded multi-GPU: after an all-gather of every shard's (cost, global index) per target
  * (n_shards x n_targets each, shard-major, DEVICE memory), pick per target the shard entry with
  * the smallest cost, lowest global index on equal cost -- the same first-minimum rule as

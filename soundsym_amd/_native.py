@@ -38,6 +38,7 @@ ABI_SYMBOLS = [
     "ssym_ctx_synchronize", "ssym_get_timings", "ssym_dict_create", "ssym_dict_create_device",
     "ssym_dict_append", "ssym_dict_size", "ssym_dict_destroy", "ssym_queries_create",
     "ssym_queries_create_device", "ssym_queries_destroy", "ssym_match_queries", "ssym_match_begin",
+    "ssym_match_candidates", "ssym_match_begin_pruned",
     "ssym_match_finish", "ssym_match_topk",
     "ssym_match_batch",
     "ssym_match_one", "ssym_chain", "ssym_pair_matrix", "ssym_merge_shards", "ssym_merge_shards_at", "ssym_samples_create",
@@ -168,6 +169,10 @@ def lib() -> ctypes.CDLL:
     L.ssym_match_queries.argtypes = [vp, vp, vp, vp, u32, vp, vp, u32]
     L.ssym_match_begin.restype = i32
     L.ssym_match_begin.argtypes = [vp, vp, vp, vp, u32, vp]
+    L.ssym_match_candidates.restype = i32
+    L.ssym_match_candidates.argtypes = [vp, vp, vp, vp]
+    L.ssym_match_begin_pruned.restype = i32
+    L.ssym_match_begin_pruned.argtypes = [vp, vp, vp, u32, vp, vp]
     L.ssym_match_finish.restype = i32
     L.ssym_match_finish.argtypes = [vp, vp, vp, vp, u32]
     L.ssym_match_topk.restype = i32

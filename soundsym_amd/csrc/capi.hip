@@ -319,7 +319,8 @@ __global__ void targets_to_slots_kernel(const double *__restrict__ byTarget, con
 // back from bounds_dev (after the ranks' all-reduce) and runs selection, re-scoring and the fold.
 static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queries *q,
                           const double *distance, uint32_t index_base, uint32_t k_top, uint32_t *out_idx,
-                          double *out_cost, uint32_t flags, int phase = 0, double *bounds_dev = nullptr)
+                          double *out_cost, uint32_t flags, int phase = 0, double *bounds_dev = nullptr,
+                          const double *prune_cost_dev = nullptr /* phase 1: reduced candidate costs, by target */)
 {
     StageScope stageScope(ctx);
     int32_t rc = check_match_args(ctx, dict, q);
@@ -397,13 +398,19 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
                 return rc;
             float *cmat = (float *)ctx->cmat.ptr;
             // early abandoning applies to the plain first-minimum search of one unsharded call
-            const bool prune = (flags & SSYM_DTW_PRUNE) && phase == 0 && !wide && k_top == 1 && !distDev;
+            // (phase 1: the candidates were scored by ssym_match_candidates, their costs reduced over the ranks;
+            //  phase 2: what phase 1 did)
+            const bool prune = phase == 2 ? ctx->pending.pruned
+                                          : (flags & SSYM_DTW_PRUNE) && !wide && k_top == 1 && !distDev &&
+                                                (phase == 0 || prune_cost_dev != nullptr);
             if (phase != 2) {
                 SSYM_HIP_CHECK(ctx, hipEventRecord(ev[0], st));
                 const float *abandon = nullptr;
                 unsigned long long *colCtr = nullptr;
                 if (prune) {
-                    rc = launch_dtw_prune_thresholds(ctx, src, tgt, &abandon);
+                    rc = phase == 0 ? launch_dtw_prune_candidates(ctx, src, tgt) : SSYM_OK;
+                    if (rc == SSYM_OK)
+                        rc = launch_dtw_prune_thresholds(ctx, src, tgt, prune_cost_dev, &abandon);
                     if (rc != SSYM_OK)
                         return rc;
                     colCtr = (unsigned long long *)((char *)ctx->abandon.ptr + ctx->abandon.bytes) - 1;
@@ -417,12 +424,12 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
                 if (prune)
                     SSYM_HIP_CHECK(ctx, hipMemcpyAsync(&ctx->pruned_cells, colCtr, sizeof(*colCtr),
                                                        hipMemcpyDeviceToHost, st));
-                tm.pruned = prune ? 1 : 0;
                 rc = wide ? launch_dtw_bounds_partial(ctx, src, tgt, cmat)
                           : launch_dtw_bounds(ctx, src, tgt, cmat, distDev, k_top);
                 if (rc != SSYM_OK)
                     return rc;
             }
+            tm.pruned = prune ? 1 : 0;
             tm.main_launches = 1;
             if (phase == 1) {
                 // hand the threshold out: non-negative doubles (or +inf), bit for bit what stage 1 uses
@@ -431,6 +438,7 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
                 SSYM_HIP_CHECK(ctx, hipGetLastError());
                 SSYM_HIP_CHECK(ctx, hipStreamSynchronize(st));
                 ctx->pending.main_ms = ev_ms(ev[6], ev[1]);
+                ctx->pending.pruned = prune;
                 tm.main_ms = ctx->pending.main_ms;
                 ctx->timings = tm;
                 return SSYM_OK;
@@ -511,7 +519,7 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
             }
             tm.main_ms = phase == 2 ? ctx->pending.main_ms : ev_ms(ev[6], ev[1]);
             if (tm.pruned) {
-                tm.prune_ms = ev_ms(ev[0], ev[6]);
+                tm.prune_ms = phase == 2 ? 0.f : ev_ms(ev[0], ev[6]);
                 tm.n_filter_cells = ctx->pruned_cells * 64ull;
             }
             tm.select_ms = sel_ms;
@@ -582,8 +590,53 @@ int32_t ssym_match_topk(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queries
 
 // Two-phase match for source-sharded runs (see the header).  A tiny kernel-free helper fills the
 // bounds with +inf when the filter does not apply; the all-reduce then changes nothing.
-int32_t ssym_match_begin(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queries *q, const double *distance,
-                         uint32_t index_base, double *bounds_dev)
+static bool prune_applies(const ssym_ctx *ctx, const ssym_dict *dict, const ssym_queries *q)
+{
+    const bool wideFrames = (int)dict->set.dim > filter_dim_used((int)dict->set.dim);
+    return ctx->metric == SSYM_METRIC_DTW && q->set.n > 0 && !wideFrames && filter_supported(ctx, dict->set, q->set);
+}
+
+__global__ void fill_f64_kernel(double *p, double v, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        p[i] = v;
+}
+
+int32_t ssym_match_candidates(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queries *q, double *cost_dev)
+{
+    int32_t rc = check_match_args(ctx, dict, q);
+    if (rc != SSYM_OK)
+        return rc;
+    if (!cost_dev) {
+        ctx->err = "ssym_match_candidates: cost_dev is NULL";
+        return SSYM_E_INVALID;
+    }
+    ssym_ctx::Pending &pd = ctx->pending;
+    pd = ssym_ctx::Pending{};
+    const uint32_t M = q->set.n;
+    if (M == 0)
+        return SSYM_OK;
+    SSYM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (prune_applies(ctx, dict, q)) {
+        rc = launch_dtw_prune_candidates(ctx, dict->set, q->set);
+        if (rc != SSYM_OK)
+            return rc;
+        slots_to_targets_kernel<<<(M + 255) / 256, 256, 0, ctx->stream>>>((const double *)ctx->prune_cost.ptr,
+                                                                          q->set.perm, M, cost_dev);
+        pd.cand = true;
+        pd.dict = dict;
+        pd.q = q;
+    } else {
+        fill_f64_kernel<<<(M + 255) / 256, 256, 0, ctx->stream>>>(cost_dev, (double)INFINITY, M);
+    }
+    SSYM_HIP_CHECK(ctx, hipGetLastError());
+    SSYM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return SSYM_OK;
+}
+
+static int32_t match_begin_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queries *q, const double *distance,
+                                uint32_t index_base, double *bounds_dev, const double *prune_cost_dev)
 {
     int32_t rc = check_match_args(ctx, dict, q);
     if (rc != SSYM_OK)
@@ -593,6 +646,10 @@ int32_t ssym_match_begin(ssym_ctx *ctx, const ssym_dict *dict, const ssym_querie
         return SSYM_E_INVALID;
     }
     ssym_ctx::Pending &pd = ctx->pending;
+    // the reduced candidate costs are only usable when THIS context scored its candidates for the same sets
+    // (finish appends them); otherwise the call is a plain begin
+    if (prune_cost_dev && !(pd.cand && pd.dict == dict && pd.q == q && !distance))
+        prune_cost_dev = nullptr;
     pd = ssym_ctx::Pending{};
     pd.dict = dict;
     pd.q = q;
@@ -605,7 +662,8 @@ int32_t ssym_match_begin(ssym_ctx *ctx, const ssym_dict *dict, const ssym_querie
     pd.filter = ctx->metric == SSYM_METRIC_DTW && M > 0 && filter_supported(ctx, dict->set, q->set) &&
                 (!wideFrames || !distance);
     if (pd.filter) {
-        rc = match_impl(ctx, dict, q, distance, index_base, 1, nullptr, nullptr, 0, 1, bounds_dev);
+        rc = match_impl(ctx, dict, q, distance, index_base, 1, nullptr, nullptr, prune_cost_dev ? SSYM_DTW_PRUNE : 0u, 1,
+                        bounds_dev, prune_cost_dev);
         if (rc != SSYM_OK)
             return rc;
     } else if (M > 0) {
@@ -617,6 +675,22 @@ int32_t ssym_match_begin(ssym_ctx *ctx, const ssym_dict *dict, const ssym_querie
     }
     pd.valid = true;
     return SSYM_OK;
+}
+
+int32_t ssym_match_begin(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queries *q, const double *distance,
+                         uint32_t index_base, double *bounds_dev)
+{
+    return match_begin_impl(ctx, dict, q, distance, index_base, bounds_dev, nullptr);
+}
+
+int32_t ssym_match_begin_pruned(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queries *q, uint32_t index_base,
+                                const double *cost_dev, double *bounds_dev)
+{
+    if (ctx && !cost_dev) {
+        ctx->err = "ssym_match_begin_pruned: cost_dev is NULL";
+        return SSYM_E_INVALID;
+    }
+    return match_begin_impl(ctx, dict, q, nullptr, index_base, bounds_dev, cost_dev);
 }
 
 int32_t ssym_match_finish(ssym_ctx *ctx, const double *bounds_dev, uint32_t *out_idx, double *out_cost,

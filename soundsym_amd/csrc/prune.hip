@@ -141,7 +141,8 @@ __global__ __launch_bounds__(256) void prune_candidate_kernel(const float *__res
 }
 
 // abandon[slot] in accumulator units; pad slots get -inf (their lanes never hold a wave back)
-__global__ void prune_threshold_kernel(const double *__restrict__ exact, uint32_t nTgt, uint32_t nTgtPad,
+__global__ void prune_threshold_kernel(const double *__restrict__ exact, const uint32_t *__restrict__ permT,
+                                       uint32_t nTgt, uint32_t nTgtPad,
                                        const int *__restrict__ tgtLen, const float *__restrict__ tgtMaxSq,
                                        double srcMaxSq, int srcMaxFrames, MarginParams mp, double outScale,
                                        float *__restrict__ abandon)
@@ -153,7 +154,7 @@ __global__ void prune_threshold_kernel(const double *__restrict__ exact, uint32_
         abandon[t] = -__builtin_inff();
         return;
     }
-    const double c = exact[t];
+    const double c = exact[permT ? permT[t] : t];
     float thr = __builtin_inff();                       // no finite bound: nothing is dropped for this target
     if (c < __builtin_inf()) {
         const double u = 5.9604644775390625e-8;         // 2^-24
@@ -213,22 +214,18 @@ static int32_t ensure_centroids(ssym_ctx *ctx, const SegmentSet &set)
     return SSYM_OK;
 }
 
-int32_t launch_dtw_prune_thresholds(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt,
-                                    const float **abandon_out)
+// step 1-3 of the header comment: candidate pair per target slot and its exact cost
+// (ctx->prune_pairs: hdr | pairs[M] by slot | source by target; ctx->prune_cost[M] by slot)
+int32_t launch_dtw_prune_candidates(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt)
 {
     hipStream_t st = ctx->stream;
-    double scale = 1.0;
-    int32_t rc = ensure_filter_records(ctx, src, tgt, &scale);      // fixes the scale the thresholds are expressed in
-    if (rc == SSYM_OK)
-        rc = ensure_centroids(ctx, src);
+    int32_t rc = ensure_centroids(ctx, src);
     if (rc == SSYM_OK)
         rc = ensure_centroids(ctx, tgt);
     if (rc == SSYM_OK)
         rc = ensure(ctx, ctx->prune_pairs, sizeof(uint32_t) * 2 + (sizeof(uint2) + sizeof(uint32_t)) * (size_t)tgt.n);
     if (rc == SSYM_OK)
         rc = ensure(ctx, ctx->prune_cost, sizeof(double) * tgt.n);
-    if (rc == SSYM_OK)
-        rc = ensure(ctx, ctx->abandon, (sizeof(float) * tgt.n_pad + 15) / 8 * 8 + sizeof(unsigned long long));
     if (rc != SSYM_OK)
         return rc;
     uint32_t *hdr = (uint32_t *)ctx->prune_pairs.ptr;
@@ -238,14 +235,28 @@ int32_t launch_dtw_prune_thresholds(ssym_ctx *ctx, const SegmentSet &src, const 
         src.centroid, src.off, src.n, tgt.centroid, tgt.off, tgt.perm, tgt.n, src.dim, ctx->band, hdr, pairs,
         (uint32_t *)(pairs + tgt.n));
     SSYM_HIP_CHECK(ctx, hipGetLastError());
-    rc = launch_dtw_exact(ctx, src, tgt, pairs, hdr, tgt.n, (double *)ctx->prune_cost.ptr);
+    return launch_dtw_exact(ctx, src, tgt, pairs, hdr, tgt.n, (double *)ctx->prune_cost.ptr);
+}
+
+// step 4: thresholds in accumulator units -> ctx->abandon.  cost_by_target == NULL: this context's own
+// candidate costs; else per-target costs in the CALLER's order (a source-sharded run hands in the minimum
+// over all ranks' candidates: any pair above it loses to another shard's pair)
+int32_t launch_dtw_prune_thresholds(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt,
+                                    const double *cost_by_target, const float **abandon_out)
+{
+    hipStream_t st = ctx->stream;
+    double scale = 1.0;
+    int32_t rc = ensure_filter_records(ctx, src, tgt, &scale);      // fixes the scale the thresholds are expressed in
+    if (rc == SSYM_OK)
+        rc = ensure(ctx, ctx->abandon, (sizeof(float) * tgt.n_pad + 15) / 8 * 8 + sizeof(unsigned long long));
     if (rc != SSYM_OK)
         return rc;
     const MarginParams mp = margin_params(ctx, src);
     const double outScale = ctx->squared ? 1.0 / (scale * scale) : 1.0 / scale;
     prune_threshold_kernel<<<(tgt.n_pad + 255) / 256, 256, 0, st>>>(
-        (const double *)ctx->prune_cost.ptr, tgt.n, tgt.n_pad, tgt.len, tgt.max_sqnorm, src.max_sqnorm_all,
-        (int)src.max_frames, mp, outScale, (float *)ctx->abandon.ptr);
+        cost_by_target ? cost_by_target : (const double *)ctx->prune_cost.ptr, cost_by_target ? tgt.perm : nullptr,
+        tgt.n, tgt.n_pad, tgt.len, tgt.max_sqnorm, src.max_sqnorm_all, (int)src.max_frames, mp, outScale,
+        (float *)ctx->abandon.ptr);
     SSYM_HIP_CHECK(ctx, hipGetLastError());
     *abandon_out = (const float *)ctx->abandon.ptr;
     return SSYM_OK;

@@ -117,6 +117,8 @@ struct ssym_ctx {
     // ssym_match_begin .. ssym_match_finish (two-phase match of a source-sharded run)
     struct Pending {
         bool valid = false, filter = false, has_dist = false;
+        bool cand = false;          // ssym_match_candidates has scored this (dict, q): begin may prune
+        bool pruned = false;        // begin ran the filter with early abandoning: finish appends the candidates
         const ssym_dict *dict = nullptr;
         const ssym_queries *q = nullptr;
         uint32_t index_base = 0;
@@ -196,9 +198,11 @@ bool filter_supported(const ssym_ctx *ctx, const SegmentSet &src, const SegmentS
 int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt,
                           float *cmat /*[src.n_pad][tgt.n_pad]*/, const float *abandon = nullptr,
                           unsigned long long *colCtr = nullptr /* PRUNE: += column steps x rows per pass */);
-// prune.hip: candidate per target -> exact cost -> thresholds in ctx->abandon
+// prune.hip: candidate per target -> exact cost (ctx->prune_pairs / prune_cost, by target slot) ...
+int32_t launch_dtw_prune_candidates(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt);
+// ... -> thresholds in ctx->abandon, from the own costs or from cost_by_target (caller's target order)
 int32_t launch_dtw_prune_thresholds(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt,
-                                    const float **abandon_out);
+                                    const double *cost_by_target, const float **abandon_out);
 // the candidates (pairs + exact costs) join list 2 behind the entries dtw_exact has filled in
 int32_t launch_prune_append_known(ssym_ctx *ctx, uint32_t n_tgt);
 // the common scale the (unbanded) filter runs the two sets with; builds the records if needed

@@ -171,6 +171,16 @@ class Engine:
         nat.check(nat.lib().ssym_match_begin(self.ctx, d.ptr, q.ptr, dist_p, index_base, bounds.data_ptr()),
                   self.ctx)
 
+    def match_candidates(self, d: _Handle, q: _Handle, costs) -> None:
+        """ssym_match_candidates: exact cost of this shard's candidate pair per target into `costs`
+        (torch CUDA float64 [m]); all-reduce(MIN) it, then match_begin(..., candidate_costs=costs)."""
+        nat.check(nat.lib().ssym_match_candidates(self.ctx, d.ptr, q.ptr, costs.data_ptr()), self.ctx)
+
+    def match_begin_pruned(self, d: _Handle, q: _Handle, bounds, candidate_costs, index_base: int = 0) -> None:
+        """ssym_match_begin_pruned: match_begin whose filter abandons pairs above the reduced costs."""
+        nat.check(nat.lib().ssym_match_begin_pruned(self.ctx, d.ptr, q.ptr, index_base, candidate_costs.data_ptr(),
+                                                    bounds.data_ptr()), self.ctx)
+
     def match_finish(self, bounds, out_idx, out_cost):
         """ssym_match_finish with device outputs (torch CUDA tensors)."""
         nat.check(nat.lib().ssym_match_finish(self.ctx, bounds.data_ptr(), out_idx.data_ptr(),

@@ -75,13 +75,23 @@ def reduce_bounds(bounds, group=None):
     return bounds
 
 
-def match_sharded(engine, d, q, index_base, out_idx, out_cost, bounds, group=None, distance=None):
+def match_sharded(engine, d, q, index_base, out_idx, out_cost, bounds, group=None, distance=None, prune=False):
     """One rank's part of a source-sharded match: filter, agree on the per-target bound with the
     other ranks, select / re-score against it, gather every rank's winners and merge them.
-    All tensors are CUDA tensors on this rank's GPU; returns (idx [M], cost [M])."""
+    All tensors are CUDA tensors on this rank's GPU; returns (idx [M], cost [M]).
+    prune=True (plain nearest-neighbour search only): every rank scores one candidate pair per target
+    first, the costs are reduced with MIN, and the filters abandon against them -- one more exchange of
+    M f64 values, same results."""
     import torch
 
-    engine.match_begin(d, q, bounds, distance=distance, index_base=index_base)
+    if prune and distance is None:
+        cand = torch.empty_like(bounds)
+        engine.match_candidates(d, q, cand)
+        reduce_bounds(cand, group)
+        torch.cuda.current_stream().synchronize()
+        engine.match_begin_pruned(d, q, bounds, cand, index_base=index_base)
+    else:
+        engine.match_begin(d, q, bounds, distance=distance, index_base=index_base)
     reduce_bounds(bounds, group)
     torch.cuda.current_stream().synchronize()      # the library runs on its own stream
     engine.match_finish(bounds, out_idx, out_cost)

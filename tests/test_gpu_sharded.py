@@ -138,3 +138,64 @@ def test_two_shards_with_per_target_distances():
     assert np.array_equal(out_cost.cpu().numpy(), want_cost)
     for e, *_ in engines:
         e.close()
+
+
+@pytest.mark.parametrize("band", [-1, 8])
+def test_two_shards_pruned_exchange_candidates_first(oracle, band):
+    # early abandoning across shards: candidates' costs reduced with MIN before the filters run, so the shard
+    # WITHOUT a target's neighbour abandons against the neighbour's cost too; results stay those of one
+    # unsharded, unpruned match
+    n, m, f, dim = 512, 128, 64, 13
+    g = synth.make_grid(n, m, f, dim, 0x5EED0911)
+    g.sources[300] = g.sources[40]
+    g.targets[5] = g.sources[40]
+    whole = Engine(metric="dtw", dtype="f32", band=band)
+    d, q = _sets(whole, g, 0, n, f, dim)
+    want_idx, want_cost = whole.match(d, q)
+    whole.close()
+
+    shards = []
+    for r in range(2):
+        lo, hi = sharding.shard_range(n, 2, r)
+        e = Engine(metric="dtw", dtype="f32", band=band)
+        dd, qq = _sets(e, g, lo, hi, f, dim)
+        c = torch.empty(m, dtype=torch.float64, device="cuda")
+        e.match_candidates(dd, qq, c)
+        shards.append([e, dd, qq, c, lo])
+    cand = torch.minimum(shards[0][3], shards[1][3])
+    assert bool(torch.isfinite(cand).all())
+    cells = []
+    for s in shards:
+        e, dd, qq, _, lo = s
+        b = torch.empty(m, dtype=torch.float64, device="cuda")
+        e.match_begin_pruned(dd, qq, b, cand, index_base=lo)
+        tm = e.timings()
+        assert tm["pruned"] == 1
+        cells.append(tm["n_filter_cells"])
+        s.append(b)
+    agreed = torch.minimum(shards[0][5], shards[1][5])
+    costs, idxs = [], []
+    for e, dd, qq, _, lo, b in shards:
+        b.copy_(agreed)
+        oi = torch.empty(m, dtype=torch.int32, device="cuda")
+        oc = torch.empty(m, dtype=torch.float64, device="cuda")
+        e.match_finish(b, oi, oc)
+        costs.append(oc)
+        idxs.append(oi)
+    out_idx, out_cost = sharding.merge_shards(shards[0][0], torch.stack(costs), torch.stack(idxs))
+    assert np.array_equal(out_idx.cpu().numpy().astype(np.int64), want_idx.astype(np.int64))
+    assert np.array_equal(out_cost.cpu().numpy(), want_cost)
+    assert int(out_idx[5]) == 40
+    # with only its OWN candidates a shard could not drop the targets whose neighbour lives elsewhere
+    e, dd, qq, _, lo, _ = shards[1]
+    oi = torch.empty(m, dtype=torch.int32, device="cuda")
+    oc = torch.empty(m, dtype=torch.float64, device="cuda")
+    e.match(dd, qq, index_base=lo, out_idx=oi, out_cost=oc, prune=True)
+    assert e.timings()["n_filter_cells"] > cells[1]
+    # begin_pruned without candidates for these sets is a plain begin
+    b = torch.empty(m, dtype=torch.float64, device="cuda")
+    e.match_begin_pruned(dd, qq, b, cand, index_base=lo)
+    assert e.timings()["pruned"] == 0
+    e.match_finish(b, oi, oc)
+    for s in shards:
+        s[0].close()
