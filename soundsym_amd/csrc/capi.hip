@@ -417,7 +417,7 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
                     SSYM_HIP_CHECK(ctx, hipMemsetAsync(colCtr, 0, sizeof(*colCtr), st));
                 }
                 SSYM_HIP_CHECK(ctx, hipEventRecord(ev[6], st));
-                rc = launch_dtw_filter(ctx, src, tgt, cmat, abandon, colCtr);
+                rc = launch_dtw_filter(ctx, src, tgt, cmat, abandon, colCtr, prune ? prune_cand_slots(ctx, tgt) : nullptr);
                 if (rc != SSYM_OK)
                     return rc;
                 SSYM_HIP_CHECK(ctx, hipEventRecord(ev[1], st));
@@ -425,7 +425,8 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
                     SSYM_HIP_CHECK(ctx, hipMemcpyAsync(&ctx->pruned_cells, colCtr, sizeof(*colCtr),
                                                        hipMemcpyDeviceToHost, st));
                 rc = wide ? launch_dtw_bounds_partial(ctx, src, tgt, cmat)
-                          : launch_dtw_bounds(ctx, src, tgt, cmat, distDev, k_top);
+                          : launch_dtw_bounds(ctx, src, tgt, cmat, distDev, k_top,
+                                              prune ? (const double *)ctx->prune_cost.ptr : nullptr);
                 if (rc != SSYM_OK)
                     return rc;
             }

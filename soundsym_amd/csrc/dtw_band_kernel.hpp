@@ -36,7 +36,7 @@ __global__ __launch_bounds__(64 * WB, OCC) void dtw_band_kernel(
     const int *__restrict__ srcLen, const int *__restrict__ tgtLen, int srcSlots, int radius,
     int tgtFramesPad, int mPad, int nTgtBlocks, int nTasks, unsigned *__restrict__ taskCtr, float outScale,
     float *__restrict__ cmat, const float *__restrict__ abandon = nullptr,
-    unsigned long long *__restrict__ colCtr = nullptr)
+    unsigned long long *__restrict__ colCtr = nullptr, const uint32_t *__restrict__ candSlot = nullptr)
 {
     constexpr int REC = kFilterRecHalfs;
     constexpr int KB = (NTB - 1) * 16 + LASTN;   // diagonals held in registers (>= 2r+1)
@@ -115,7 +115,9 @@ __global__ __launch_bounds__(64 * WB, OCC) void dtw_band_kernel(
         float thr = INF;
         if (PRUNE)
             thr = abandon[32 * tg + col];
-        const bool dead = fa == 0 || fb_m1 < 0;        // an empty side: +inf whatever happens
+        bool dead = fa == 0 || fb_m1 < 0;              // an empty side: +inf whatever happens
+        if (PRUNE)                                     // ... or the target's candidate pair (exact cost known)
+            dead = dead || candSlot[32 * tg + col] == (uint32_t)(2 * sp + half);
         bool dropped = false;                          // wave-uniform
 
         const _Float16 *bbase = tgtRec + tgt_rec_offset(32 * tg + col, tgtFramesPad, 0, 0, half);

@@ -167,7 +167,7 @@ static int32_t ensure_records(ssym_ctx *ctx, const SegmentSet &set, double scale
 template <int NT, bool SQ>
 static void launch_one(hipStream_t st, const SegmentSet &src, const SegmentSet &tgt, int nPasses,
                        int gridBlocks, float outScale, float *handoff, unsigned *taskCtr, float *cmat,
-                       const float *abandon, unsigned long long *colCtr)
+                       const float *abandon, unsigned long long *colCtr, const uint32_t *candSlot)
 {
     // sources of at most 16 frames (one tile, one pass): three waves per SIMD, see filter_ring() -- 11 %
     // faster there; at 32 frames the gain was within 3 % and cost spills
@@ -188,18 +188,18 @@ static void launch_one(hipStream_t st, const SegmentSet &src, const SegmentSet &
         dtw_filter_kernel<NT, SQ, OCC, true><<<dim3(grid), 64 * kFilterWavesPerBlock, 0, st>>>(
             (const _Float16 *)src.rec, (const _Float16 *)tgt.rec, src.len, tgt.len, (int)src.frames_pad, nPasses,
             (int)tgt.frames_pad, (int)tgt.n_pad, nSrcPairs, nTasks, taskChunk, outScale, handoff, taskCtr, cmat,
-            abandon, colCtr);
+            abandon, colCtr, candSlot);
     else
         dtw_filter_kernel<NT, SQ, OCC, false><<<dim3(grid), 64 * kFilterWavesPerBlock, 0, st>>>(
             (const _Float16 *)src.rec, (const _Float16 *)tgt.rec, src.len, tgt.len, (int)src.frames_pad, nPasses,
             (int)tgt.frames_pad, (int)tgt.n_pad, nSrcPairs, nTasks, taskChunk, outScale, handoff, taskCtr, cmat,
-            nullptr, nullptr);
+            nullptr, nullptr, nullptr);
 }
 
 template <int NTB, int WB, int OCC, bool SQ, int LASTN, bool PRUNE>
 static int32_t launch_band_cfg2(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, uint32_t slots,
                                 size_t lds, float outScale, float *cmat, const float *abandon,
-                                unsigned long long *colCtr)
+                                unsigned long long *colCtr, const uint32_t *candSlot)
 {
     const int nTgtBlocks = (int)tgt.n_pad / (32 * WB);
     const int nTasks = ((int)src.n_pad / 2) * nTgtBlocks;
@@ -214,7 +214,7 @@ static int32_t launch_band_cfg2(ssym_ctx *ctx, const SegmentSet &src, const Segm
         SSYM_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     kern<<<dim3(grid), 64 * WB, lds, ctx->stream>>>(
         (const _Float16 *)src.rec, (const _Float16 *)tgt.rec, src.len, tgt.len, (int)slots, ctx->band,
-        (int)tgt.frames_pad, (int)tgt.n_pad, nTgtBlocks, nTasks, taskCtr, outScale, cmat, abandon, colCtr);
+        (int)tgt.frames_pad, (int)tgt.n_pad, nTgtBlocks, nTasks, taskCtr, outScale, cmat, abandon, colCtr, candSlot);
     SSYM_HIP_CHECK(ctx, hipGetLastError());
     return SSYM_OK;
 }
@@ -222,10 +222,10 @@ static int32_t launch_band_cfg2(ssym_ctx *ctx, const SegmentSet &src, const Segm
 template <int NTB, int WB, int OCC, bool SQ, int LASTN>
 static int32_t launch_band_cfg(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, uint32_t slots,
                                size_t lds, float outScale, float *cmat, const float *abandon,
-                               unsigned long long *colCtr)
+                               unsigned long long *colCtr, const uint32_t *candSlot)
 {
-    return abandon ? launch_band_cfg2<NTB, WB, OCC, SQ, LASTN, true>(ctx, src, tgt, slots, lds, outScale, cmat, abandon, colCtr)
-                   : launch_band_cfg2<NTB, WB, OCC, SQ, LASTN, false>(ctx, src, tgt, slots, lds, outScale, cmat, nullptr, nullptr);
+    return abandon ? launch_band_cfg2<NTB, WB, OCC, SQ, LASTN, true>(ctx, src, tgt, slots, lds, outScale, cmat, abandon, colCtr, candSlot)
+                   : launch_band_cfg2<NTB, WB, OCC, SQ, LASTN, false>(ctx, src, tgt, slots, lds, outScale, cmat, nullptr, nullptr, nullptr);
 }
 
 // Up to 5 tiles of diagonals (r <= 39) run two waves per SIMD (8-wave workgroups); at 4 and 5 tiles
@@ -234,20 +234,20 @@ static int32_t launch_band_cfg(ssym_ctx *ctx, const SegmentSet &src, const Segme
 // SSYM_BAND_OCC1=1 forces the one-wave variant for tuning experiments.
 template <int NTB, bool SQ>
 static int32_t launch_band(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, uint32_t slots,
-                           size_t lds, float outScale, float *cmat, const float *abandon, unsigned long long *colCtr)
+                           size_t lds, float outScale, float *cmat, const float *abandon, unsigned long long *colCtr, const uint32_t *candSlot)
 {
     static const bool forceOcc1 = getenv("SSYM_BAND_OCC1") != nullptr;
     // radii that are multiples of 8 end exactly one diagonal into their last tile
     const bool last1 = 2 * ctx->band + 1 == 16 * (NTB - 1) + 1;
     if (NTB <= 5 && !forceOcc1)
-        return last1 ? launch_band_cfg<NTB, 8, 2, SQ, 1>(ctx, src, tgt, slots, lds, outScale, cmat, abandon, colCtr)
-                     : launch_band_cfg<NTB, 8, 2, SQ, 16>(ctx, src, tgt, slots, lds, outScale, cmat, abandon, colCtr);
-    return last1 ? launch_band_cfg<NTB, 4, 1, SQ, 1>(ctx, src, tgt, slots, lds, outScale, cmat, abandon, colCtr)
-                 : launch_band_cfg<NTB, 4, 1, SQ, 16>(ctx, src, tgt, slots, lds, outScale, cmat, abandon, colCtr);
+        return last1 ? launch_band_cfg<NTB, 8, 2, SQ, 1>(ctx, src, tgt, slots, lds, outScale, cmat, abandon, colCtr, candSlot)
+                     : launch_band_cfg<NTB, 8, 2, SQ, 16>(ctx, src, tgt, slots, lds, outScale, cmat, abandon, colCtr, candSlot);
+    return last1 ? launch_band_cfg<NTB, 4, 1, SQ, 1>(ctx, src, tgt, slots, lds, outScale, cmat, abandon, colCtr, candSlot)
+                 : launch_band_cfg<NTB, 4, 1, SQ, 16>(ctx, src, tgt, slots, lds, outScale, cmat, abandon, colCtr, candSlot);
 }
 
 static int32_t launch_dtw_filter_banded(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, float *cmat,
-                                        const float *abandon, unsigned long long *colCtr)
+                                        const float *abandon, unsigned long long *colCtr, const uint32_t *candSlot)
 {
     if (tgt.n_pad % kBandTgtQuantum != 0 || src.n_pad % 2 != 0) {
         ctx->err = "dtw band filter: segment set not padded for the banded kernel";
@@ -267,8 +267,8 @@ static int32_t launch_dtw_filter_banded(ssym_ctx *ctx, const SegmentSet &src, co
     const int ntb = (2 * ctx->band + 1 + 15) / 16;
 #define SSYM_BCASE(N_)                                                                                  \
     case N_:                                                                                            \
-        return sq ? launch_band<N_, true>(ctx, src, tgt, slots, lds, outScale, cmat, abandon, colCtr)   \
-                  : launch_band<N_, false>(ctx, src, tgt, slots, lds, outScale, cmat, abandon, colCtr);
+        return sq ? launch_band<N_, true>(ctx, src, tgt, slots, lds, outScale, cmat, abandon, colCtr, candSlot)   \
+                  : launch_band<N_, false>(ctx, src, tgt, slots, lds, outScale, cmat, abandon, colCtr, candSlot);
     switch (ntb) {
         SSYM_BCASE(1) SSYM_BCASE(2) SSYM_BCASE(3) SSYM_BCASE(4) SSYM_BCASE(5) SSYM_BCASE(6)
     default:
@@ -291,10 +291,10 @@ int32_t ensure_filter_records(ssym_ctx *ctx, const SegmentSet &src, const Segmen
 }
 
 int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, float *cmat,
-                          const float *abandon, unsigned long long *colCtr)
+                          const float *abandon, unsigned long long *colCtr, const uint32_t *candSlot)
 {
     if (ctx->band >= 0)
-        return launch_dtw_filter_banded(ctx, src, tgt, cmat, abandon, colCtr);
+        return launch_dtw_filter_banded(ctx, src, tgt, cmat, abandon, colCtr, candSlot);
     const FilterShape shape = filter_shape((int)src.max_frames);
     if (shape.nt == 0 || (int)src.frames_pad != shape.rows() || src.n_pad % 8 != 0 || tgt.n_pad % 32 != 0) {
         ctx->err = "dtw filter: segment set not padded for the filter kernel";
@@ -324,8 +324,8 @@ int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
     float *hand = (float *)ctx->handoff.ptr;
 #define SSYM_CASE(NT_)                                                                          \
     case NT_:                                                                                   \
-        if (sq) launch_one<NT_, true>(st, src, tgt, shape.rb, gridBlocks, outScale, hand, taskCtr, cmat, abandon, colCtr);  \
-        else launch_one<NT_, false>(st, src, tgt, shape.rb, gridBlocks, outScale, hand, taskCtr, cmat, abandon, colCtr);    \
+        if (sq) launch_one<NT_, true>(st, src, tgt, shape.rb, gridBlocks, outScale, hand, taskCtr, cmat, abandon, colCtr, candSlot);  \
+        else launch_one<NT_, false>(st, src, tgt, shape.rb, gridBlocks, outScale, hand, taskCtr, cmat, abandon, colCtr, candSlot);    \
         break;
     switch (shape.nt) {
         SSYM_CASE(1) SSYM_CASE(2) SSYM_CASE(3) SSYM_CASE(4)

@@ -169,7 +169,8 @@ constexpr int wait_vmcnt(int n) { return 0x0F70 | (n & 15) | ((n >> 4) << 14); }
 // the path's last cell in column j lies in this pass's rows (>= the column's minimum), or the path
 // has already left through the pass's bottom row at a column <= j (>= the running minimum of the
 // bottoms), or it is still above and will enter through the top row later (>= the minimum over the
-// previous pass's bottoms).  When that bound exceeds abandon[t] for every lane of the wave -- lanes
+// previous pass's bottoms).  When that bound exceeds abandon[t] for every lane of the wave -- the lane of
+// a target's candidate pair (candSlot) needs no filter value at all and counts as dead, lanes
 // whose result is already captured count as done, lanes whose source only begins in a later pass
 // count as undecided -- the rest of the task is skipped and the unfinished lanes report +inf, which
 // selection treats as "never a candidate".
@@ -179,7 +180,8 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_ker
     const int *__restrict__ srcLen, const int *__restrict__ tgtLen, int srcRows, int nPasses,
     int tgtFramesPad, int mPad, int nSrcPairs, int nTasks, int taskChunk, float outScale,
     float *__restrict__ handoff, unsigned *__restrict__ taskCtr, float *__restrict__ cmat,
-    const float *__restrict__ abandon = nullptr, unsigned long long *__restrict__ colCtr = nullptr)
+    const float *__restrict__ abandon = nullptr, unsigned long long *__restrict__ colCtr = nullptr,
+    const uint32_t *__restrict__ candSlot = nullptr)
 {
     constexpr int REC = kFilterRecHalfs;
     constexpr int BR = NT * 16;            // rows per pass
@@ -252,7 +254,11 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_ker
         bool dropped = false;                  // wave-uniform
         if (PRUNE)
             thr = abandon[32 * tg + col];
-        const bool dead = fa == 0 || fb_m1 < 0;   // PRUNE: an empty side, the result is +inf whatever happens
+        // PRUNE: an empty side (the result is +inf whatever happens), or the target's candidate pair, whose
+        // exact cost is known and stands in for its filter value everywhere (prune.hip)
+        bool dead = fa == 0 || fb_m1 < 0;
+        if (PRUNE)
+            dead = dead || candSlot[32 * tg + col] == (uint32_t)(2 * sp + half);
         const char *const tgtGroup = reinterpret_cast<const char *>(tgtRec) + (size_t)tg * tgtFramesPad * (kTgtFrameHalfs * 2);
 
         for (int pass = nCols > 0 ? firstPass : nPasses; pass < nPasses && !dropped; ++pass) {

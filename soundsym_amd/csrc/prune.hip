@@ -12,6 +12,9 @@
 //      a segment very little, so a warped copy of a source is found; when nothing is close the
 //      candidate is still a valid pair and merely gives a weak bound);
 //   3. exact f64 cost of the M candidate pairs (dtw_exact.hip);
+//      -- the candidate pairs themselves are finished: their lanes count as dead in the filter (their
+//      exact cost seeds the selection's per-target bound instead of their filter value) and they join the
+//      final fold directly, so no task has to run to its end for their sake;
 //   4. threshold in the filter's accumulator units: a filter value D~ stands for a true prefix cost
 //      D >= D~ (1 - (L+6) u) - 1.02 L cell  (dtw_margin.hpp with the worst-case cell error over the
 //      dictionary), so "D~ > (c + 1.02 L cell) / ((1 - (L+6) u) outScale)" proves cost > c.
@@ -51,13 +54,16 @@ constexpr int kCandTargets = 16;   // targets per workgroup of the candidate sea
 
 // pairs[t] = (source with the nearest centroid among the non-empty ones, target of slot t), t < nTgt
 __global__ __launch_bounds__(256) void prune_candidate_kernel(const float *__restrict__ cenS,
-                                                              const uint64_t *__restrict__ offS, uint32_t nSrc,
+                                                              const uint64_t *__restrict__ offS,
+                                                              const uint32_t *__restrict__ permS, uint32_t nSrc,
                                                               const float *__restrict__ cenT,
                                                               const uint64_t *__restrict__ offT,
                                                               const uint32_t *__restrict__ permT, uint32_t nTgt,
-                                                              uint32_t dim, int band, uint32_t *__restrict__ hdr,
+                                                              uint32_t nTgtPad, uint32_t dim, int band,
+                                                              uint32_t *__restrict__ hdr,
                                                               uint2 *__restrict__ pairs,
-                                                              uint32_t *__restrict__ knownSrc)
+                                                              uint32_t *__restrict__ knownSrc,
+                                                              uint32_t *__restrict__ candSlot)
 {
     extern __shared__ float tm[];                       // [dim][kCandTargets]
     __shared__ float redD[4][kCandTargets];
@@ -66,6 +72,9 @@ __global__ __launch_bounds__(256) void prune_candidate_kernel(const float *__res
     const uint32_t t0 = blockIdx.x * kCandTargets;
     if (blockIdx.x == 0 && threadIdx.x == 0)
         hdr[0] = nTgt, hdr[1] = 0;
+    if (blockIdx.x == 0)
+        for (uint32_t t = nTgt + threadIdx.x; t < nTgtPad; t += 256)
+            candSlot[t] = 0xffffffffu;                  // pad target slots have no candidate
     for (uint32_t i = threadIdx.x; i < dim * kCandTargets; i += 256) {
         const uint32_t k = i / kCandTargets, tt = i % kCandTargets;
         const uint32_t slot = t0 + tt;
@@ -81,7 +90,10 @@ __global__ __launch_bounds__(256) void prune_candidate_kernel(const float *__res
 #pragma unroll
     for (int tt = 0; tt < kCandTargets; ++tt)
         best[tt] = __builtin_inff(), bi[tt] = 0xffffffffu;
-    for (uint32_t s = threadIdx.x; s < nSrc; s += 256) {
+    // sources are walked in record-slot order (slots [0, nSrc) hold the real segments): the filter wants the
+    // candidate's slot, everything else its index as the caller counts
+    for (uint32_t p = threadIdx.x; p < nSrc; p += 256) {
+        const uint32_t s = permS[p];
         const int ls = (int)(offS[s + 1] - offS[s]);
         if (ls == 0)
             continue;                                   // an empty source matches nothing
@@ -102,7 +114,7 @@ __global__ __launch_bounds__(256) void prune_candidate_kernel(const float *__res
             // inside a Sakoe-Chiba band a pair whose lengths differ by more than r has no path at all
             const float dd = (band >= 0 && abs(ls - lenT[tt]) > band) ? __builtin_inff() : d[tt];
             if (dd < best[tt] || bi[tt] == 0xffffffffu)        // (also takes a NaN distance when nothing else came)
-                best[tt] = dd, bi[tt] = s;
+                best[tt] = dd, bi[tt] = p;
         }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -133,9 +145,11 @@ __global__ __launch_bounds__(256) void prune_candidate_kernel(const float *__res
             i = take ? oi : i;
         }
         if (slot < nTgt) {
-            const uint32_t s = i == 0xffffffffu ? 0u : i;          // all sources empty: cost +inf anyway
+            const uint32_t p = i == 0xffffffffu ? 0u : i;          // all sources empty: cost +inf anyway
+            const uint32_t s = permS[p];
             pairs[slot] = make_uint2(s, permT[slot]);
             knownSrc[permT[slot]] = s;
+            candSlot[slot] = p;
         }
     }
 }
@@ -214,6 +228,12 @@ static int32_t ensure_centroids(ssym_ctx *ctx, const SegmentSet &set)
     return SSYM_OK;
 }
 
+// the candidate's source SLOT per target slot (pad slots: none), behind the pairs and the per-target sources
+uint32_t *prune_cand_slots(ssym_ctx *ctx, const SegmentSet &tgt)
+{
+    return (uint32_t *)((uint2 *)((uint32_t *)ctx->prune_pairs.ptr + 2) + tgt.n) + tgt.n;
+}
+
 // step 1-3 of the header comment: candidate pair per target slot and its exact cost
 // (ctx->prune_pairs: hdr | pairs[M] by slot | source by target; ctx->prune_cost[M] by slot)
 int32_t launch_dtw_prune_candidates(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt)
@@ -223,7 +243,8 @@ int32_t launch_dtw_prune_candidates(ssym_ctx *ctx, const SegmentSet &src, const 
     if (rc == SSYM_OK)
         rc = ensure_centroids(ctx, tgt);
     if (rc == SSYM_OK)
-        rc = ensure(ctx, ctx->prune_pairs, sizeof(uint32_t) * 2 + (sizeof(uint2) + sizeof(uint32_t)) * (size_t)tgt.n);
+        rc = ensure(ctx, ctx->prune_pairs,
+                    sizeof(uint32_t) * 2 + (sizeof(uint2) + sizeof(uint32_t)) * (size_t)tgt.n + sizeof(uint32_t) * tgt.n_pad);
     if (rc == SSYM_OK)
         rc = ensure(ctx, ctx->prune_cost, sizeof(double) * tgt.n);
     if (rc != SSYM_OK)
@@ -232,8 +253,8 @@ int32_t launch_dtw_prune_candidates(ssym_ctx *ctx, const SegmentSet &src, const 
     uint2 *pairs = (uint2 *)(hdr + 2);
     const unsigned nb = (tgt.n + kCandTargets - 1) / kCandTargets;
     prune_candidate_kernel<<<nb, 256, sizeof(float) * src.dim * kCandTargets, st>>>(
-        src.centroid, src.off, src.n, tgt.centroid, tgt.off, tgt.perm, tgt.n, src.dim, ctx->band, hdr, pairs,
-        (uint32_t *)(pairs + tgt.n));
+        src.centroid, src.off, src.perm, src.n, tgt.centroid, tgt.off, tgt.perm, tgt.n, tgt.n_pad, src.dim, ctx->band, hdr,
+        pairs, (uint32_t *)(pairs + tgt.n), prune_cand_slots(ctx, tgt));
     SSYM_HIP_CHECK(ctx, hipGetLastError());
     return launch_dtw_exact(ctx, src, tgt, pairs, hdr, tgt.n, (double *)ctx->prune_cost.ptr);
 }

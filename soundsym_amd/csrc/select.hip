@@ -579,8 +579,19 @@ int32_t launch_dtw_select2(ssym_ctx *ctx, const SegmentSet &src, const SegmentSe
 }
 
 // stage-1 threshold per target -> ctx->tmin: the smallest (k-th smallest distinct) worst-case upper key bound
+// ub[t] = the exact cost of a pair scored already (early abandoning: the target's candidate), a valid
+// upper bound of the target's minimum that does not depend on the pair's filter value
+__global__ void seed_bounds_kernel(const double *__restrict__ seed, uint32_t n, unsigned long long *__restrict__ ub)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n)
+        return;
+    const double c = seed[t];
+    ub[t] = (c >= 0.0 && c < __builtin_inf()) ? (unsigned long long)__double_as_longlong(c) : kInfBits;
+}
+
 int32_t launch_dtw_bounds(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, const float *cmat,
-                          const double *dist_dev, uint32_t k_top)
+                          const double *dist_dev, uint32_t k_top, const double *seed_by_slot)
 {
     hipStream_t st = ctx->stream;
     const MarginParams mp = margin_params(ctx, src);
@@ -589,7 +600,10 @@ int32_t launch_dtw_bounds(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
         return rc;
     unsigned long long *ub = (unsigned long long *)ctx->tmin.ptr;
     const uint32_t nChunks = (src.n + kSelChunk - 1) / kSelChunk;
-    fill_u64_kernel<<<(tgt.n + 255) / 256, 256, 0, st>>>(ub, kInfBits, tgt.n);
+    if (seed_by_slot && k_top <= 1 && !dist_dev)
+        seed_bounds_kernel<<<(tgt.n + 255) / 256, 256, 0, st>>>(seed_by_slot, tgt.n, ub);
+    else
+        fill_u64_kernel<<<(tgt.n + 255) / 256, 256, 0, st>>>(ub, kInfBits, tgt.n);
     dim3 grid((tgt.n + 255) / 256, nChunks);
     if (k_top <= 1) {
         dtw_colmin_kernel<<<grid, 256, 0, st>>>(cmat, src.n, tgt.n, tgt.n_pad, dist_dev, src.len,

@@ -197,9 +197,11 @@ bool filter_supported(const ssym_ctx *ctx, const SegmentSet &src, const SegmentS
 // abandon != NULL: early abandoning against per-target-slot thresholds in accumulator units (prune.hip)
 int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt,
                           float *cmat /*[src.n_pad][tgt.n_pad]*/, const float *abandon = nullptr,
-                          unsigned long long *colCtr = nullptr /* PRUNE: += column steps x rows per pass */);
+                          unsigned long long *colCtr = nullptr /* PRUNE: += column steps x rows per pass */,
+                          const uint32_t *candSlot = nullptr /* PRUNE: per target slot, the source slot scored already */);
 // prune.hip: candidate per target -> exact cost (ctx->prune_pairs / prune_cost, by target slot) ...
 int32_t launch_dtw_prune_candidates(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt);
+uint32_t *prune_cand_slots(ssym_ctx *ctx, const SegmentSet &tgt);   // candidate's source slot per target slot
 // ... -> thresholds in ctx->abandon, from the own costs or from cost_by_target (caller's target order)
 int32_t launch_dtw_prune_thresholds(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt,
                                     const double *cost_by_target, const float **abandon_out);
@@ -222,7 +224,8 @@ int32_t launch_dtw_exact(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet 
 // [n_tgt][k_top] (rounds of the same fold, each above the previous round's (key, index))
 // stage 1: worst-case margin over the whole filter matrix -> ctx->cand (list 1)
 int32_t launch_dtw_bounds(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, const float *cmat,
-                          const double *dist_dev, uint32_t k_top);      // threshold per target -> ctx->tmin
+                          const double *dist_dev, uint32_t k_top,       // threshold per target -> ctx->tmin
+                          const double *seed_by_slot = nullptr /* exact costs of pairs known already (k_top = 1) */);
 // wide frames: the filter cost is only a lower bound; the threshold is the EXACT cost of the pair the
 // filter likes best per target (one exact evaluation per target) -> ctx->tmin
 int32_t launch_dtw_bounds_partial(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, const float *cmat);
