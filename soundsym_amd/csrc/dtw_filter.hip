@@ -295,11 +295,18 @@ int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
 {
     if (ctx->band >= 0)
         return launch_dtw_filter_banded(ctx, src, tgt, cmat, abandon, colCtr, candSlot);
-    const FilterShape shape = filter_shape((int)src.max_frames);
+    FilterShape shape = filter_shape((int)src.max_frames);
     if (shape.nt == 0 || (int)src.frames_pad != shape.rows() || src.n_pad % 8 != 0 || tgt.n_pad % 32 != 0) {
         ctx->err = "dtw filter: segment set not padded for the filter kernel";
         return SSYM_E_UNSUPPORTED;
     }
+    // Early abandoning, tuning knob SSYM_PRUNE_NT=2: a dropped task never leaves its first row pass, and with
+    // 32-row passes it sweeps half the cells (headline grid 4.7 -> 3.1 ms) -- but a task that is NOT dropped
+    // pays two more hand-offs (+17 % on data without close pairs), and once a threshold exceeds what 32 rows
+    // cost (256-frame segments) no pass can be left early at all (3.2 -> 13 ms).  Not the default.
+    static const int pruneNt = getenv("SSYM_PRUNE_NT") ? atoi(getenv("SSYM_PRUNE_NT")) : 4;
+    if (abandon && shape.nt == 4 && (pruneNt == 2 || pruneNt == 1))
+        shape = FilterShape{pruneNt, shape.rb * (4 / pruneNt)};
     const double scale = common_scale(src, tgt);
     int32_t rc = ensure_records(ctx, src, scale, src.frames_pad, -1);
     if (rc != SSYM_OK)

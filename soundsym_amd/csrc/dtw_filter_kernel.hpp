@@ -147,6 +147,12 @@ constexpr int kFilterWavesPerBlock = 4;
 #ifndef SSYM_PRUNE_EVERY
 #define SSYM_PRUNE_EVERY 8
 #endif
+#ifndef SSYM_PRUNE_FINE
+#define SSYM_PRUNE_FINE 48
+#endif
+// pairs far above their threshold are dropped within the first few dozen columns: there the test runs every
+// 4 columns (a later test costs a sixth of the columns such a task sweeps at all), afterwards every kPruneEvery
+constexpr int kPruneFine = SSYM_PRUNE_FINE;
 constexpr int kPruneEvery = SSYM_PRUNE_EVERY;   // PRUNE: columns between two abandon tests (a test is BR/2 v_min3 + a vote)
 constexpr int kTaskCtrStride = 64;      // the 8 task counters sit in separate 256-byte lines (separate L2 channels)
 // Target columns staged in LDS per wave: 4 at two waves per SIMD (three columns of lead); the single-pass
@@ -390,7 +396,7 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_ker
                         }
                         if (PRUNE) {
                             runBot = __builtin_fminf(runBot, bottom);
-                            if (q == 3 && (j & (kPruneEvery - 1)) == kPruneEvery - 1) {
+                            if (q == 3 && (j < kPruneFine || (j & (kPruneEvery - 1)) == kPruneEvery - 1)) {
                                 // q == 3: the column just written is L0
                                 float lb = haveTop ? allBotPrev : INF;
                                 if (!lastPass)
