@@ -522,6 +522,10 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
             if (tm.pruned) {
                 tm.prune_ms = phase == 2 ? 0.f : ev_ms(ev[0], ev[6]);
                 tm.n_filter_cells = ctx->pruned_cells * 64ull;
+                if (ctx->band < 0) {
+                    const double full = (double)src.n_pad * tgt.n_pad * src.frames_pad * std::max<uint32_t>(tgt.max_frames, 1);
+                    ctx->prune_swept = (float)std::min(1.0, (double)tm.n_filter_cells / full);
+                }
             }
             tm.select_ms = sel_ms;
             tm.refine_ms = ref_ms;

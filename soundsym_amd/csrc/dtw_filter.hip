@@ -300,13 +300,16 @@ int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
         ctx->err = "dtw filter: segment set not padded for the filter kernel";
         return SSYM_E_UNSUPPORTED;
     }
-    // Early abandoning, tuning knob SSYM_PRUNE_NT=2: a dropped task never leaves its first row pass, and with
-    // 32-row passes it sweeps half the cells (headline grid 4.7 -> 3.1 ms) -- but a task that is NOT dropped
-    // pays two more hand-offs (+17 % on data without close pairs), and once a threshold exceeds what 32 rows
-    // cost (256-frame segments) no pass can be left early at all (3.2 -> 13 ms).  Not the default.
-    static const int pruneNt = getenv("SSYM_PRUNE_NT") ? atoi(getenv("SSYM_PRUNE_NT")) : 4;
-    if (abandon && shape.nt == 4 && (pruneNt == 2 || pruneNt == 1))
-        shape = FilterShape{pruneNt, shape.rb * (4 / pruneNt)};
+    // Early abandoning: the work of a pruned task is about the area where D <= threshold, counted in whole
+    // row passes x columns, so lower passes waste less: with 32-row passes the headline grid takes 3.1 ms
+    // instead of 4.6.  But a task that cannot be cut short pays two more hand-offs per 128 rows (+17 % on
+    // data without close pairs).  Results do not depend on the pass height, so it follows the data: 32 rows
+    // when the previous pruned call on this context swept less than a quarter of its cells, 64 otherwise
+    // (and on the first call).  SSYM_PRUNE_NT=2|4 pins it for measurements.
+    static const int pinned = getenv("SSYM_PRUNE_NT") ? atoi(getenv("SSYM_PRUNE_NT")) : 0;
+    const int pruneNt = pinned == 2 || pinned == 4 ? pinned : (ctx->prune_swept < 0.25f ? 2 : 4);
+    if (abandon && shape.nt == 4 && pruneNt == 2)
+        shape = FilterShape{2, shape.rb * 2};
     const double scale = common_scale(src, tgt);
     int32_t rc = ensure_records(ctx, src, scale, src.frames_pad, -1);
     if (rc != SSYM_OK)

@@ -171,15 +171,16 @@ constexpr int wait_vmcnt(int n) { return 0x0F70 | (n & 15) | ((n >> 4) << 14); }
 // PRUNE (early abandoning, SSYM_DTW_PRUNE): abandon[t] is a per-target value, in the accumulator's
 // units, that no pair of interest can exceed (prune.hip derives it from the exact cost of one
 // candidate pair per target plus the filter's worst-case error).  Costs are non-negative, so the
-// cost of a pair is at least the D value of any cell its optimal path visits; after column j of pass p
-// the path's last cell in column j lies in this pass's rows (>= the column's minimum), or the path
-// has already left through the pass's bottom row at a column <= j (>= the running minimum of the
-// bottoms), or it is still above and will enter through the top row later (>= the minimum over the
-// previous pass's bottoms).  When that bound exceeds abandon[t] for every lane of the wave -- the lane of
-// a target's candidate pair (candSlot) needs no filter value at all and counts as dead, lanes
-// whose result is already captured count as done, lanes whose source only begins in a later pass
-// count as undecided -- the rest of the task is skipped and the unfinished lanes report +inf, which
-// selection treats as "never a candidate".
+// cost of a pair is at least the D value of any cell its optimal path visits.  A row pass STOPS at
+// column j when, on every lane, the minimum over the pass's rows in column j exceeds abandon[t] (or the
+// lane's target has ended, or the lane is dead: an empty side, or the target's candidate pair, candSlot,
+// which needs no filter value at all) and the previous pass delivered nothing beyond column j: a path
+// that is inside this pass's rows at column j, or enters them later, is above its threshold, so only
+// paths that have left through the bottom row at a column <= j can still matter -- the next pass reads
+// the bottoms up to j and +inf behind them.  The TASK is dropped after a pass whose bottoms are all
+// above the thresholds (every path crosses that row; a lane whose source only begins in a later pass
+// keeps the task alive): the remaining passes are skipped and the unfinished lanes report +inf, which
+// selection treats as "never a candidate".  The work per task is then about the area where D <= threshold.
 template <int NT, bool SQ, int OCC = 2, bool PRUNE = false>
 __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_kernel(
     const _Float16 *__restrict__ srcRec, const _Float16 *__restrict__ tgtRec,
@@ -256,8 +257,9 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_ker
         const int firstPass = min(max(r0min - 1, 0) / BR, nPasses - 1);
 
         float res = INF;
-        float thr = INF, allBotPrev = INF;     // PRUNE: threshold of the lane's target; min over the previous pass's bottoms
+        float thr = INF;                       // PRUNE: threshold of the lane's target
         bool dropped = false;                  // wave-uniform
+        int lastTop = -1;                      // PRUNE: last column the previous pass computed (its bottoms end there)
         if (PRUNE)
             thr = abandon[32 * tg + col];
         // PRUNE: an empty side (the result is +inf whatever happens), or the target's candidate pair, whose
@@ -351,14 +353,17 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_ker
 
             float bq[4] = {INF, INF, INF, INF};                     // bottoms of the current group of 4 columns
             float runBot = INF;                                     // PRUNE: min of this pass's bottoms so far
-            for (int j0 = 0; j0 < nCols && !dropped; j0 += 4) {
+            bool passOver = false;                                  // PRUNE: nothing at or below a threshold is left in this pass
+            int lastCol = nCols - 1;
+            for (int j0 = 0; j0 < nCols && !passOver; j0 += 4) {
                 if (PRUNE)
                     colSteps += (unsigned)min(4, nCols - j0);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int j = j0 + q;
                     if (j < nCols) {                                // wave-uniform
-                        const float up = haveTop ? topN : INF;
+                        // (PRUNE: the previous pass may have stopped early; beyond its last column nothing enters from above)
+                        const float up = (haveTop && (!PRUNE || j <= lastTop)) ? topN : INF;
                         const float diag = (j == 0) ? diagCol0 : prevTop;
                         prevTop = up;
                         // column j+1 was staged kFilterRing - 1 columns ago; at least the two
@@ -398,23 +403,27 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_ker
                             runBot = __builtin_fminf(runBot, bottom);
                             if (q == 3 && (j < kPruneFine || (j & (kPruneEvery - 1)) == kPruneEvery - 1)) {
                                 // q == 3: the column just written is L0
-                                float lb = haveTop ? allBotPrev : INF;
-                                if (!lastPass)
-                                    lb = __builtin_fminf(lb, runBot);
+                                float cm = L0[0];
 #pragma unroll
-                                for (int i = 0; i < BR; i += 2)
-                                    lb = __builtin_fminf(__builtin_fminf(lb, L0[i]), L0[i + 1]);
-                                // (a source that begins below this pass has no cell here yet: its lane waits)
-                                const bool gone = (started && !(lb <= thr)) || (lastPass && j >= fb_m1) || dead;
-                                dropped = __all(gone);
+                                for (int i = 1; i < BR; i += 2)
+                                    cm = __builtin_fminf(__builtin_fminf(cm, L0[i]), i + 1 < BR ? L0[i + 1] : L0[i]);
+                                // every path still inside this pass's rows at column j is above the threshold (or the
+                                // lane's target has ended, or the lane is dead), and nothing enters from above any
+                                // more: whatever can still win has left through the bottom row already
+                                const bool quiet = !(cm <= thr) || j >= fb_m1 || dead;
+                                if (__all(quiet) && j >= lastTop) {
+                                    passOver = true;
+                                    lastCol = j;
+                                }
                             }
                         }
                     }
                 }
             }
-            if (PRUNE && !lastPass && !dropped) {
-                // every path still has to cross this pass's bottom row
-                allBotPrev = runBot;
+            if (PRUNE && !lastPass) {
+                // the paths that can still win crossed this pass's bottom row at a column <= lastCol (a source
+                // that begins below this pass has no cell here yet: its lane keeps the task alive)
+                lastTop = lastCol;
                 dropped = __all((started && !(runBot <= thr)) || dead);
             }
         }

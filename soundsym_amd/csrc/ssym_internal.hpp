@@ -110,6 +110,7 @@ struct ssym_ctx {
     ssym::DeviceBuf part;       // refcos partial argmin
     ssym::DeviceBuf out_idx, out_cost;  // staging for host outputs
     hipEvent_t ev[8]{};
+    float prune_swept = 1.f;               // share of the filter's cells the last pruned call swept (picks the pass height)
     unsigned long long pruned_cells = 0;   // SSYM_DTW_PRUNE: the filter's counter of the last call (host copy)
     // set by ssym_match_batch / ssym_match_one around their internal pack: the call synchronises
     // once at its end, so the pack stages need not wait for their copies individually

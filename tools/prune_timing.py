@@ -46,5 +46,6 @@ if __name__ == "__main__":
     run(4096, 4096, 128, 13, 0x5EED0003, planted=False)
     run(2048, 2048, 256, 13, 0x5EED0013)
     run(4096, 4096, 40, 13, 0x5EED0023)
+    run(1024, 1024, 512, 13, 0x5EED0033, reps=3)
     run(4096, 4096, 256, 40, 0x5EED0005, band=32, reps=3)
     run(4096, 4096, 256, 40, 0x5EED0005, band=32, reps=3, planted=False)
