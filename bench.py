@@ -265,8 +265,8 @@ def main():
             "filter_cells_swept_frac": ptm["n_filter_cells"] / full_cells if ptm["pruned"] else None,
             "phase_ms": {k: round(float(v), 3) for k, v in ptm.items() if k.endswith("_ms")},
             "rank0_only": ["filter_cells_swept_frac", "phase_ms"] if world > 1 else [],
-            "note": "one centroid-nearest candidate per target scored exactly, then the filter abandons 64-pair "
-                    "tasks that are provably above it; planted grid = best case (no-close-pair data: +4 % over the full search)",
+            "note": "one centroid-nearest candidate per target scored exactly, then the filter stops row passes and drops "
+                    "64-pair tasks that are provably above it; planted grid = best case (no-close-pair data: +4 % over the full search)",
         }
 
     if rank == 0:
