@@ -306,7 +306,8 @@ int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
     // data without close pairs).  Results do not depend on the pass height, so it follows the data: 32 rows
     // when the previous pruned call on this context swept less than a quarter of its cells, 64 otherwise
     // (and on the first call).  SSYM_PRUNE_NT=2|4 pins it for measurements.
-    static const int pinned = getenv("SSYM_PRUNE_NT") ? atoi(getenv("SSYM_PRUNE_NT")) : 0;
+    const char *pin = abandon ? getenv("SSYM_PRUNE_NT") : nullptr;
+    const int pinned = pin ? atoi(pin) : 0;
     const int pruneNt = pinned == 2 || pinned == 4 ? pinned : (ctx->prune_swept < 0.25f ? 2 : 4);
     if (abandon && shape.nt == 4 && pruneNt == 2)
         shape = FilterShape{2, shape.rb * 2};

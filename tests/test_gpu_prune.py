@@ -9,6 +9,8 @@ from soundsym_amd import Engine, synth
 from soundsym_amd.engine import pack_segments
 
 pytestmark = pytest.mark.gpu
+import os
+_N = int(os.environ.get("SSYM_FUZZ_CASES", "40"))      # SSYM_FUZZ_CASES=N widens the seeded sweeps
 
 
 def _both(e, d, q, **kw):
@@ -42,7 +44,7 @@ def test_prune_planted_grid(oracle, n, m, f, d):
     e.close()
 
 
-@pytest.mark.parametrize("case", range(40))
+@pytest.mark.parametrize("case", range(_N))
 def test_prune_random_shapes(oracle, case):
     st = synth.Stream(0x5EED4000 + case)
     dim = int([1, 2, 5, 12, 13, 14, 20, 40, 42][st.integers(1, 9)[0]])
@@ -98,7 +100,7 @@ def test_prune_banded_planted_grid(oracle, n, m, f, d, band):
     e.close()
 
 
-@pytest.mark.parametrize("case", range(24))
+@pytest.mark.parametrize("case", range(max(24, _N // 2)))
 def test_prune_banded_random_shapes(oracle, case):
     st = synth.Stream(0x5EED4200 + case)
     dim = int([2, 13, 14, 40][st.integers(1, 4)[0]])
@@ -130,6 +132,40 @@ def test_prune_banded_random_shapes(oracle, case):
     assert np.array_equal(np.isinf(cost), np.isinf(want_cost)), info
     fin = np.isfinite(want_cost)
     assert np.allclose(cost[fin], want_cost[fin], rtol=1e-12, atol=0), info
+    e.close()
+
+
+@pytest.mark.parametrize("seed", range(max(2, _N // 40)))
+@pytest.mark.parametrize("dim,band,nt", [(13, -1, 0), (13, -1, 2), (20, -1, 4), (13, 24, 0)])
+def test_prune_medium_ragged(oracle, dim, band, nt, seed, monkeypatch):
+    # several workgroups and task ranges, lengths from 1 frame to five 64-row (ten 32-row) passes, sources
+    # end-aligned at every offset inside a pass, near copies of every closeness next to unrelated targets:
+    # passes stop at different columns per wave, tasks are dropped after different passes
+    st = synth.Stream(0x5EED4300 + 31 * dim + band + 7919 * seed + nt)
+    n, m = 300, 96
+    hi = 260 if band < 0 else 120
+    src = [st.normal(int(f) * dim).reshape(int(f), dim) * synth.sigma(dim) for f in 1 + st.integers(n, hi)]
+    tgt = [st.normal(int(f) * dim).reshape(int(f), dim) * synth.sigma(dim) for f in 1 + st.integers(m, hi)]
+    for t in range(0, m, 3):
+        s = (t * 7) % n
+        eps = [0.0, 0.01, 0.3, 1.0][(t // 3) % 4]
+        tgt[t] = src[s] + eps * st.normal(src[s].size).reshape(src[s].shape) * synth.sigma(dim)
+    src[211] = src[17].copy()
+    sf, so = pack_segments(src, dim, np.float32)
+    tf, to = pack_segments(tgt, dim, np.float32)
+    if nt:
+        monkeypatch.setenv("SSYM_PRUNE_NT", str(nt))       # pins the pass height (read at every launch)
+    e = Engine(metric="dtw", dtype="f32", band=band)
+    d, q = e.dictionary(sf, so, dim), e.queries(tf, to, dim)
+    idx, cost, _, t1 = _both(e, d, q)
+    idx2, cost2 = e.match(d, q, prune=True)                 # second pruned call: the pass height may have changed
+    assert np.array_equal(idx, idx2) and np.array_equal(cost, cost2)
+    assert t1["pruned"] == 1
+    want_idx, want_cost = oracle.dtw_match_all(sf.astype(np.float64), so, tf.astype(np.float64), to, dim, band=band,
+                                               nthreads=oracle.max_threads())
+    assert np.array_equal(idx, want_idx)
+    fin = np.isfinite(want_cost)
+    assert np.allclose(cost[fin], want_cost[fin], rtol=1e-12, atol=0) and np.isinf(cost[~fin]).all()
     e.close()
 
 
