@@ -47,7 +47,10 @@ struct EmptyDictionary : Error {
 // One GPU context; metric 0 = refcos (the crate's own cosine_sim), 1 = dtw.
 class Context {
   public:
-    explicit Context(int metric = SSYM_METRIC_REFCOS, int device = 0, int band = -1, bool squared = false)
+    // prune: dtw nearest-neighbour searches of 64 targets and more abandon pairs early (same results,
+    // data-dependent time)
+    explicit Context(int metric = SSYM_METRIC_REFCOS, int device = 0, int band = -1, bool squared = false,
+                     bool prune = false)
     {
         ssym_config cfg{};
         cfg.struct_size = sizeof(cfg);
@@ -57,6 +60,7 @@ class Context {
         cfg.band = band;
         cfg.dtw_squared = squared ? 1 : 0;
         cfg.stream = nullptr;
+        cfg.dtw_prune = prune ? 1 : 0;
         int rc = ssym_ctx_create(&cfg, &ctx_);
         if (rc != SSYM_OK)
             throw Error(rc, ssym_last_error(nullptr));

@@ -88,6 +88,10 @@ typedef struct ssym_config {
     int32_t band;          /* dtw: Sakoe-Chiba radius in frames, -1 = none                       */
     int32_t dtw_squared;   /* dtw: 0 = L2 local cost (default), 1 = squared L2                   */
     void *stream;          /* hipStream_t to enqueue on; NULL = the library creates one          */
+    int32_t dtw_prune;     /* dtw: 1 = every batched match of at least 64 targets runs as if          */
+                           /* SSYM_DTW_PRUNE were passed (the entry points without a flags argument,  */
+                           /* ssym_match_batch, included); 0 = only where the flag is given           */
+    int32_t reserved;      /* 0                                                                  */
 } ssym_config;
 
 /* Per-phase device time of the LAST ssym_match_* call on the context, measured with HIP events

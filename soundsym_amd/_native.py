@@ -70,6 +70,8 @@ class Config(ctypes.Structure):
         ("band", ctypes.c_int32),
         ("dtw_squared", ctypes.c_int32),
         ("stream", ctypes.c_void_p),
+        ("dtw_prune", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
     ]
 
 

@@ -67,6 +67,7 @@ int32_t ssym_ctx_create(const ssym_config *cfg, ssym_ctx **out)
     ctx->dtype = cfg->dtype;
     ctx->band = cfg->band;
     ctx->squared = cfg->dtw_squared ? 1 : 0;
+    ctx->prune_default = cfg->dtw_prune != 0;
     ctx->num_cus = prop.multiProcessorCount;
     if (cfg->stream) {
         ctx->stream = (hipStream_t)cfg->stream;
@@ -342,6 +343,8 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
     SSYM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const bool outDev = (flags & SSYM_OUT_DEVICE) != 0;
+    if (ctx->prune_default && phase == 0 && M >= 64)      // (a handful of targets: the extra launches cost more than they save)
+        flags |= SSYM_DTW_PRUNE;
 
     // per-target distance (morph_to, src/sound.rs:440-446)
     const double *distDev = nullptr;

@@ -86,6 +86,7 @@ struct ssym_ctx {
     int dtype = SSYM_DTYPE_F32;
     int band = -1;
     int squared = 0;
+    bool prune_default = false;     // ssym_config.dtw_prune
     hipStream_t stream = nullptr;
     bool owns_stream = false;
     std::string err;

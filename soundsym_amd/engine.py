@@ -70,14 +70,14 @@ class Engine:
     """One ssym_ctx: one GPU, one stream, one metric / dtype configuration."""
 
     def __init__(self, metric: str = "dtw", dtype: str = "f32", device: int = 0, band: int = -1,
-                 squared: bool = False, stream: Optional[int] = None):
+                 squared: bool = False, stream: Optional[int] = None, prune: bool = False):
         self.metric, self.dtype = metric, dtype
         self.np_dtype = {"f64": np.float64, "f32": np.float32}[dtype]
         self.ctx = None
         cfg = nat.Config(ctypes.sizeof(nat.Config), device,
                          {"refcos": nat.METRIC_REFCOS, "dtw": nat.METRIC_DTW}[metric],
                          {"f64": nat.DTYPE_F64, "f32": nat.DTYPE_F32}[dtype], band,
-                         1 if squared else 0, stream)
+                         1 if squared else 0, stream, 1 if prune else 0, 0)
         out = ctypes.c_void_p()
         nat.check(nat.lib().ssym_ctx_create(ctypes.byref(cfg), ctypes.byref(out)), None)
         self.ctx = out.value

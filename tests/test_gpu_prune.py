@@ -225,3 +225,22 @@ def test_prune_after_append_uses_the_new_sources(oracle):
     idx, cost, _, _ = _both(e, d, q)
     assert np.array_equal(idx, g.planted)
     e.close()
+
+
+def test_prune_as_the_context_default_reaches_the_entry_points_without_flags(oracle):
+    g = synth.make_grid(128, 96, 48, 13, 0x5EED0466)
+    sf, so = g.flat("sources")
+    tf, to = g.flat("targets")
+    plain = Engine(metric="dtw", dtype="f32")
+    want_idx, want_cost = plain.match_batch(plain.dictionary(sf, so, 13), tf, to)
+    assert plain.timings()["pruned"] == 0
+    plain.close()
+    e = Engine(metric="dtw", dtype="f32", prune=True)             # ssym_config.dtw_prune
+    d = e.dictionary(sf, so, 13)
+    idx, cost = e.match_batch(d, tf, to)                          # ssym_match_batch has no flags argument
+    assert e.timings()["pruned"] == 1
+    assert np.array_equal(idx, want_idx) and np.array_equal(cost, want_cost)
+    few_idx, few_cost = e.match_batch(d, tf[: 5 * 48 * 13], to[:6])   # a handful of targets: not worth the extra launches
+    assert e.timings()["pruned"] == 0
+    assert np.array_equal(few_idx, want_idx[:5]) and np.array_equal(few_cost, want_cost[:5])
+    e.close()
