@@ -167,13 +167,13 @@ static int32_t ensure_records(ssym_ctx *ctx, const SegmentSet &set, double scale
 template <int NT, bool SQ>
 static void launch_one(hipStream_t st, const SegmentSet &src, const SegmentSet &tgt, int nPasses,
                        int gridBlocks, float outScale, float *handoff, unsigned *taskCtr, float *cmat,
-                       const float *abandon, unsigned long long *colCtr, const uint32_t *candSlot)
+                       const float *abandon, unsigned long long *colCtr, const uint32_t *candSlot,
+                       int spBase, int nSrcPairs, int rowOrigin)
 {
     // sources of at most 16 frames (one tile, one pass): three waves per SIMD, see filter_ring() -- 11 %
     // faster there; at 32 frames the gain was within 3 % and cost spills
     constexpr int OCC = NT == 1 ? 3 : 2;
     gridBlocks = gridBlocks / 2 * OCC;
-    const int nSrcPairs = (int)src.n_pad / 2;
     const int nTgtGroups = (int)tgt.n_pad / 32;
     const int nTasks = nSrcPairs * nTgtGroups;            // one wave's 64 pairs each
     const int blocksWanted = (nTasks + kFilterWavesPerBlock - 1) / kFilterWavesPerBlock;
@@ -181,19 +181,19 @@ static void launch_one(hipStream_t st, const SegmentSet &src, const SegmentSet &
     // tasks per grab: several SHORT tasks at a time so that the L2 atomics stay invisible (at 16 frames a
     // task is ~1 us of work), one at a time once a task is long enough to matter for the tail; always
     // at least 16 grabs per wave
-    const long cellsPerTask = (long)src.frames_pad * std::max<uint32_t>(tgt.max_frames, 1);
+    const long cellsPerTask = (long)(16 * NT * nPasses) * std::max<uint32_t>(tgt.max_frames, 1);
     int taskChunk = (int)std::max(1L, std::min(8L, 8192 / std::max(1L, cellsPerTask)));
     taskChunk = std::max(1, std::min(taskChunk, nTasks / (grid * kFilterWavesPerBlock * 16)));
     if (abandon)
         dtw_filter_kernel<NT, SQ, OCC, true><<<dim3(grid), 64 * kFilterWavesPerBlock, 0, st>>>(
             (const _Float16 *)src.rec, (const _Float16 *)tgt.rec, src.len, tgt.len, (int)src.frames_pad, nPasses,
             (int)tgt.frames_pad, (int)tgt.n_pad, nSrcPairs, nTasks, taskChunk, outScale, handoff, taskCtr, cmat,
-            abandon, colCtr, candSlot);
+            abandon, colCtr, candSlot, rowOrigin, spBase);
     else
         dtw_filter_kernel<NT, SQ, OCC, false><<<dim3(grid), 64 * kFilterWavesPerBlock, 0, st>>>(
             (const _Float16 *)src.rec, (const _Float16 *)tgt.rec, src.len, tgt.len, (int)src.frames_pad, nPasses,
             (int)tgt.frames_pad, (int)tgt.n_pad, nSrcPairs, nTasks, taskChunk, outScale, handoff, taskCtr, cmat,
-            nullptr, nullptr, nullptr);
+            nullptr, nullptr, nullptr, rowOrigin, spBase);
 }
 
 template <int NTB, int WB, int OCC, bool SQ, int LASTN, bool PRUNE>
@@ -309,6 +309,7 @@ int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
     const char *pin = abandon ? getenv("SSYM_PRUNE_NT") : nullptr;
     const int pinned = pin ? atoi(pin) : 0;
     const int pruneNt = pinned == 2 || pinned == 4 ? pinned : (ctx->prune_swept < 0.25f ? 2 : 4);
+    const FilterShape setShape = shape;
     if (abandon && shape.nt == 4 && pruneNt == 2)
         shape = FilterShape{2, shape.rb * 2};
     const double scale = common_scale(src, tgt);
@@ -321,30 +322,80 @@ int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
     // persistent grid: 2 workgroups of 4 waves per CU (2 waves per SIMD), a multiple of 8 so that
     // task & 7 is the XCD group; one hand-off row of [target frames][64] floats per wave
     const int gridBlocks = std::max(8, ctx->num_cus * 2 / 8 * 8);
-    // + 8 task counters behind the hand-off rows
+    // + 4 x 8 task counters behind the hand-off rows (one set per launch below)
     // (sized for the three-workgroups-per-CU launch of the one-tile kernel too)
     const size_t handBytes = (size_t)(gridBlocks / 2 * 3) * kFilterWavesPerBlock * ((tgt.frames_pad + 3) / 4) * 256 * sizeof(float);
-    rc = ensure(ctx, ctx->handoff, handBytes + 8 * kTaskCtrStride * sizeof(unsigned));
+    const size_t ctrBytes = 8 * kTaskCtrStride * sizeof(unsigned);
+    rc = ensure(ctx, ctx->handoff, handBytes + 4 * ctrBytes);
     if (rc != SSYM_OK)
         return rc;
     unsigned *taskCtr = (unsigned *)((char *)ctx->handoff.ptr + handBytes);
-    SSYM_HIP_CHECK(ctx, hipMemsetAsync(taskCtr, 0, 8 * kTaskCtrStride * sizeof(unsigned), ctx->stream));
+    SSYM_HIP_CHECK(ctx, hipMemsetAsync(taskCtr, 0, 4 * ctrBytes, ctx->stream));
     hipStream_t st = ctx->stream;
     const bool sq = ctx->squared != 0;
     const float outScale = (float)(sq ? 1.0 / (scale * scale) : 1.0 / scale);
     float *hand = (float *)ctx->handoff.ptr;
-#define SSYM_CASE(NT_)                                                                          \
-    case NT_:                                                                                   \
-        if (sq) launch_one<NT_, true>(st, src, tgt, shape.rb, gridBlocks, outScale, hand, taskCtr, cmat, abandon, colCtr, candSlot);  \
-        else launch_one<NT_, false>(st, src, tgt, shape.rb, gridBlocks, outScale, hand, taskCtr, cmat, abandon, colCtr, candSlot);    \
-        break;
-    switch (shape.nt) {
-        SSYM_CASE(1) SSYM_CASE(2) SSYM_CASE(3) SSYM_CASE(4)
-    default:
-        ctx->err = "dtw filter: unsupported shape";
-        return SSYM_E_UNSUPPORTED;
+
+    // Record slots are ordered by segment length, so source pairs fall into contiguous CLASSES by the
+    // 16-row tiles their longer member needs.  Pairs that fit one, two or three tiles run the single-pass
+    // variant with exactly that many (on the last rows of their end-aligned slots) -- a dictionary of
+    // 8...40-frame segments otherwise paid 48 rows for every pair --, the rest the set's own shape,
+    // whose leading all-padding passes are skipped per task.  One launch per non-empty class.
+    const int nPairs = (int)src.n_pad / 2;
+    auto pairLen = [&](int sp) -> uint32_t {      // longer member of source pair sp; slots [0, n) are real, ascending
+        auto len = [&](uint32_t p) -> uint32_t {
+            if (p >= src.n)
+                return 0u;
+            const uint32_t s = src.h_perm[p];
+            return (uint32_t)(src.h_off[s + 1] - src.h_off[s]);
+        };
+        return std::max(len(2u * sp), len(2u * sp + 1u));
+    };
+    const int nRealPairs = (int)((src.n + 1) / 2);  // pairs behind them hold padding only: they ride with the last class
+    auto firstAbove = [&](uint32_t frames) {        // first real pair whose longer member exceeds `frames`
+        int lo = 0, hi = nRealPairs;
+        while (lo < hi) {
+            const int mid = (lo + hi) / 2;
+            if (pairLen(mid) > frames)
+                hi = mid;
+            else
+                lo = mid + 1;
+        }
+        return lo;
+    };
+    const int topTiles = setShape.nt;               // tiles of the set's own shape (4 = multi-pass)
+    static const bool oneLaunch = getenv("SSYM_FILTER_ONE_LAUNCH") != nullptr;     // measurements: the set's shape for every pair
+    int bound[4] = {0, 0, 0, 0};                    // bound[c]: first pair that needs more than c tiles
+    for (int c = 1; c < topTiles; ++c)
+        bound[c] = oneLaunch ? 0 : firstAbove(16u * c);
+#define SSYM_LAUNCH(NT_, PASSES_, ORIGIN_, LO_, HI_, K_)                                                          \
+    if ((HI_) > (LO_)) {                                                                                          \
+        if (sq) launch_one<NT_, true>(st, src, tgt, PASSES_, gridBlocks, outScale, hand, taskCtr + (K_) * 8 * kTaskCtrStride, \
+                                      cmat, abandon, colCtr, candSlot, LO_, (HI_) - (LO_), ORIGIN_);              \
+        else launch_one<NT_, false>(st, src, tgt, PASSES_, gridBlocks, outScale, hand, taskCtr + (K_) * 8 * kTaskCtrStride, \
+                                    cmat, abandon, colCtr, candSlot, LO_, (HI_) - (LO_), ORIGIN_);                \
     }
-#undef SSYM_CASE
+    const int rowsPad = (int)src.frames_pad;
+    if (topTiles == 4) {
+        SSYM_LAUNCH(1, 1, rowsPad - 16, bound[0], bound[1], 0)
+        SSYM_LAUNCH(2, 1, rowsPad - 32, bound[1], bound[2], 1)
+        SSYM_LAUNCH(3, 1, rowsPad - 48, bound[2], bound[3], 2)
+        if (shape.nt == 2) {
+            SSYM_LAUNCH(2, shape.rb, 0, bound[3], nPairs, 3)
+        } else {
+            SSYM_LAUNCH(4, shape.rb, 0, bound[3], nPairs, 3)
+        }
+    } else if (topTiles == 3) {
+        SSYM_LAUNCH(1, 1, rowsPad - 16, bound[0], bound[1], 0)
+        SSYM_LAUNCH(2, 1, rowsPad - 32, bound[1], bound[2], 1)
+        SSYM_LAUNCH(3, 1, 0, bound[2], nPairs, 2)
+    } else if (topTiles == 2) {
+        SSYM_LAUNCH(1, 1, rowsPad - 16, bound[0], bound[1], 0)
+        SSYM_LAUNCH(2, 1, 0, bound[1], nPairs, 1)
+    } else {
+        SSYM_LAUNCH(1, 1, 0, 0, nPairs, 0)
+    }
+#undef SSYM_LAUNCH
     SSYM_HIP_CHECK(ctx, hipGetLastError());
     return SSYM_OK;
 }

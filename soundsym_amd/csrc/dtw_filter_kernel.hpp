@@ -166,7 +166,10 @@ constexpr int wait_vmcnt(int n) { return 0x0F70 | (n & 15) | ((n >> 4) << 14); }
 // s_waitcnt immediates (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14])
 
 // Persistent kernel: every wave keeps taking (source pair, target group) tasks of 64 pairs until
-// none is left (taskCtr: 8 counters, zeroed by the host before the launch).
+// none is left (taskCtr: 8 counters, zeroed by the host before the launch).  A launch covers the
+// source pairs [spBase, spBase + nSrcPairs) and the rows [rowOrigin, rowOrigin + nPasses * 16 * NT) of
+// their slots: record slots are ordered by segment length, so the host gives every class of source
+// lengths the variant with just enough 16-row tiles (dtw_filter.hip).
 //
 // PRUNE (early abandoning, SSYM_DTW_PRUNE): abandon[t] is a per-target value, in the accumulator's
 // units, that no pair of interest can exceed (prune.hip derives it from the exact cost of one
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_ker
     int tgtFramesPad, int mPad, int nSrcPairs, int nTasks, int taskChunk, float outScale,
     float *__restrict__ handoff, unsigned *__restrict__ taskCtr, float *__restrict__ cmat,
     const float *__restrict__ abandon = nullptr, unsigned long long *__restrict__ colCtr = nullptr,
-    const uint32_t *__restrict__ candSlot = nullptr)
+    const uint32_t *__restrict__ candSlot = nullptr, int rowOrigin = 0, int spBase = 0)
 {
     constexpr int REC = kFilterRecHalfs;
     constexpr int BR = NT * 16;            // rows per pass
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_ker
        for (unsigned gi = got; gi < gotEnd; ++gi) {
         const unsigned lin = rangeLo + (rangeLen - 1u - gi);
         const int tg = (int)(lin / (unsigned)nSrcPairs);
-        const int sp = (int)(lin % (unsigned)nSrcPairs);    // source pair of this wave
+        const int sp = spBase + (int)(lin % (unsigned)nSrcPairs);    // source pair of this wave
 
         const int fa = srcLen[2 * sp + half];
         const int fb_m1 = tgtLen[32 * tg + col] - 1;
@@ -254,7 +257,8 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_ker
         }
         nCols = __builtin_amdgcn_readfirstlane(nCols);
         r0min = __builtin_amdgcn_readfirstlane(r0min);
-        const int firstPass = min(max(r0min - 1, 0) / BR, nPasses - 1);
+        // (a source that begins exactly on a pass boundary needs nothing of the pass above: diagCol0 starts it)
+        const int firstPass = min(max(r0min - rowOrigin, 0) / BR, nPasses - 1);
 
         float res = INF;
         float thr = INF;                       // PRUNE: threshold of the lane's target
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_ker
         const char *const tgtGroup = reinterpret_cast<const char *>(tgtRec) + (size_t)tg * tgtFramesPad * (kTgtFrameHalfs * 2);
 
         for (int pass = nCols > 0 ? firstPass : nPasses; pass < nPasses && !dropped; ++pass) {
-            const int rowBase = pass * BR;
+            const int rowBase = rowOrigin + pass * BR;
 #ifdef SSYM_ABL_NOHAND
             const bool haveTop = false;
 #else

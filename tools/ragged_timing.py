@@ -8,7 +8,7 @@ from soundsym_amd.engine import pack_segments
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 e = Engine(metric="dtw", dtype="f32")
-for lo, hi in ((128, 129), (16, 129), (16, 257), (4, 65)):
+for lo, hi in ((128, 129), (16, 129), (16, 257), (4, 65), (8, 41), (4, 25)):
     src, tgt = synth.make_ragged(n, n, lo, hi, 13, 0x5EED0A00 + hi)
     sf, so = pack_segments(src, 13, np.float32)
     tf, to = pack_segments(tgt, 13, np.float32)
