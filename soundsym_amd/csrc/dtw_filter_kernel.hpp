@@ -238,13 +238,23 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_ker
         if (got >= rangeLen)
             break;
         const unsigned gotEnd = min(got + (unsigned)taskChunk, rangeLen);
+        // the lengths of the chunk's next task are fetched while the current one runs: for short tasks the
+        // two dependent round trips of a task's start (lengths, then operands) were as long as its columns
+        int preFa = 0, preFb = 0;
+        bool havePre = false;                   // wave-uniform
        for (unsigned gi = got; gi < gotEnd; ++gi) {
         const unsigned lin = rangeLo + (rangeLen - 1u - gi);
         const int tg = (int)(lin / (unsigned)nSrcPairs);
         const int sp = spBase + (int)(lin % (unsigned)nSrcPairs);    // source pair of this wave
 
-        const int fa = srcLen[2 * sp + half];
-        const int fb_m1 = tgtLen[32 * tg + col] - 1;
+        const int fa = havePre ? preFa : srcLen[2 * sp + half];
+        const int fb_m1 = (havePre ? preFb : tgtLen[32 * tg + col]) - 1;
+        havePre = gi + 1 < gotEnd;
+        if (havePre) {
+            const unsigned linN = lin - 1u;
+            preFa = srcLen[2 * (spBase + (int)(linN % (unsigned)nSrcPairs)) + half];
+            preFb = tgtLen[32 * (int)(linN / (unsigned)nSrcPairs) + col];
+        }
         const int r0 = srcRows - fa;   // first real row: sources are END-ALIGNED in their row slots
 
         // wave-uniform bounds: columns up to the longest target of the group; passes that hold
