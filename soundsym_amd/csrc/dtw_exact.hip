@@ -188,7 +188,18 @@ __global__ __launch_bounds__(64) void dtw_exact_kernel(
 //     every two values -- and the loads of step tau + 1 are in flight while step tau computes;
 //   * (0 - 0)^2 = +0.0 added to a non-negative sum leaves it unchanged bit for bit, so the padding
 //     does not alter the result.
-template <int DIMR, int PARTS = 1>
+//   * BT = float when the context's features were f32 (they were widened exactly, so narrowing the staged
+//     target frames back is exact too): half the LDS per pair means twice the resident waves, and the
+//     short candidate lists this kernel usually sees are bound by latency, not by issue.
+template <int DIMR>
+constexpr int exact_ld(bool f32)
+{
+    // row stride in elements: 16-byte aligned rows whose 128-bit reads by consecutive lanes tile the banks
+    return f32 ? ((DIMR + 3) / 4 * 4) + ((((DIMR + 3) / 4 * 4) % 8 == 4) ? 0 : 4)      // = 4 (mod 8) floats
+               : ((DIMR % 4 == 2) ? DIMR : DIMR + 2);                                     // = 2 (mod 4) doubles
+}
+
+template <int DIMR, int PARTS = 1, typename BT = double>
 __global__ __launch_bounds__(64) void dtw_exact_reg_kernel(
     const double *__restrict__ srcRaw, const uint64_t *__restrict__ srcOff,
     const double *__restrict__ tgtRaw, const uint64_t *__restrict__ tgtOff, uint32_t nSrc,
@@ -197,10 +208,12 @@ __global__ __launch_bounds__(64) void dtw_exact_reg_kernel(
     double *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    constexpr int LD = (DIMR % 4 == 2) ? DIMR : DIMR + 2;     // = 2 mod 4 doubles: see above
+    constexpr bool BF32 = sizeof(BT) == 4;
+    constexpr int LD = exact_ld<DIMR>(BF32);
+    constexpr int VPR = 16 / (int)sizeof(BT);    // values per 128-bit LDS read
     double *bound0 = smem;                       // [fbCap]
     double *bound1 = smem + fbCap;               // [fbCap]
-    double *ldsB = smem + 2 * (size_t)fbCap;     // [fbCap][LD], fbCap is even so rows stay 16-byte aligned
+    BT *ldsB = reinterpret_cast<BT *>(smem + 2 * (size_t)fbCap);     // [rows][LD], fbCap is even so rows stay 16-byte aligned
     const double INF = __builtin_inf();
     const int lane = threadIdx.x;
 
@@ -234,7 +247,7 @@ __global__ __launch_bounds__(64) void dtw_exact_reg_kernel(
         if (band < 0)
             for (int i = lane; i < Fb * DIMR; i += 64) {
                 const int fr = i / DIMR, e = i % DIMR;
-                ldsB[(size_t)fr * LD + e] = e < (int)dim ? b0[(size_t)fr * dim + e] : 0.0;
+                ldsB[(size_t)fr * LD + e] = (BT)(e < (int)dim ? b0[(size_t)fr * dim + e] : 0.0);
             }
         double result = INF;
         int chunk = 0;
@@ -263,7 +276,7 @@ __global__ __launch_bounds__(64) void dtw_exact_reg_kernel(
                 __syncthreads();   // the previous chunk's window is no longer read
                 for (int i = lane; i < (whi - wlo + 1) * DIMR; i += 64) {
                     const int fr = i / DIMR, e = i % DIMR;
-                    ldsB[(size_t)fr * LD + e] = e < (int)dim ? b0[(size_t)(wlo + fr) * dim + e] : 0.0;
+                    ldsB[(size_t)fr * LD + e] = (BT)(e < (int)dim ? b0[(size_t)(wlo + fr) * dim + e] : 0.0);
                 }
             }
             for (int j = lane; j < Fb; j += 64)
@@ -273,27 +286,28 @@ __global__ __launch_bounds__(64) void dtw_exact_reg_kernel(
             double mine = INF;      // D(r, j-1)
             double diagReg = INF;   // D(r-1, j-1)
             const int tauEnd = jhi + rowsHere;     // exclusive: lane l works on column tau - l
-            typedef double d2 __attribute__((ext_vector_type(2)));
+            typedef BT d2 __attribute__((ext_vector_type(VPR)));        // one 128-bit read
             constexpr int PW = DIMR / PARTS;              // values fetched at a time
-            d2 bv[PW / 2], bn[PARTS == 1 ? PW / 2 : 1];
+            constexpr int NV = (PW + VPR - 1) / VPR;      // reads per fetch (a row's padding covers the overhang)
+            d2 bv[NV], bn[PARTS == 1 ? NV : 1];
             if (PARTS == 1) {
                 const int jc = min(max(jlo - lane, wlo), whi) - wlo;
                 const d2 *bp = reinterpret_cast<const d2 *>(ldsB + (size_t)jc * LD);
 #pragma unroll
-                for (int e = 0; e < PW / 2; ++e)
+                for (int e = 0; e < NV; ++e)
                     bn[e] = bp[e];
             }
             for (int tau = jlo; tau < tauEnd; ++tau) {
                 const int j = tau - lane;
                 if (PARTS == 1) {
 #pragma unroll
-                    for (int e = 0; e < PW / 2; ++e)
+                    for (int e = 0; e < NV; ++e)
                         bv[e] = bn[e];
                     // next step's frame (clamped to a valid row; unused when out of range)
                     const int jc = min(max(j + 1, wlo), whi) - wlo;
                     const d2 *bp = reinterpret_cast<const d2 *>(ldsB + (size_t)jc * LD);
 #pragma unroll
-                    for (int e = 0; e < PW / 2; ++e)
+                    for (int e = 0; e < NV; ++e)
                         bn[e] = bp[e];
                 }
                 double fromAbove = shfl_up1(mine);        // D(r-1, j) for lanes >= 1
@@ -312,7 +326,7 @@ __global__ __launch_bounds__(64) void dtw_exact_reg_kernel(
                 if (PARTS == 1) {
 #pragma unroll
                     for (int e = 0; e < DIMR; ++e) {
-                        const double df = __dsub_rn(ar[e], bv[e >> 1][e & 1]);
+                        const double df = __dsub_rn(ar[e], (double)bv[e / VPR][e % VPR]);
                         acc = __dadd_rn(acc, __dmul_rn(df, df));
                     }
                 } else {
@@ -322,11 +336,11 @@ __global__ __launch_bounds__(64) void dtw_exact_reg_kernel(
                     for (int h = 0; h < PARTS; ++h) {
                         const d2 *bp = reinterpret_cast<const d2 *>(ldsB + (size_t)jc * LD + h * PW);
 #pragma unroll
-                        for (int e = 0; e < PW / 2; ++e)
+                        for (int e = 0; e < NV; ++e)
                             bv[e] = bp[e];
 #pragma unroll
                         for (int e = 0; e < PW; ++e) {
-                            const double df = __dsub_rn(ar[h * PW + e], bv[e >> 1][e & 1]);
+                            const double df = __dsub_rn(ar[h * PW + e], (double)bv[e / VPR][e % VPR]);
                             acc = __dadd_rn(acc, __dmul_rn(df, df));
                         }
                     }
@@ -381,12 +395,21 @@ int32_t launch_dtw_exact(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet 
     // frames of up to 48 values: source frame in registers, target frames zero-padded in LDS
     const uint32_t fbEven = (fbCap + 1) & ~1u;
     const int dimr = dim <= 12 ? 12 : dim <= 14 ? 14 : dim <= 16 ? 16 : dim <= 40 ? 40 : dim <= 48 ? 48 : dim <= 64 ? 64 : 0;
-    const int ldr = (dimr % 4 == 2) ? dimr : dimr + 2;
+    const bool bf32 = ctx->dtype == SSYM_DTYPE_F32;     // every feature buffer of the context was f32: exact in float
+    const int up4 = (dimr + 3) / 4 * 4;
+    const int ldr = bf32 ? up4 + (up4 % 8 == 4 ? 0 : 4) : ((dimr % 4 == 2) ? dimr : dimr + 2);   // exact_ld<>
     // staged target rows: all of them, or (banded) the widest window a 64-row chunk can reach
     const uint32_t winRows = ctx->band >= 0 ? std::min<uint32_t>(fbEven, 64 + 2 * (uint32_t)ctx->band + 2) : fbEven;
-    const size_t regLds = 2 * (size_t)fbEven * sizeof(double) + (size_t)winRows * ldr * sizeof(double);
+    const size_t regLds = 2 * (size_t)fbEven * sizeof(double) + (size_t)winRows * ldr * (bf32 ? sizeof(float) : sizeof(double));
     if (dimr && regLds <= (size_t)(dimr == 64 ? 150 : 64) * 1024) {
 #define SSYM_EXACT_REG(...)                                                                                    \
+    do {                                                                                                       \
+        if (bf32)                                                                                              \
+            SSYM_EXACT_REG2(__VA_ARGS__, float);                                                               \
+        else                                                                                                   \
+            SSYM_EXACT_REG2(__VA_ARGS__, double);                                                              \
+    } while (0)
+#define SSYM_EXACT_REG2(...)                                                                                   \
     do {                                                                                                       \
         auto kern = dtw_exact_reg_kernel<__VA_ARGS__>;                                                         \
         if (regLds > 64 * 1024)                                                                                \
@@ -396,14 +419,15 @@ int32_t launch_dtw_exact(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet 
                                        ctx->squared, pairs, count_dev, max_pairs, fbEven, out);                \
     } while (0)
         switch (dimr) {
-        case 12: SSYM_EXACT_REG(12); break;
-        case 14: SSYM_EXACT_REG(14); break;
-        case 16: SSYM_EXACT_REG(16); break;
-        case 40: SSYM_EXACT_REG(40); break;
-        case 48: SSYM_EXACT_REG(48); break;
+        case 12: SSYM_EXACT_REG(12, 1); break;
+        case 14: SSYM_EXACT_REG(14, 1); break;
+        case 16: SSYM_EXACT_REG(16, 1); break;
+        case 40: SSYM_EXACT_REG(40, 1); break;
+        case 48: SSYM_EXACT_REG(48, 1); break;
         default: SSYM_EXACT_REG(64, 2); break;      // 49..64 values: the frame is fetched in two halves
         }
 #undef SSYM_EXACT_REG
+#undef SSYM_EXACT_REG2
         SSYM_HIP_CHECK(ctx, hipGetLastError());
         return SSYM_OK;
     }
