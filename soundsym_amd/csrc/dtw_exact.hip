@@ -297,6 +297,7 @@ __global__ __launch_bounds__(64) void dtw_exact_reg_kernel(
                 for (int e = 0; e < NV; ++e)
                     bn[e] = bp[e];
             }
+#pragma unroll 2
             for (int tau = jlo; tau < tauEnd; ++tau) {
                 const int j = tau - lane;
                 if (PARTS == 1) {
