@@ -205,7 +205,7 @@ __global__ __launch_bounds__(64) void dtw_exact_reg_kernel(
     const double *__restrict__ tgtRaw, const uint64_t *__restrict__ tgtOff, uint32_t nSrc,
     uint32_t nTgt, uint32_t dim, int band, int squared, const uint2 *__restrict__ pairs,
     const uint32_t *__restrict__ countDev, uint32_t maxPairs, uint32_t fbCap,
-    double *__restrict__ out)
+    double *__restrict__ out, uint64_t totalLo = 0, uint64_t totalHi = ~0ull)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr bool BF32 = sizeof(BT) == 4;
@@ -224,6 +224,8 @@ __global__ __launch_bounds__(64) void dtw_exact_reg_kernel(
     } else {
         total = (uint64_t)nSrc * nTgt;
     }
+    if (total < totalLo || total > totalHi)      // the list length decides between this kernel and its sibling (see the launcher)
+        return;
     for (uint64_t k = blockIdx.x; k < total; k += gridDim.x) {
         uint32_t s, t;
         if (pairs) {
@@ -297,7 +299,6 @@ __global__ __launch_bounds__(64) void dtw_exact_reg_kernel(
                 for (int e = 0; e < NV; ++e)
                     bn[e] = bp[e];
             }
-#pragma unroll 2
             for (int tau = jlo; tau < tauEnd; ++tau) {
                 const int j = tau - lane;
                 if (PARTS == 1) {
@@ -371,6 +372,195 @@ __global__ __launch_bounds__(64) void dtw_exact_reg_kernel(
     }
 }
 
+// Row chunks PIPELINED over the waves of a workgroup (sources of 65...512 frames): wave w owns chunk w
+// and starts as soon as the wave above has finished the first columns of its bottom row, instead of one
+// wave walking the chunks one after the other -- the steps in sequence drop from chunks x (Fb + 64) to
+// about Fb + 80 x chunks, which is what a short candidate list (early abandoning's M pairs, list 2) is bound
+// by.  Same arithmetic, same order per cell.  Hand-over through LDS: the producer's lane 63 writes
+// D(bottom row, j) and then publishes "columns < p are final" (prog[w]); the consumer reads prog[w - 1]
+// only when it has caught up and then waits for 16 columns more than it needs, so it polls once per 16
+// steps.  Nobody waits for a wave BELOW it, wave 0 waits for nobody, and every wave publishes "all
+// final" when it leaves its chunk, so the chain always drains; the spin is bounded all the same, and a
+// wave that gives up reports NaN (never a candidate) instead of hanging the GPU.
+constexpr int kPipeLag = 16;
+constexpr int kPipeDone = 0x7fffffff;
+
+template <int DIMR, typename BT>
+__global__ __launch_bounds__(512) void dtw_exact_pipe_kernel(
+    const double *__restrict__ srcRaw, const uint64_t *__restrict__ srcOff,
+    const double *__restrict__ tgtRaw, const uint64_t *__restrict__ tgtOff, uint32_t nSrc,
+    uint32_t nTgt, uint32_t dim, int band, int squared, const uint2 *__restrict__ pairs,
+    const uint32_t *__restrict__ countDev, uint32_t maxPairs, uint32_t fbCap,
+    double *__restrict__ out, uint64_t totalLo = 0, uint64_t totalHi = ~0ull)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr bool BF32 = sizeof(BT) == 4;
+    constexpr int LD = exact_ld<DIMR>(BF32);
+    constexpr int VPR = 16 / (int)sizeof(BT);
+    constexpr int NV = (DIMR + VPR - 1) / VPR;
+    typedef BT bvec __attribute__((ext_vector_type(VPR)));
+    const int W = (int)(blockDim.x >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    double *bound = smem;                                                  // [W][fbCap]
+    BT *ldsB = reinterpret_cast<BT *>(smem + (size_t)W * fbCap);           // [fbCap][LD]  (fbCap even: 16-byte aligned)
+    volatile int *prog = reinterpret_cast<volatile int *>(ldsB + (size_t)fbCap * LD);      // [W], then the pair's failure flag
+    volatile int *failed = prog + W;
+    const double INF = __builtin_inf();
+
+    uint64_t total;
+    if (pairs) {
+        uint32_t c = *countDev;
+        total = c < maxPairs ? c : maxPairs;
+    } else {
+        total = (uint64_t)nSrc * nTgt;
+    }
+    if (total < totalLo || total > totalHi)      // the list length decides between this kernel and its sibling (see the launcher)
+        return;
+    for (uint64_t k = blockIdx.x; k < total; k += gridDim.x) {
+        uint32_t s, t;
+        if (pairs) {
+            uint2 p = pairs[k];
+            s = p.x;
+            t = p.y;
+        } else {
+            s = (uint32_t)(k / nTgt);
+            t = (uint32_t)(k % nTgt);
+        }
+        const int Fa = (int)(srcOff[s + 1] - srcOff[s]);
+        const int Fb = (int)(tgtOff[t + 1] - tgtOff[t]);
+        const double *a0 = srcRaw + srcOff[s] * dim;
+        const double *b0 = tgtRaw + tgtOff[t] * dim;
+        if (Fa == 0 || Fb == 0) {                    // block-uniform
+            if (threadIdx.x == 0)
+                out[k] = INF;
+            continue;
+        }
+        __syncthreads();                             // the previous pair's frames and rows are no longer read
+        for (int i = threadIdx.x; i < Fb * DIMR; i += blockDim.x) {
+            const int fr = i / DIMR, e = i % DIMR;
+            ldsB[(size_t)fr * LD + e] = (BT)(e < (int)dim ? b0[(size_t)fr * dim + e] : 0.0);
+        }
+        for (int i = threadIdx.x; i < W * (int)fbCap; i += blockDim.x)
+            bound[i] = INF;
+        if (lane == 0)
+            prog[wave] = 0;
+        if (threadIdx.x == 0)
+            *failed = 0;
+        __syncthreads();
+
+        const int c0 = wave * 64;
+        if (c0 < Fa) {                               // this wave has a chunk (the host sized W for the longest source)
+            const int r = c0 + lane;
+            const bool rowValid = r < Fa;
+            const int rowsHere = min(64, Fa - c0);
+            double ar[DIMR];
+            {
+                const double *arow = a0 + (size_t)(rowValid ? r : c0) * dim;
+#pragma unroll
+                for (int e = 0; e < DIMR; ++e)
+                    ar[e] = e < (int)dim ? arow[e] : 0.0;
+            }
+            const double *boundPrev = bound + (size_t)(wave > 0 ? wave - 1 : 0) * fbCap;
+            double *boundCur = bound + (size_t)wave * fbCap;
+            int jlo = 0, jhi = Fb - 1;
+            if (band >= 0) {
+                jlo = max(0, c0 - band);
+                jhi = min(Fb - 1, c0 + rowsHere - 1 + band);
+            }
+            double mine = INF, diagReg = INF, result = INF;
+            const int tauEnd = jhi + rowsHere;       // exclusive: lane l works on column tau - l
+            bvec bv[NV], bn[NV];
+            {
+                const int jc = min(max(jlo - lane, 0), Fb - 1);
+                const bvec *bp = reinterpret_cast<const bvec *>(ldsB + (size_t)jc * LD);
+#pragma unroll
+                for (int e = 0; e < NV; ++e)
+                    bn[e] = bp[e];
+            }
+            int known = wave > 0 ? 0 : kPipeDone;    // columns of the row above known to be final
+            bool gaveUp = false;
+            for (int tau = jlo; tau < tauEnd; ++tau) {
+                const int j = tau - lane;
+                const int need = min(tau + 1, Fb);   // lane 0 reads boundPrev[tau] and boundPrev[tau - 1]
+                if (known < need) {                  // wave-uniform
+                    const int want = min(need + kPipeLag, Fb);
+                    int spins = 0;
+                    for (;;) {
+                        known = __builtin_amdgcn_readfirstlane(prog[wave - 1]);
+                        if (known >= want)
+                            break;
+                        if (++spins > (1 << 22)) {
+                            gaveUp = true;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    if (gaveUp)
+                        break;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      // the row above is read after its progress
+                }
+#pragma unroll
+                for (int e = 0; e < NV; ++e)
+                    bv[e] = bn[e];
+                {
+                    const int jc = min(max(j + 1, 0), Fb - 1);
+                    const bvec *bp = reinterpret_cast<const bvec *>(ldsB + (size_t)jc * LD);
+#pragma unroll
+                    for (int e = 0; e < NV; ++e)
+                        bn[e] = bp[e];
+                }
+                double fromAbove = shfl_up1(mine);        // D(r-1, j) for lanes >= 1
+                double diagv = diagReg;
+                if (lane == 0) {
+                    if (c0 == 0) {
+                        fromAbove = INF;
+                        diagv = (j == 0) ? 0.0 : INF;     // virtual D(-1,-1) = 0
+                    } else {
+                        fromAbove = (j >= 0 && j < Fb) ? boundPrev[j] : INF;
+                        diagv = (j >= 1 && j <= Fb) ? boundPrev[j - 1] : INF;
+                    }
+                }
+                double acc = 0.0;
+#pragma unroll
+                for (int e = 0; e < DIMR; ++e) {
+                    const double df = __dsub_rn(ar[e], (double)bv[e / VPR][e % VPR]);
+                    acc = __dadd_rn(acc, __dmul_rn(df, df));
+                }
+                const double c = squared ? acc : sqrt(acc);
+                const bool active = rowValid && j >= 0 && j < Fb;
+                if (active) {
+                    double cur = INF;
+                    const int dij = r - j;
+                    if (band < 0 || (dij <= band && -dij <= band)) {
+                        double best = fromAbove;              // D(i-1, j)
+                        if (mine < best) best = mine;         // D(i,   j-1)
+                        if (diagv < best) best = diagv;       // D(i-1, j-1)
+                        cur = __dadd_rn(c, best);
+                    }
+                    if (lane == 63)
+                        boundCur[j] = cur;
+                    if (r == Fa - 1 && j == Fb - 1)
+                        result = cur;
+                    mine = cur;
+                }
+                diagReg = fromAbove;
+                // lane 63 has just finished column tau - 63 (columns left of the band stay +inf and count as final)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // ... and its value is stored before that is said
+                if (lane == 63)
+                    prog[wave] = tau - 62;
+            }
+            if (gaveUp && lane == 0)
+                *failed = 1;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 63)
+                prog[wave] = kPipeDone;              // also when this wave gave up: the waves below must not wait for it
+            if ((Fa - 1) / 64 == wave && (Fa - 1) % 64 == lane)      // (the last chunk ends after every chunk above it)
+                out[k] = (gaveUp || *failed) ? __builtin_nan("") : result;
+        }
+    }
+}
+
 int32_t launch_dtw_exact(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt,
                          const uint2 *pairs, const uint32_t *count_dev, uint32_t max_pairs,
                          double *out)
@@ -402,6 +592,53 @@ int32_t launch_dtw_exact(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet 
     // staged target rows: all of them, or (banded) the widest window a 64-row chunk can reach
     const uint32_t winRows = ctx->band >= 0 ? std::min<uint32_t>(fbEven, 64 + 2 * (uint32_t)ctx->band + 2) : fbEven;
     const size_t regLds = 2 * (size_t)fbEven * sizeof(double) + (size_t)winRows * ldr * (bf32 ? sizeof(float) : sizeof(double));
+    uint64_t regLo = 0;
+    // sources of 65...512 frames: row chunks pipelined over the waves of a workgroup (dtw_exact_pipe_kernel)
+    const uint32_t pipeW = (src.max_frames + 63) / 64;
+    const int ldp = ldr;
+    const size_t pipeLds = (size_t)pipeW * fbEven * sizeof(double) + (size_t)fbEven * ldp * (bf32 ? sizeof(float) : sizeof(double)) +
+                           (pipeW + 1) * sizeof(int);
+    // It pays while the list is short enough to be bound by the length of a pair's wavefront rather than by
+    // issue (measured: 2x at 1024 pairs of 512 frames, 1.4x at 2048 of 256, even at 4096 of 128), and it loses
+    // once the chip is full, because a waiting wave holds its slot -- and inside a band, where a chunk
+    // needs two thirds of the chunk above before it can start.  The list length lives on the device, so
+    // both kernels are launched and the length decides which of them works.
+    static const bool pipeOff = getenv("SSYM_EXACT_PIPE") && atoi(getenv("SSYM_EXACT_PIPE")) == 0;
+    const uint64_t pipeMax = (uint64_t)ctx->num_cus * 64 / std::max<uint32_t>(pipeW, 1);
+    const bool pipeOk = !pipeOff && ctx->band < 0 && dimr && dimr <= 48 && pipeW >= 2 && pipeW <= 8 &&
+                        pipeLds <= 150 * 1024 && regLds <= 64 * 1024;
+    if (pipeOk && !(pairs == nullptr && total > pipeMax)) {
+#define SSYM_EXACT_PIPE2(D_, T_)                                                                               \
+    do {                                                                                                       \
+        auto kern = dtw_exact_pipe_kernel<D_, T_>;                                                             \
+        if (pipeLds > 64 * 1024)                                                                               \
+            SSYM_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                                    (int)pipeLds));                                            \
+        kern<<<std::min<unsigned>(grid, (unsigned)pipeMax), 64 * pipeW, pipeLds, st>>>(                       \
+            src.raw, src.off, tgt.raw, tgt.off, src.n, tgt.n, dim, ctx->band, ctx->squared, pairs, count_dev,  \
+            max_pairs, fbEven, out, (uint64_t)0, pipeMax);                                                     \
+    } while (0)
+#define SSYM_EXACT_PIPE(D_)                                                                                    \
+    do {                                                                                                       \
+        if (bf32)                                                                                              \
+            SSYM_EXACT_PIPE2(D_, float);                                                                       \
+        else                                                                                                   \
+            SSYM_EXACT_PIPE2(D_, double);                                                                      \
+    } while (0)
+        switch (dimr) {
+        case 12: SSYM_EXACT_PIPE(12); break;
+        case 14: SSYM_EXACT_PIPE(14); break;
+        case 16: SSYM_EXACT_PIPE(16); break;
+        case 40: SSYM_EXACT_PIPE(40); break;
+        default: SSYM_EXACT_PIPE(48); break;
+        }
+#undef SSYM_EXACT_PIPE
+#undef SSYM_EXACT_PIPE2
+        SSYM_HIP_CHECK(ctx, hipGetLastError());
+        if (!pairs || max_pairs <= pipeMax)      // the list cannot be longer than the pipelined kernel takes
+            return SSYM_OK;
+        regLo = pipeMax + 1;                     // longer lists: the one-wave-per-pair kernel below
+    }
     if (dimr && regLds <= (size_t)(dimr == 64 ? 150 : 64) * 1024) {
 #define SSYM_EXACT_REG(...)                                                                                    \
     do {                                                                                                       \
@@ -417,7 +654,7 @@ int32_t launch_dtw_exact(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet 
             SSYM_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                                     (int)regLds));                                             \
         kern<<<grid, 64, regLds, st>>>(src.raw, src.off, tgt.raw, tgt.off, src.n, tgt.n, dim, ctx->band,      \
-                                       ctx->squared, pairs, count_dev, max_pairs, fbEven, out);                \
+                                       ctx->squared, pairs, count_dev, max_pairs, fbEven, out, regLo, ~0ull);  \
     } while (0)
         switch (dimr) {
         case 12: SSYM_EXACT_REG(12, 1); break;

@@ -590,3 +590,31 @@ def test_dtw_very_wide_frames_generic_exact_kernel(oracle):
     want_idx, want_cost = oracle.dtw_match_all(sf.astype(np.float64), so, tf.astype(np.float64), to, 100)
     assert np.array_equal(idx, want_idx) and np.allclose(cost, want_cost, rtol=EXACT_RTOL, atol=0)
     e.close()
+
+
+@pytest.mark.parametrize("dim,dtype,lo,hi", [(13, "f32", 300, 512), (13, "f64", 65, 200), (40, "f32", 129, 400),
+                                             (12, "f64", 449, 512), (48, "f32", 70, 130)])
+def test_dtw_exact_chunks_pipelined_over_waves(oracle, dim, dtype, lo, hi):
+    # sources of 65...512 frames and a short list: dtw_exact_pipe_kernel (one wave per 64-row chunk, bottom rows
+    # handed over through LDS as they are produced).  Every pair against the oracle, exact kernel on all of them.
+    st = synth.Stream(0x5EED6000 + dim + hi)
+    n, m = 9, 7
+    ls = lo + st.integers(n, hi - lo + 1)
+    lt = 1 + st.integers(m, hi)
+    ls[0], ls[1] = hi, lo                                    # the longest (all waves busy) and the shortest
+    src = [st.normal(int(f) * dim).reshape(int(f), dim) * synth.sigma(dim) for f in ls]
+    tgt = [st.normal(int(f) * dim).reshape(int(f), dim) * synth.sigma(dim) for f in lt]
+    tgt[2] = src[3][5:].copy()
+    npdt = np.float32 if dtype == "f32" else np.float64
+    sf, so = pack_segments(src, dim, npdt)
+    tf, to = pack_segments(tgt, dim, npdt)
+    e = Engine(metric="dtw", dtype=dtype)
+    d, q = e.dictionary(sf, so, dim), e.queries(tf, to, dim)
+    _, _, want = oracle.dtw_match_all(sf.astype(np.float64), so, tf.astype(np.float64), to, dim, want_matrix=True,
+                                      nthreads=oracle.max_threads())
+    got = e.pair_matrix(d, q, exact=True)
+    assert np.array_equal(np.isfinite(got), np.isfinite(want))
+    assert np.allclose(got, want, rtol=1e-12, atol=0)
+    idx, cost = e.match(d, q, force_exact=True)
+    assert np.array_equal(idx, want.argmin(axis=0)) and np.allclose(cost, want.min(axis=0), rtol=1e-12, atol=0)
+    e.close()
