@@ -73,11 +73,11 @@ enum { SSYM_DTYPE_F64 = 0, SSYM_DTYPE_F32 = 1 };
 enum {
     SSYM_OUT_DEVICE = 1u,      /* out_idx / out_cost are device pointers on ctx's GPU            */
     SSYM_DTW_FORCE_EXACT = 2u, /* skip the f32 MFMA filter: exact f64 kernel on every pair       */
-    SSYM_DTW_PRUNE = 4u        /* dtw first-minimum search (no distances, unbanded, frames of at
-                                  most 42 values): one candidate pair per target is scored first
-                                  and the filter abandons pairs that are provably above it; same
-                                  indices and costs, the time then depends on the data; ignored
-                                  where it does not apply                                         */
+    SSYM_DTW_PRUNE = 4u        /* dtw first-minimum search (k = 1, no per-target distances): one
+                                  candidate pair per target is scored first and the filter
+                                  abandons pairs that are provably above it; same indices and
+                                  costs, the time then depends on the data; ignored where it does
+                                  not apply                                                       */
 };
 
 typedef struct ssym_config {

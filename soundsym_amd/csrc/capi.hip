@@ -404,8 +404,8 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
             // (phase 1: the candidates were scored by ssym_match_candidates, their costs reduced over the ranks;
             //  phase 2: what phase 1 did)
             const bool prune = phase == 2 ? ctx->pending.pruned
-                                          : (flags & SSYM_DTW_PRUNE) && !wide && k_top == 1 && !distDev &&
-                                                (phase == 0 || prune_cost_dev != nullptr);
+                                          : (flags & SSYM_DTW_PRUNE) && k_top == 1 && !distDev &&
+                                                (phase == 0 ? true : (prune_cost_dev != nullptr && !wide));
             if (phase != 2) {
                 SSYM_HIP_CHECK(ctx, hipEventRecord(ev[0], st));
                 const float *abandon = nullptr;
@@ -427,7 +427,7 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
                 if (prune)
                     SSYM_HIP_CHECK(ctx, hipMemcpyAsync(&ctx->pruned_cells, colCtr, sizeof(*colCtr),
                                                        hipMemcpyDeviceToHost, st));
-                rc = wide ? launch_dtw_bounds_partial(ctx, src, tgt, cmat)
+                rc = wide ? launch_dtw_bounds_partial(ctx, src, tgt, cmat, prune ? (const double *)ctx->prune_cost.ptr : nullptr)
                           : launch_dtw_bounds(ctx, src, tgt, cmat, distDev, k_top,
                                               prune ? (const double *)ctx->prune_cost.ptr : nullptr);
                 if (rc != SSYM_OK)

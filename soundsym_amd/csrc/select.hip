@@ -654,17 +654,22 @@ __global__ __launch_bounds__(256) void dtw_partial_argmin_kernel(const float *__
     pairs[t] = make_uint2(permS[bs], permT[t]);                    // exact kernel: the caller's indices
 }
 
-__global__ void dtw_partial_threshold_kernel(const double *__restrict__ exact, uint32_t nTgt,
-                                             unsigned long long *__restrict__ ub)
+__global__ void dtw_partial_threshold_kernel(const double *__restrict__ exact, const double *__restrict__ seed,
+                                             uint32_t nTgt, unsigned long long *__restrict__ ub)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nTgt)
         return;
-    const double c = exact[t];
+    double c = exact[t];
+    if (seed) {                          // early abandoning: the candidate's exact cost is an upper bound too
+        const double s = seed[t];
+        c = (s >= 0.0 && (s < c || c != c)) ? s : c;
+    }
     ub[t] = c == c ? (unsigned long long)__double_as_longlong(c < 0.0 ? 0.0 : c) : kInfBits;   // NaN: nothing can win
 }
 
-int32_t launch_dtw_bounds_partial(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, const float *cmat)
+int32_t launch_dtw_bounds_partial(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, const float *cmat,
+                                  const double *seed_by_slot)
 {
     hipStream_t st = ctx->stream;
     int32_t rc = ensure(ctx, ctx->tmin, sizeof(unsigned long long) * tgt.n);
@@ -682,7 +687,7 @@ int32_t launch_dtw_bounds_partial(ssym_ctx *ctx, const SegmentSet &src, const Se
     rc = launch_dtw_exact(ctx, src, tgt, pairs, hdr, tgt.n, (double *)ctx->cand_cost.ptr);
     if (rc != SSYM_OK)
         return rc;
-    dtw_partial_threshold_kernel<<<tb, 256, 0, st>>>((const double *)ctx->cand_cost.ptr, tgt.n,
+    dtw_partial_threshold_kernel<<<tb, 256, 0, st>>>((const double *)ctx->cand_cost.ptr, seed_by_slot, tgt.n,
                                                      (unsigned long long *)ctx->tmin.ptr);
     SSYM_HIP_CHECK(ctx, hipGetLastError());
     return SSYM_OK;

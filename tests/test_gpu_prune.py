@@ -47,7 +47,7 @@ def test_prune_planted_grid(oracle, n, m, f, d):
 @pytest.mark.parametrize("case", range(_N))
 def test_prune_random_shapes(oracle, case):
     st = synth.Stream(0x5EED4000 + case)
-    dim = int([1, 2, 5, 12, 13, 14, 20, 40, 42][st.integers(1, 9)[0]])
+    dim = int([1, 2, 5, 12, 13, 14, 20, 40, 42, 43, 64, 90][st.integers(1, 12)[0]])
     hi = int([3, 17, 33, 50, 66, 130, 150][st.integers(1, 7)[0]])
     lo = int(st.integers(1, 2)[0])
     n, m = int(2 + st.integers(1, 60)[0]), int(1 + st.integers(1, 70)[0])
@@ -166,6 +166,23 @@ def test_prune_medium_ragged(oracle, dim, band, nt, seed, monkeypatch):
     assert np.array_equal(idx, want_idx)
     fin = np.isfinite(want_cost)
     assert np.allclose(cost[fin], want_cost[fin], rtol=1e-12, atol=0) and np.isinf(cost[~fin]).all()
+    e.close()
+
+
+@pytest.mark.parametrize("dim,f,band", [(50, 64, -1), (64, 100, -1), (90, 40, -1), (64, 96, 16)])
+def test_prune_wide_frames(oracle, dim, f, band):
+    # frames wider than the filter takes in: its cost is a lower bound, which is all abandoning needs
+    g = synth.make_grid(160, 256 if band >= 0 else 96, f, dim, 0x5EED0600 + dim)
+    sf, so = g.flat("sources")
+    tf, to = g.flat("targets")
+    e = Engine(metric="dtw", dtype="f32", band=band)
+    dd, q = e.dictionary(sf, so, dim), e.queries(tf, to, dim)
+    idx, cost, t0, t1 = _both(e, dd, q)
+    assert t1["pruned"] == t1["used_filter"] == 1
+    assert np.array_equal(idx, g.planted)
+    want_idx, want_cost = oracle.dtw_match_all(sf.astype(np.float64), so, tf.astype(np.float64), to, dim, band=band,
+                                               nthreads=oracle.max_threads())
+    assert np.array_equal(idx, want_idx) and np.allclose(cost, want_cost, rtol=1e-12, atol=0)
     e.close()
 
 
