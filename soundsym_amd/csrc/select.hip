@@ -661,7 +661,10 @@ __global__ void dtw_partial_threshold_kernel(const double *__restrict__ exact, c
     if (t >= nTgt)
         return;
     double c = exact[t];
-    if (seed) {                          // early abandoning: the candidate's exact cost is an upper bound too
+    if (seed) {
+        // early abandoning: the candidate's exact cost is an upper bound too.  (It does not replace the pair the
+        // filter likes best: without close pairs the centroid candidate is a poor bound and the lower-bound
+        // selection would keep 10^2 times more pairs -- measured 15 -> 110 ms at 64 values per frame.)
         const double s = seed[t];
         c = (s >= 0.0 && (s < c || c != c)) ? s : c;
     }

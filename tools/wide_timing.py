@@ -26,6 +26,12 @@ for dim in (64, 90):
         if planted:
             line += f", planted recovered: {bool(np.array_equal(idx, g.planted))}"
         print(line)
+        e.match(d, q, prune=True)
+        pi, pc = e.match(d, q, prune=True)
+        tp = e.timings()
+        print(f"   with early abandoning: total {tp['total_ms']:.1f} ms (thresholds {tp['prune_ms']:.1f}, filter {tp['main_ms']:.1f}, "
+              f"select {tp['select_ms']:.1f}, refine {tp['refine_ms']:.1f}), same answers: "
+              f"{bool(np.array_equal(pi, idx) and np.array_equal(pc, cost))}")
         if dim == 64 and planted:
             m = 256
             qs = e.queries(tgt[:m].reshape(-1), off[:m + 1], dim)
