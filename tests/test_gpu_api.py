@@ -111,18 +111,64 @@ def test_reconstruction_tail_on_the_gpu(oracle):
     assert np.array_equal(out[:big.size][~np.isnan(big)], big[~np.isnan(big)])
 
 
-def test_reconstruction_example_end_to_end(tmp_path, oracle):
-    """examples/reconstruction.py on synthetic WAVs: read -> segment -> features -> match (GPU) ->
-    length fit + concatenation + 32-bit conversion (GPU) -> WAV, checked against the oracle."""
+def _load_reconstruction_example():
     import importlib.util
     import os
-    from oracle.oracle import pack_segments
-    from soundsym_amd import io as sio
-    from soundsym_amd.features import frame_features
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("reconstruction", os.path.join(here, "examples", "reconstruction.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
+    return mod
+
+
+def _run_and_check_reconstruction(mod, oracle, ps, pt, po, labels, extra):
+    """One run of examples/reconstruction.py, then the same segmentation and features through the oracle."""
+    from oracle.oracle import pack_segments
+    from soundsym_amd import io as sio
+    from soundsym_amd.features import frame_features
+    got = mod.main(["-s", ps, "-t", pt, "-o", po] + extra)
+    s_smp, srate = sio.read_wav(ps)
+    t_smp, rate = sio.read_wav(pt)
+    back, r = sio.read_wav(po)
+    assert r == rate and back.size == got.size
+    assert np.array_equal(back, sio.pcm32(got).astype(np.float64) / 2147483647.0)
+    seg = 16 * HOP
+    slens = mod.chunk_lengths(s_smp.size, seg)
+    sfe = frame_features(s_smp, srate)
+    ssm, sft, pos, fpos = [], [], 0, 0
+    for L in slens:
+        nf = L // HOP
+        ssm.append(s_smp[pos:pos + L]); sft.append(sfe[fpos:fpos + nf * NCOEFFS]); pos += L; fpos += nf * NCOEFFS
+    if "--labels" in extra:
+        tsm = []
+        for a, b, _ in sio.audacity_labels_to_timestamps(labels):
+            piece = t_smp[int(round(a * rate)):int(round(b * rate)) + 1]
+            if piece.size >= HOP:
+                tsm.append(piece)
+        tft = [frame_features(x, rate) for x in tsm]
+    else:
+        tfe = frame_features(t_smp, rate)
+        tsm, tft, pos, fpos = [], [], 0, 0
+        for L in mod.chunk_lengths(t_smp.size, seg):
+            nf = L // HOP
+            tsm.append(t_smp[pos:pos + L]); tft.append(tfe[fpos:fpos + nf * NCOEFFS]); pos += L; fpos += nf * NCOEFFS
+    flat, off = pack_segments(sft, NCOEFFS)
+    tflat, toff = pack_segments(tft, NCOEFFS)
+    if "dtw" in extra:
+        idx, _ = oracle.dtw_match_all(flat, off, tflat, toff, NCOEFFS, nthreads=oracle.max_threads())
+    else:
+        idx, _ = oracle.refcos_match_all(flat, off, tflat, toff, NCOEFFS)
+    soff = np.concatenate([[0], np.cumsum([x.size for x in ssm])]).astype(np.uint64)
+    ooff = np.concatenate([[0], np.cumsum([x.size for x in tsm])]).astype(np.uint64)
+    assert np.array_equal(got, oracle.reconstruct(np.concatenate(ssm), soff, idx, ooff))
+    return len(ssm), len(tsm), idx
+
+
+def test_reconstruction_example_end_to_end(tmp_path, oracle):
+    """examples/reconstruction.py on synthetic WAVs: read -> segment -> features -> match (GPU) ->
+    length fit + concatenation + 32-bit conversion (GPU) -> WAV, checked against the oracle."""
+    from soundsym_amd import io as sio
+    mod = _load_reconstruction_example()
     rate = 22050
     t = np.arange(rate * 3) / rate
     src = 0.4 * np.sin(2 * np.pi * (200 + 300 * t) * t) + 0.1 * np.sin(2 * np.pi * 1700 * t)
@@ -133,40 +179,25 @@ def test_reconstruction_example_end_to_end(tmp_path, oracle):
     labels = str(tmp_path / "l.txt")
     open(labels, "w").write("0.10\t0.45\ta\n0.45\t0.60\tb\n0.60\t1.40\tc\n1.40\t1.95\td\n")
     for extra in ([], ["--labels", labels], ["--metric", "dtw"]):
-        got = mod.main(["-s", ps, "-t", pt, "-o", po] + extra)
-        back, r = sio.read_wav(po)
-        assert r == rate and back.size == got.size
-        assert np.array_equal(back, sio.pcm32(got).astype(np.float64) / 2147483647.0)
-        # oracle for the same segmentation and features
-        s_smp, _ = sio.read_wav(ps)
-        t_smp, _ = sio.read_wav(pt)
-        seg = 16 * HOP
-        slens = mod.chunk_lengths(s_smp.size, seg)
-        sfe = frame_features(s_smp, rate)
-        ssm, sft, pos, fpos = [], [], 0, 0
-        for L in slens:
-            nf = L // HOP
-            ssm.append(s_smp[pos:pos + L]); sft.append(sfe[fpos:fpos + nf * NCOEFFS]); pos += L; fpos += nf * NCOEFFS
-        if "--labels" in extra:
-            tsm = []
-            for a, b, _ in sio.audacity_labels_to_timestamps(labels):
-                tsm.append(t_smp[int(round(a * rate)):int(round(b * rate)) + 1])
-            tft = [frame_features(x, rate) for x in tsm]
-        else:
-            tfe = frame_features(t_smp, rate)
-            tsm, tft, pos, fpos = [], [], 0, 0
-            for L in mod.chunk_lengths(t_smp.size, seg):
-                nf = L // HOP
-                tsm.append(t_smp[pos:pos + L]); tft.append(tfe[fpos:fpos + nf * NCOEFFS]); pos += L; fpos += nf * NCOEFFS
-        flat, off = pack_segments(sft, NCOEFFS)
-        tflat, toff = pack_segments(tft, NCOEFFS)
-        if "dtw" in extra:
-            idx, _ = oracle.dtw_match_all(flat, off, tflat, toff, NCOEFFS)
-        else:
-            idx, _ = oracle.refcos_match_all(flat, off, tflat, toff, NCOEFFS)
-        soff = np.concatenate([[0], np.cumsum([x.size for x in ssm])]).astype(np.uint64)
-        ooff = np.concatenate([[0], np.cumsum([x.size for x in tsm])]).astype(np.uint64)
-        assert np.array_equal(got, oracle.reconstruct(np.concatenate(ssm), soff, idx, ooff))
+        _run_and_check_reconstruction(mod, oracle, ps, pt, po, labels, extra)
+
+
+@pytest.mark.parametrize("metric", ["refcos", "dtw"])
+def test_config1_reference_recordings(tmp_path, oracle, metric):
+    """BASELINE.json configs[0] / SURVEY.md section 8(d) "Config 1", on the reference's own recordings
+    (tests/golden/audio, data files of the reference's tests): tests/sample.wav cut into 16-frame chunks is the
+    dictionary, tests/Section_7_1.wav segmented by tests/vowel.txt (55 labels) the targets; features from the
+    GPU MFCC front-end; every target replaced by its nearest chunk, length-fitted, concatenated and written as a
+    32-bit WAV -- indices and samples equal to the oracle's on the same features."""
+    import os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    mod = _load_reconstruction_example()
+    ps, pt = os.path.join(gold, "audio", "sample.wav"), os.path.join(gold, "audio", "Section_7_1.wav")
+    labels, po = os.path.join(gold, "vowel.txt"), str(tmp_path / "reconstructed.wav")
+    n_src, n_tgt, idx = _run_and_check_reconstruction(mod, oracle, ps, pt, po, labels,
+                                                      ["--labels", labels, "--metric", metric])
+    assert n_src == 284 and n_tgt == 55            # 1 163 214 samples: 283 chunks of 4096 and one of 15 frames; the 55 labels of vowel.txt
+    assert len(set(idx.tolist())) > 5              # a real matching, not one chunk for everything
 
 
 def test_small_abi_entry_points():

@@ -62,3 +62,24 @@ def test_max_power_and_wav16(tmp_path):
     sio.write_wav16(str(tmp_path / "a.wav"), q, 8000)
     back, rate = sio.read_wav(str(tmp_path / "a.wav"))
     assert rate == 8000 and np.array_equal(back, q.astype(np.float64) / 32767.0)
+
+
+def test_reference_sample_wav_known_answers():
+    # the reference's own known-answer test on its own data file (test_sound_from_samples, src/lib.rs:246-260):
+    #   max |sample| of tests/sample.wav = 0.6503654301602161 (1e-9)  -- pins the WAV convention of
+    #   src/sound.rs:116-126 (24-bit PCM divided by i32::MAX >> 8);
+    # its second constant (max_power = 0.25781895526454907) is stale upstream: analyze_max_power as written
+    # today (128-sample windows hopped by 64, src/sound.rs:244-256) gives 0.3263162680772736, and the
+    # constant is reproduced by 2048-sample windows only -- both stated here.
+    x, rate = sio.read_wav(os.path.join(GOLD, "audio", "sample.wav"))
+    assert rate == 44100.0 and x.dtype == np.float64
+    assert abs(np.abs(x).max() - 0.6503654301602161) < 1e-9
+    assert abs(sio.max_power(x) - 0.3263162680772736) < 1e-12
+    n = (x.size - 2048) // 1024 + 1
+    idx = np.arange(n)[:, None] * 1024 + np.arange(2048)[None, :]
+    assert abs(float(np.sqrt((x[idx] ** 2).sum(axis=1) / 2048.0).max()) - 0.25781895526454907) < 1e-12
+    y, r2 = sio.read_wav(os.path.join(GOLD, "audio", "Section_7_1.wav"))
+    assert y.size > 0 and r2 > 0
+    # every label of the reference's vowel.txt lies inside its recording
+    ts = sio.audacity_labels_to_timestamps(os.path.join(GOLD, "vowel.txt"))
+    assert 0 <= ts[0][0] and ts[-1][1] * r2 <= y.size
