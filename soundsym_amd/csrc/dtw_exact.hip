@@ -585,7 +585,8 @@ int32_t launch_dtw_exact(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet 
     hipStream_t st = ctx->stream;
     // frames of up to 48 values: source frame in registers, target frames zero-padded in LDS
     const uint32_t fbEven = (fbCap + 1) & ~1u;
-    const int dimr = dim <= 12 ? 12 : dim <= 14 ? 14 : dim <= 16 ? 16 : dim <= 40 ? 40 : dim <= 48 ? 48 : dim <= 64 ? 64 : 0;
+    const int dimr = dim <= 12 ? 12 : dim <= 14 ? 14 : dim <= 16 ? 16 : dim <= 40 ? 40 : dim <= 48 ? 48 : dim <= 64 ? 64
+                                                                                                   : dim <= 96 ? 96 : 0;
     const bool bf32 = ctx->dtype == SSYM_DTYPE_F32;     // every feature buffer of the context was f32: exact in float
     const int up4 = (dimr + 3) / 4 * 4;
     const int ldr = bf32 ? up4 + (up4 % 8 == 4 ? 0 : 4) : ((dimr % 4 == 2) ? dimr : dimr + 2);   // exact_ld<>
@@ -639,7 +640,7 @@ int32_t launch_dtw_exact(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet 
             return SSYM_OK;
         regLo = pipeMax + 1;                     // longer lists: the one-wave-per-pair kernel below
     }
-    if (dimr && regLds <= (size_t)(dimr == 64 ? 150 : 64) * 1024) {
+    if (dimr && regLds <= (size_t)(dimr >= 64 ? 150 : 64) * 1024) {
 #define SSYM_EXACT_REG(...)                                                                                    \
     do {                                                                                                       \
         if (bf32)                                                                                              \
@@ -662,7 +663,8 @@ int32_t launch_dtw_exact(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet 
         case 16: SSYM_EXACT_REG(16, 1); break;
         case 40: SSYM_EXACT_REG(40, 1); break;
         case 48: SSYM_EXACT_REG(48, 1); break;
-        default: SSYM_EXACT_REG(64, 2); break;      // 49..64 values: the frame is fetched in two halves
+        case 64: SSYM_EXACT_REG(64, 2); break;      // 49..64 values: the frame is fetched in two halves
+        default: SSYM_EXACT_REG(96, 3); break;      // 65..96 values: three fetches of 32
         }
 #undef SSYM_EXACT_REG
 #undef SSYM_EXACT_REG2
