@@ -151,6 +151,21 @@ int main()
         ssym_oracle_dtw_match_all(flat.data(), off.data(), (uint32_t)dd->sounds.size(), pf.data(), po.data(), 1,
                                   NCOEFFS, -1, 0, 1, &want, &cost, nullptr);
         CHECK(dd->match_sound(probe) == dd->sounds[want]);
+
+        // the same dictionary behind a context with early abandoning as its default (ssym_config.dtw_prune):
+        // batches of 64 targets and more are pruned, and answer exactly as the plain context does
+        auto pctx = std::make_shared<Context>(SSYM_METRIC_DTW, 0, -1, false, true);
+        auto pd = SoundDictionary::from_segments(pctx, src, segs);
+        std::vector<ArcSound> many;
+        for (int r = 0; r < 6; ++r)
+            for (const auto &snd : dd->sounds)
+                many.push_back(snd);
+        CHECK(many.size() >= 64);
+        const std::vector<uint32_t> plain = dd->match_indices(many, nullptr), pruned = pd->match_indices(many, nullptr);
+        CHECK(plain == pruned);
+        ssym_timings tm{};
+        CHECK(ssym_get_timings(pctx->get(), &tm) == SSYM_OK && tm.pruned == 1);
+        CHECK(ssym_get_timings(dctx->get(), &tm) == SSYM_OK && tm.pruned == 0);
     }
     std::printf(g_fail ? "%d checks FAILED\n" : "all checks passed\n", g_fail);
     return g_fail ? 1 : 0;
