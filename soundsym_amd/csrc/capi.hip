@@ -318,6 +318,8 @@ __global__ void targets_to_slots_kernel(const double *__restrict__ byTarget, con
 // phase 0: the whole match.  Phases 1 / 2 are ssym_match_begin / ssym_match_finish: phase 1 stops
 // after the filter and the per-target threshold (copied to bounds_dev), phase 2 takes the threshold
 // back from bounds_dev (after the ranks' all-reduce) and runs selection, re-scoring and the fold.
+constexpr uint32_t kFlagFewTargets = 0x80000000u;      // internal: set by ssym_match_batch / ssym_match_one for <= 4 targets
+
 static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queries *q,
                           const double *distance, uint32_t index_base, uint32_t k_top, uint32_t *out_idx,
                           double *out_cost, uint32_t flags, int phase = 0, double *bounds_dev = nullptr,
@@ -392,7 +394,11 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
         // frames wider than the filter's 42 values: the filter scores the first 42 and bounds the cost from
         // below; that supports the plain first-minimum search (no per-target distances, k = 1)
         const bool wide = (int)src.dim > filter_dim_used((int)src.dim);
-        const bool useFilter = !(flags & SSYM_DTW_FORCE_EXACT) && filter_supported(ctx, src, tgt) &&
+        // few short queries against a small dictionary: the exact kernel on every pair is one launch of a few
+        // thousand waves, the filter path a chain of ~20 launches (1 query x 1024 entries of 5...40 frames:
+        // 81 us against 227 us per call; from 16 queries on the filter path is the shorter one)
+        const bool fewPairs = (flags & kFlagFewTargets) && (uint64_t)N * M <= 8192 && src.max_frames + tgt.max_frames <= 128;
+        const bool useFilter = !(flags & SSYM_DTW_FORCE_EXACT) && !fewPairs && filter_supported(ctx, src, tgt) &&
                                (!wide || (k_top == 1 && !(phase == 2 ? ctx->pending.has_dist : distance != nullptr)));
         tm.used_filter = useFilter ? 1 : 0;
         if (useFilter) {
@@ -750,7 +756,9 @@ int32_t ssym_match_batch(ssym_ctx *ctx, const ssym_dict *dict, const void *tgt_f
         return rc;
     }
     SSYM_HIP_CHECK(ctx, hipEventRecord(e1, ctx->stream));
-    rc = ssym_match_queries(ctx, dict, q, distance, 0, out_idx, out_cost, 0);
+    // a handful of queries at a time is the reference's own call pattern (match_sound per target,
+    // src/sound.rs:453-454): what counts then is the length of the launch chain, see match_impl
+    rc = match_impl(ctx, dict, q, distance, 0, 1, out_idx, out_cost, n_targets <= 4 ? kFlagFewTargets : 0u);
     if (rc == SSYM_OK)
         ctx->timings.pack_ms = ev_ms(e0, e1);
     else
