@@ -1,0 +1,45 @@
+"""bench.py keeps its contract: ONE JSON line with the keys the driver reads, on a small workload so that the
+check costs a second (the default workload is measured by the driver itself)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1",
+                          "--src-per-gpu", "512", "--targets", "256", "--frames", "64", "--no-cpu-baseline"] + extra,
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def test_bench_prints_one_json_line_with_the_contract_keys():
+    line = _run(["--no-secondary"])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in line, key
+    assert line["metric"] == "segment-pairs/sec (DTW cost+argmin)" and line["unit"] == "segment-pairs/s"
+    assert line["n_gpus"] == 1 and line["steps"] == 2 and line["warmup"] == 1 and line["higher_is_better"] is True
+    assert line["scaling"] == "weak" and line["vs_baseline"] is None and line["dtype"] == "f32" and line["data"] == "synthetic"
+    assert "workload" in line["config"] and line["config"]["indices_equal_planted"] is True
+    rl = line["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in rl, key
+    assert rl["bound"] == "hbm" and rl["unit"] == "GB/s" and abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-12
+    assert line["value"] > 0 and abs(line["value"] - 512 * 256 / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-6
+
+
+def test_bench_early_abandon_leg_is_identical_to_the_full_search():
+    line = _run([])                                   # with the secondary legs (refcos, chain, mfcc, early abandoning)
+    ea = line["early_abandon"]
+    assert ea["identical_to_full_search"] is True and ea["value"] > 0
+    assert 0 < ea["filter_cells_swept_frac"] <= 1
+    assert set(line["secondary"]) >= {"refcos", "chain", "mfcc"}
