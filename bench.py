@@ -283,10 +283,12 @@ def main():
         stream_gbps = pairs_launch * 2 * f * dd * 4 / k_s / 1e9
         flops_tf = pairs_launch * 2.0 * cells_pair * dd / k_s / 1e12
         cells_per_s = pairs_launch * cells_pair / k_s
-        traffic = None
+        traffic = mfma_busy = valu_busy = None
         prof = sorted(glob.glob(os.path.join(ROOT, "profiles", "*bench_1gpu.json")))
         if prof and n_gpus == 1 and (hi - lo, m, f, dd, r) == (SRC_PER_GPU, N_TGT, FRAMES, DIM, -1):
-            traffic = json.load(open(prof[-1])).get("hbm_traffic_bytes_per_launch")
+            pj = json.load(open(prof[-1]))           # rocprofv3 PMC passes over this same command (tools/profile_bench.sh)
+            traffic = pj.get("hbm_traffic_bytes_per_launch")
+            mfma_busy, valu_busy = pj.get("mfma_busy_fraction"), pj.get("valu_busy_fraction")
         # VALU floor measured on MI355X (profiles/): v_sqrt_f32 8 + v_min3_f32 4 + v_add_f32 4
         # cycles per wave-instruction = 16 cycles per 64 cells per SIMD, 1024 SIMDs
         valu_peak_cells = 1024 * 64 / 16.0 * 2.4e9
@@ -330,10 +332,11 @@ def main():
                 "kernel_ms": k_ms,
                 "mfma": {"achieved": flops_tf, "unit": "TFLOP/s", "algorithmic_flops_per_pair": 2 * cells_pair * dd,
                          "peak_f32_mfma": PEAK_F32_MFMA_TFLOPS, "frac_of_f32_mfma_peak": flops_tf / PEAK_F32_MFMA_TFLOPS,
+                         "pipe_busy_frac_pmc": mfma_busy,
                          "note": "cost block runs on the f16 matrix pipe (3 x 32x32x16 per 32x32 tile, "
                                  "two-piece operand split); algorithmic flops, not issued flops"},
                 "valu": {"achieved": cells_per_s, "unit": "DP cells/s", "peak": valu_peak_cells,
-                         "frac": cells_per_s / valu_peak_cells,
+                         "frac": cells_per_s / valu_peak_cells, "busy_frac_pmc": valu_busy,
                          "note": "16 VALU cycles per cell per SIMD at 2.4 GHz (measured issue costs)"},
             },
         }

@@ -86,6 +86,13 @@ def main():
             line += "; clock under load %.2f GHz; %.2f VALU-busy cycles and %.2f elapsed SIMD cycles per wave-cell (floor: 16)" % (
                 ghz, 4.0 * p["SQ_ACTIVE_INST_VALU"]["mean_per_launch"] / cells, cyc * 1024.0 / cells)
         lines += ["", line + "."]
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in p:
+            # MI355X_MICROARCH.md: SQ_VALU_MFMA_BUSY_CYCLES counts cycles (32 per 32x32x16 MFMA), summed over the SIMDs
+            mf = p["SQ_VALU_MFMA_BUSY_CYCLES"]["mean_per_launch"] / (cyc * 1024.0)
+            out["mfma_busy_fraction"] = mf
+            lines += ["", "MFMA utilisation of the dominant kernel = %.3f of the matrix pipes' cycles (SQ_VALU_MFMA_BUSY_CYCLES / "
+                      "(GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); three 32x32x16 f16 MFMAs per 32x32 tile of cells): the matrix pipe runs beside the VALU, "
+                      "which sets the pace." % mf]
     os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
     open(dst + ".md", "w").write("\n".join(lines) + "\n")
     json.dump(out, open(dst + ".json", "w"), indent=1)
