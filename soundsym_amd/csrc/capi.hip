@@ -345,6 +345,8 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
     SSYM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const bool outDev = (flags & SSYM_OUT_DEVICE) != 0;
+    if (phase == 0)
+        ctx->pending.cand = false;      // any other match may reuse the candidate buffers of ssym_match_candidates
     if (ctx->prune_default && phase == 0 && M >= 64)      // (a handful of targets: the extra launches cost more than they save)
         flags |= SSYM_DTW_PRUNE;
 

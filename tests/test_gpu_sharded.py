@@ -199,3 +199,27 @@ def test_two_shards_pruned_exchange_candidates_first(oracle, band):
     e.match_finish(b, oi, oc)
     for s in shards:
         s[0].close()
+
+
+def test_candidates_are_dropped_when_another_match_comes_in_between(oracle):
+    # ssym_match_candidates leaves its pairs in the context; a different pruned match overwrites them, so the
+    # begin that follows must not trust them any more (it runs as a plain begin -- results stay right)
+    g = synth.make_grid(256, 96, 48, 13, 0x5EED0922)
+    e = Engine(metric="dtw", dtype="f32")
+    d, q = _sets(e, g, 0, 256, 48, 13)
+    want_idx, want_cost = e.match(d, q)
+    other = synth.make_grid(128, 80, 48, 13, 0x5EED0923)
+    d2, q2 = _sets(e, other, 0, 128, 48, 13)
+    m = 96
+    c = torch.empty(m, dtype=torch.float64, device="cuda")
+    e.match_candidates(d, q, c)
+    e.match(d2, q2, prune=True)                                  # reuses the candidate buffers
+    b = torch.empty(m, dtype=torch.float64, device="cuda")
+    e.match_begin_pruned(d, q, b, c)
+    assert e.timings()["pruned"] == 0
+    oi = torch.empty(m, dtype=torch.int32, device="cuda")
+    oc = torch.empty(m, dtype=torch.float64, device="cuda")
+    e.match_finish(b, oi, oc)
+    assert np.array_equal(oi.cpu().numpy().astype(np.int64), want_idx.astype(np.int64))
+    assert np.array_equal(oc.cpu().numpy(), want_cost)
+    e.close()
