@@ -221,6 +221,8 @@ SSYM_API int32_t ssym_pair_matrix(ssym_ctx *ctx, const ssym_dict *dict, const ss
  *                      none of whose pairs in this shard can win -- ssym_merge_shards then takes
  *                      another shard's entry)
  * dict / q / distance must stay alive between the two calls; flags as for ssym_match_queries.
+ * Any other matching call on the context in between (it would use the same scratch) ends the pair:
+ * ssym_match_finish then fails with "without ssym_match_begin".
  * Where the filter does not apply (refcos, shapes outside its limits) begin writes +inf and finish
  * is a plain ssym_match_queries, so callers need no second code path.  With one rank, or without
  * the all-reduce, the pair is equivalent to ssym_match_queries. */

@@ -345,8 +345,12 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
     SSYM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const bool outDev = (flags & SSYM_OUT_DEVICE) != 0;
-    if (phase == 0)
-        ctx->pending.cand = false;      // any other match may reuse the candidate buffers of ssym_match_candidates
+    if (phase == 0) {
+        // any other call that uses the context's scratch ends a begin .. finish in progress (finish then reports
+        // "without begin") and drops the candidates of ssym_match_candidates: their buffers are shared
+        ctx->pending.cand = false;
+        ctx->pending.valid = false;
+    }
     if (ctx->prune_default && phase == 0 && M >= 64)      // (a handful of targets: the extra launches cost more than they save)
         flags |= SSYM_DTW_PRUNE;
 
@@ -799,6 +803,8 @@ int32_t ssym_chain(ssym_ctx *ctx, ssym_dict *dict, const void *start_feats, uint
         return SSYM_E_EMPTY_DICT;
     }
     SSYM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    ctx->pending.cand = false;          // (the chain uses the scratch a begin .. finish would still need)
+    ctx->pending.valid = false;
     hipStream_t st = ctx->stream;
     const bool refcos = ctx->metric == SSYM_METRIC_REFCOS;
     const double init = refcos ? 2.0 : (double)INFINITY;
@@ -886,6 +892,8 @@ int32_t ssym_pair_matrix(ssym_ctx *ctx, const ssym_dict *dict, const ssym_querie
         ctx->err = "out_matrix is NULL";
         return SSYM_E_INVALID;
     }
+    ctx->pending.cand = false;          // (the matrix lands in the scratch a begin .. finish would still need)
+    ctx->pending.valid = false;
     const SegmentSet &src = dict->set;
     const SegmentSet &tgt = q->set;
     const uint32_t N = src.n, M = tgt.n;

@@ -222,4 +222,9 @@ def test_candidates_are_dropped_when_another_match_comes_in_between(oracle):
     e.match_finish(b, oi, oc)
     assert np.array_equal(oi.cpu().numpy().astype(np.int64), want_idx.astype(np.int64))
     assert np.array_equal(oc.cpu().numpy(), want_cost)
+    # and a match between begin and finish ends the pair: finish says so instead of folding foreign scratch
+    e.match_begin(d, q, b)
+    e.match(d2, q2)
+    with pytest.raises(SsymError):
+        e.match_finish(b, oi, oc)
     e.close()
