@@ -98,7 +98,7 @@ int32_t ssym_ctx_destroy(ssym_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     DeviceBuf *bufs[] = {&ctx->handoff, &ctx->cmat, &ctx->tmin, &ctx->cand, &ctx->cand2, &ctx->cand_xmin,
                          &ctx->cand_cost, &ctx->best, &ctx->selmask, &ctx->selcnt, &ctx->topk,
-                         &ctx->abandon, &ctx->prune_pairs, &ctx->prune_cost, &ctx->dist, &ctx->part, &ctx->out_idx, &ctx->out_cost};
+                         &ctx->abandon, &ctx->prune_pairs, &ctx->prune_cost, &ctx->one_ticket, &ctx->dist, &ctx->part, &ctx->out_idx, &ctx->out_cost};
     for (DeviceBuf *b : bufs)
         if (b->ptr)
             (void)hipFree(b->ptr);
@@ -776,6 +776,37 @@ int32_t ssym_match_batch(ssym_ctx *ctx, const ssym_dict *dict, const void *tgt_f
 int32_t ssym_match_one(ssym_ctx *ctx, const ssym_dict *dict, const void *feats, uint64_t n_frames,
                        double distance, uint32_t *out_idx, double *out_cost)
 {
+    // refcos: the whole call in one launch (refcos.hip, refcos_match_one_kernel)
+    if (ctx && dict && dict->set.n > 0 && out_idx && (feats || n_frames == 0) &&
+        refcos_one_supported(ctx, dict->set, n_frames)) {
+        StageScope stageScope(ctx);
+        SSYM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+        ctx->pending.cand = false;
+        ctx->pending.valid = false;
+        const size_t qBytes = (size_t)n_frames * dict->set.dim * (ctx->dtype == SSYM_DTYPE_F32 ? sizeof(float) : sizeof(double));
+        char *qPinned = stage_take(ctx, qBytes ? qBytes : 8);
+        char *outPinned = stage_take(ctx, 16);
+        if (qPinned && outPinned) {
+            if (qBytes)
+                memcpy(qPinned, feats, qBytes);
+            hipEvent_t *ev = ctx->ev;
+            SSYM_HIP_CHECK(ctx, hipEventRecord(ev[0], ctx->stream));
+            int32_t rc = launch_refcos_match_one(ctx, dict->set, qPinned, n_frames, distance, outPinned);
+            if (rc != SSYM_OK)
+                return rc;
+            SSYM_HIP_CHECK(ctx, hipEventRecord(ev[1], ctx->stream));
+            SSYM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            *out_idx = *(const uint32_t *)(outPinned + 8);
+            if (out_cost)
+                *out_cost = *(const double *)outPinned;
+            ssym_timings tm{};
+            tm.n_pairs = dict->set.n;
+            tm.main_ms = tm.total_ms = ev_ms(ev[0], ev[1]);
+            tm.main_launches = 1;
+            ctx->timings = tm;
+            return SSYM_OK;
+        }
+    }
     const uint64_t off[2] = {0, n_frames};
     return ssym_match_batch(ctx, dict, feats, off, 1, &distance, out_idx, out_cost);
 }

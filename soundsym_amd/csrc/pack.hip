@@ -145,7 +145,7 @@ void dev_cache_release(ssym_ctx *ctx)
 // ---- pinned staging ------------------------------------------------------------------------------
 constexpr size_t kStageBytes = (size_t)1 << 20, kStageMaxCopy = (size_t)256 << 10;
 
-static char *stage_take(ssym_ctx *ctx, size_t bytes)
+char *stage_take(ssym_ctx *ctx, size_t bytes)
 {
     if (bytes > kStageMaxCopy)
         return nullptr;

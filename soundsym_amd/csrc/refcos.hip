@@ -152,6 +152,142 @@ __global__ __launch_bounds__(256) void refcos_sims_kernel(
         }
 }
 
+// ---------------------------------------------------------------------------------------------
+// ONE query against the dictionary in ONE launch: SoundDictionary::at_distance as the reference calls it, once per
+// target (src/sound.rs:351-370, 453-454).  The batched path above costs a single query ~10 stream operations
+// (pack copies, norm, similarity tile, two fold kernels, result copies) -- 125 us per call, almost all of it launch
+// chain.  Here the kernel reads the query straight from the pinned staging buffer, recomputes its norm (the same
+// sequential fold), gives every dictionary entry EIGHT lanes -- lane i keeps rulinalg's running sum p_i, so
+// the eight sums and their combination are exactly those of the tile kernel --, folds |sim - distance| to the
+// first minimum per workgroup, and the last workgroup to finish folds the workgroups in index order from the
+// reference's start value (0, 2.0) and writes index and value back into pinned memory.
+constexpr int kOneMaxVals = 4096;           // query values held in LDS
+constexpr int kOneEntries = 32;             // dictionary entries per 256-thread workgroup
+
+__global__ __launch_bounds__(256) void refcos_match_one_kernel(
+    const double *__restrict__ srcRaw, const uint64_t *__restrict__ srcOff, const double *__restrict__ srcNorm,
+    uint32_t nSrc, uint32_t dim, const void *__restrict__ query, int queryIsF32, uint32_t qLen, double distance,
+    double *__restrict__ partVal, uint32_t *__restrict__ partIdx, unsigned *__restrict__ ticket,
+    uint32_t *__restrict__ outIdx, double *__restrict__ outVal)
+{
+    __shared__ double sq[kOneMaxVals];
+    __shared__ double normQ;
+    __shared__ double cv[kOneEntries];
+    __shared__ uint32_t ci[kOneEntries];
+    __shared__ bool last;
+    const int tid = threadIdx.x;
+    for (uint32_t i = tid; i < qLen; i += 256)
+        sq[i] = queryIsF32 ? (double)static_cast<const float *>(query)[i] : static_cast<const double *>(query)[i];
+    __syncthreads();
+    if (tid == 255) {                               // norm(you), src/sound.rs:35-38: memo = item * item + memo
+        double memo = 0.0;
+        for (uint32_t i = 0; i < qLen; ++i)
+            memo = __dadd_rn(__dmul_rn(sq[i], sq[i]), memo);
+        normQ = memo;
+    }
+    const int i8 = tid & 7;
+    const uint32_t s = blockIdx.x * kOneEntries + (tid >> 3);
+    double v = __builtin_inf();
+    double dot = 0.0;
+    uint32_t len = 0;
+    unsigned long long base = 0;
+    if (s < nSrc) {
+        base = srcOff[s] * dim;
+        const uint32_t la = (uint32_t)((srcOff[s + 1] - srcOff[s]) * dim);
+        len = la < qLen ? la : qLen;                // src/sound.rs:24-28
+    }
+    const uint32_t qb = len / 8, rem = len % 8;
+    double p = 0.0;                                 // running sum p_i of rulinalg's dot
+    for (uint32_t k = 0; k < qb; ++k)
+        p = __dadd_rn(p, __dmul_rn(srcRaw[base + 8 * k + i8], sq[8 * k + i8]));
+    const int g0 = (tid & 63) & ~7;                 // first lane of this entry's group of eight
+    const double p0 = __shfl(p, g0 + 0), p1 = __shfl(p, g0 + 1), p2 = __shfl(p, g0 + 2), p3 = __shfl(p, g0 + 3);
+    const double p4 = __shfl(p, g0 + 4), p5 = __shfl(p, g0 + 5), p6 = __shfl(p, g0 + 6), p7 = __shfl(p, g0 + 7);
+    if (i8 == 0 && s < nSrc) {
+        double acc = 0.0;
+        acc = __dadd_rn(acc, __dadd_rn(p0, p4));
+        acc = __dadd_rn(acc, __dadd_rn(p1, p5));
+        acc = __dadd_rn(acc, __dadd_rn(p2, p6));
+        acc = __dadd_rn(acc, __dadd_rn(p3, p7));
+        for (uint32_t i = 0; i < rem; ++i)
+            acc = __dadd_rn(acc, __dmul_rn(srcRaw[base + 8 * qb + i], sq[8 * qb + i]));
+        dot = acc;
+    }
+    __syncthreads();                                // normQ
+    if (i8 == 0) {
+        if (s < nSrc) {
+            const double nrm = __dmul_rn(srcNorm[s], normQ);        // src/sound.rs:30
+            const double sim = __ddiv_rn(dot, nrm);                 // src/sound.rs:32
+            v = fabs(__dsub_rn(sim, distance));                     // src/sound.rs:359
+        }
+        cv[tid >> 3] = v;
+        ci[tid >> 3] = s;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // first minimum over this workgroup's entries in index order (NaN never wins, src/sound.rs:361-367)
+        double best = __builtin_inf();
+        uint32_t bi = 0xffffffffu;
+        for (int e = 0; e < kOneEntries; ++e)
+            if (cv[e] < best) {
+                best = cv[e];
+                bi = ci[e];
+            }
+        partVal[blockIdx.x] = best;
+        partIdx[blockIdx.x] = bi;
+        __threadfence();
+        last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last && tid == 0) {
+        __threadfence();
+        uint32_t minIdx = 0;                        // fold start (0usize, 2f64), src/sound.rs:361
+        double minVal = 2.0;
+        for (uint32_t b = 0; b < gridDim.x; ++b) {
+            const double pv = static_cast<volatile double *>(partVal)[b];
+            if (pv < minVal) {
+                minVal = pv;
+                minIdx = static_cast<volatile uint32_t *>(partIdx)[b];
+            }
+        }
+        *outIdx = minIdx;
+        *outVal = minVal;
+        *ticket = 0;                                // ready for the next call
+        __threadfence_system();
+    }
+}
+
+bool refcos_one_supported(const ssym_ctx *ctx, const SegmentSet &src, uint64_t n_frames)
+{
+    return ctx->metric == SSYM_METRIC_REFCOS && src.n > 0 && n_frames * src.dim <= (uint64_t)kOneMaxVals;
+}
+
+// query_dev: device-accessible (pinned) copy of the query in the context's dtype; out_pinned: 16 bytes, value then index
+int32_t launch_refcos_match_one(ssym_ctx *ctx, const SegmentSet &src, const void *query_dev, uint64_t n_frames,
+                                double distance, void *out_pinned)
+{
+    const uint32_t nb = (src.n + kOneEntries - 1) / kOneEntries;
+    int32_t rc = ensure(ctx, ctx->part, (sizeof(double) + sizeof(uint32_t)) * (size_t)nb + 256);
+    if (rc != SSYM_OK)
+        return rc;
+    if (!ctx->one_ticket.ptr) {
+        rc = ensure(ctx, ctx->one_ticket, 256);
+        if (rc != SSYM_OK)
+            return rc;
+        SSYM_HIP_CHECK(ctx, hipMemsetAsync(ctx->one_ticket.ptr, 0, 256, ctx->stream));
+    }
+    double *partVal = (double *)ctx->part.ptr;
+    uint32_t *partIdx = (uint32_t *)(partVal + nb);
+    double *outVal = (double *)out_pinned;
+    uint32_t *outIdx = (uint32_t *)(outVal + 1);
+    refcos_match_one_kernel<<<nb, 256, 0, ctx->stream>>>(src.raw, src.off, src.norm, src.n, src.dim, query_dev,
+                                                         ctx->dtype == SSYM_DTYPE_F32 ? 1 : 0,
+                                                         (uint32_t)(n_frames * src.dim), distance, partVal, partIdx,
+                                                         (unsigned *)ctx->one_ticket.ptr, outIdx, outVal);
+    SSYM_HIP_CHECK(ctx, hipGetLastError());
+    return SSYM_OK;
+}
+
 int32_t launch_refcos_sims(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, double *sims)
 {
     if (src.dim != tgt.dim) {

@@ -109,6 +109,7 @@ struct ssym_ctx {
     ssym::DeviceBuf abandon;    // SSYM_DTW_PRUNE: per-target-slot thresholds (f32, accumulator units) + cell counter
     ssym::DeviceBuf dist;       // per-target distance (f64)
     ssym::DeviceBuf part;       // refcos partial argmin
+    ssym::DeviceBuf one_ticket; // refcos_match_one_kernel: the "last workgroup" counter (zero between calls)
     ssym::DeviceBuf out_idx, out_cost;  // staging for host outputs
     hipEvent_t ev[8]{};
     float prune_swept = 1.f;               // share of the filter's cells the last pruned call swept (picks the pass height)
@@ -259,6 +260,11 @@ int32_t launch_chain_pairs(ssym_ctx *ctx, const uint32_t *cur, uint32_t n, uint2
 // refcos.hip
 int32_t launch_refcos_sims(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt,
                            double *sims /*[n_src][n_tgt]*/);
+// one query, one launch (ssym_match_one with the refcos metric)
+bool refcos_one_supported(const ssym_ctx *ctx, const SegmentSet &src, uint64_t n_frames);
+int32_t launch_refcos_match_one(ssym_ctx *ctx, const SegmentSet &src, const void *query_dev, uint64_t n_frames,
+                                double distance, void *out_pinned);
+char *stage_take(ssym_ctx *ctx, size_t bytes);      // pack.hip: room in the call's pinned window (NULL: none)
 int32_t launch_refcos_argmin(ssym_ctx *ctx, uint32_t n_src, uint32_t n_tgt, const double *sims,
                              const double *dist_dev, uint32_t index_base, uint32_t k_top,
                              uint32_t *out_idx_dev, double *out_cost_dev);

@@ -618,3 +618,33 @@ def test_dtw_exact_chunks_pipelined_over_waves(oracle, dim, dtype, lo, hi):
     idx, cost = e.match(d, q, force_exact=True)
     assert np.array_equal(idx, want.argmin(axis=0)) and np.allclose(cost, want.min(axis=0), rtol=1e-12, atol=0)
     e.close()
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_refcos_match_one_single_launch_equals_the_batched_path(oracle, dtype):
+    # ssym_match_one with the refcos metric is one kernel (refcos_match_one_kernel); it must return bit for bit what the
+    # batched path and the oracle return: ragged entries, empty entries, an empty query, lengths around the blocks of
+    # eight, distances on both sides of the similarities, a query longer than every entry
+    st = synth.Stream(0x5EED6100)
+    dim, n = 12, 333
+    lens = st.integers(n, 41)
+    lens[[5, 77]] = 0
+    src = [st.normal(int(f) * dim).reshape(int(f), dim) * 0.05 for f in lens]
+    npdt = np.float64 if dtype == "f64" else np.float32
+    sf, so = pack_segments(src, dim, npdt)
+    e = Engine(metric="refcos", dtype=dtype)
+    d = e.dictionary(sf, so, dim)
+    queries = [st.normal(int(f) * dim).reshape(int(f), dim) * 0.05 for f in [0, 1, 2, 7, 8, 9, 16, 23, 40, 41, 60, 300]]
+    queries.append(src[9].copy())
+    queries.append(np.full((3, dim), np.nan))
+    for qi, qf in enumerate(queries):
+        qv = np.ascontiguousarray(qf, dtype=npdt).reshape(-1)
+        for dist in (1.0, 0.0, 0.37, 1.9, -3.0):
+            idx, val = e.match_one(d, qv, dist)
+            assert e.timings()["main_launches"] == 1
+            tf, to = pack_segments([qf], dim, npdt)
+            bi, bv = e.match(d, e.queries(tf, to, dim), distance=np.array([dist]))
+            wi, wv = oracle.refcos_match_all(sf.astype(np.float64), so, tf.astype(np.float64), to, dim, np.array([dist]))
+            assert idx == int(bi[0]) == int(wi[0]), (qi, dist)
+            assert np.array_equal(np.array([val]), bv) and np.array_equal(bv, wv), (qi, dist, val, bv, wv)
+    e.close()
