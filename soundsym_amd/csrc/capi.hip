@@ -755,7 +755,16 @@ int32_t ssym_match_batch(ssym_ctx *ctx, const ssym_dict *dict, const void *tgt_f
     SSYM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     SSYM_HIP_CHECK(ctx, hipEventRecord(e0, ctx->stream));
     ctx->defer_sync = true;        // this call synchronises once, at the end of the match
+    // a handful of short dtw queries go to the exact kernel on every pair (match_impl, kFlagFewTargets): their
+    // pack can leave out everything only the filter needs
+    uint64_t maxQ = 0;
+    if (tgt_frame_offsets)
+        for (uint32_t i = 0; i < n_targets; ++i)
+            maxQ = std::max<uint64_t>(maxQ, tgt_frame_offsets[i + 1] - tgt_frame_offsets[i]);
+    ctx->pack_light = ctx->metric == SSYM_METRIC_DTW && n_targets <= 4 && (uint64_t)dict->set.n * n_targets <= 8192 &&
+                      dict->set.max_frames + maxQ <= 128;
     int32_t rc = ssym_queries_create(ctx, tgt_feats, tgt_frame_offsets, n_targets, dict->set.dim, &q);
+    ctx->pack_light = false;
     ctx->defer_sync = false;
     if (rc != SSYM_OK) {
         (void)hipStreamSynchronize(ctx->stream);      // the caller's buffers may go after an error too

@@ -107,6 +107,8 @@ static size_t band_lds_bytes(int radius, const SegmentSet &src, const SegmentSet
 
 bool filter_supported(const ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt)
 {
+    if (src.light || tgt.light)
+        return false;   // packed for the exact kernels only
     if (src.dim != tgt.dim)
         return false;   // (frames wider than 42 values: capi.hip decides, the filter is then a lower bound only)
     if (ctx->band >= 0) {

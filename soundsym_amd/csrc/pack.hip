@@ -239,6 +239,10 @@ static int32_t build_derived(ssym_ctx *ctx, SegmentSet &set)
         { int32_t rca = dev_alloc(ctx, (void **)&set.norm, sizeof(double) * n); if (rca != SSYM_OK) return rca; }
         segment_norm_kernel<<<(n + 63) / 64, 64, 0, st>>>(set.raw, set.off, n, dim, set.norm);
         SSYM_HIP_CHECK(ctx, hipGetLastError());
+    } else if (ctx->pack_light && !set.is_source) {
+        // a handful of short queries that will be scored by the exact kernel on every pair (capi.hip, kFlagFewTargets):
+        // no slot order, no statistics, no synchronisation for them
+        set.light = true;
     } else {
         // sources: 8 per workgroup; targets: groups of 32, 8 groups per workgroup in the banded kernel
         const uint32_t quantum = (!set.is_source && ctx->band >= 0) ? 256u : 32u;

@@ -59,6 +59,7 @@ struct SegmentSet {
     uint32_t n_pad = 0;
     uint32_t frames_pad = 0;        // record slots per segment
     bool is_source = false;
+    bool light = false;             // dtw targets packed without slot order and statistics: exact kernels only
     // f16 operand records, (re)built by dtw_filter.hip whenever the common scale changes
     mutable void *rec = nullptr;    // [n_pad][frames_pad][48] _Float16
     mutable double rec_scale = 0.0;
@@ -117,6 +118,7 @@ struct ssym_ctx {
     // set by ssym_match_batch / ssym_match_one around their internal pack: the call synchronises
     // once at its end, so the pack stages need not wait for their copies individually
     bool defer_sync = false;
+    bool pack_light = false;        // set by ssym_match_batch around the pack of a handful of short dtw queries
     // ssym_match_begin .. ssym_match_finish (two-phase match of a source-sharded run)
     struct Pending {
         bool valid = false, filter = false, has_dist = false;
