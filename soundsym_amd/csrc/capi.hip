@@ -750,6 +750,45 @@ int32_t ssym_match_batch(ssym_ctx *ctx, const ssym_dict *dict, const void *tgt_f
         return SSYM_E_EMPTY_DICT;
     }
     StageScope stageScope(ctx);       // one staging window for the pack and the match
+    // refcos, up to 64 short queries: the whole call in ONE launch (refcos.hip, refcos_match_one_kernel) -- queries,
+    // offsets and distances go into the pinned window, which the kernel reads and answers into directly
+    if (out_idx && tgt_feats && refcos_few_supported(ctx, dict->set, tgt_frame_offsets, n_targets)) {
+        const size_t esz = ctx->dtype == SSYM_DTYPE_F32 ? sizeof(float) : sizeof(double);
+        const uint64_t f0 = tgt_frame_offsets[0], f1 = tgt_frame_offsets[n_targets];
+        const size_t qBytes = (size_t)(f1 - f0) * dict->set.dim * esz;
+        char *qP = stage_take(ctx, qBytes ? qBytes : 8);
+        uint64_t *offP = (uint64_t *)stage_take(ctx, sizeof(uint64_t) * (n_targets + 1));
+        double *distP = distance ? (double *)stage_take(ctx, sizeof(double) * n_targets) : nullptr;
+        double *valP = (double *)stage_take(ctx, sizeof(double) * n_targets);
+        uint32_t *idxP = (uint32_t *)stage_take(ctx, sizeof(uint32_t) * n_targets);
+        if (qP && offP && valP && idxP && (distP || !distance)) {
+            SSYM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+            ctx->pending.cand = false;
+            ctx->pending.valid = false;
+            if (qBytes)
+                memcpy(qP, (const char *)tgt_feats + (size_t)f0 * dict->set.dim * esz, qBytes);
+            for (uint32_t i = 0; i <= n_targets; ++i)
+                offP[i] = tgt_frame_offsets[i] - f0;
+            if (distP)
+                memcpy(distP, distance, sizeof(double) * n_targets);
+            hipEvent_t *ev = ctx->ev;
+            SSYM_HIP_CHECK(ctx, hipEventRecord(ev[0], ctx->stream));
+            int32_t rcf = launch_refcos_match_few(ctx, dict->set, qP, offP, n_targets, distP, 1.0, valP, idxP);
+            if (rcf != SSYM_OK)
+                return rcf;
+            SSYM_HIP_CHECK(ctx, hipEventRecord(ev[1], ctx->stream));
+            SSYM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            memcpy(out_idx, idxP, sizeof(uint32_t) * n_targets);
+            if (out_cost)
+                memcpy(out_cost, valP, sizeof(double) * n_targets);
+            ssym_timings tm{};
+            tm.n_pairs = (uint64_t)dict->set.n * n_targets;
+            tm.main_ms = tm.total_ms = ev_ms(ev[0], ev[1]);
+            tm.main_launches = 1;
+            ctx->timings = tm;
+            return SSYM_OK;
+        }
+    }
     ssym_queries *q = nullptr;
     hipEvent_t e0 = ctx->ev[6], e1 = ctx->ev[7];
     SSYM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -785,37 +824,6 @@ int32_t ssym_match_batch(ssym_ctx *ctx, const ssym_dict *dict, const void *tgt_f
 int32_t ssym_match_one(ssym_ctx *ctx, const ssym_dict *dict, const void *feats, uint64_t n_frames,
                        double distance, uint32_t *out_idx, double *out_cost)
 {
-    // refcos: the whole call in one launch (refcos.hip, refcos_match_one_kernel)
-    if (ctx && dict && dict->set.n > 0 && out_idx && (feats || n_frames == 0) &&
-        refcos_one_supported(ctx, dict->set, n_frames)) {
-        StageScope stageScope(ctx);
-        SSYM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-        ctx->pending.cand = false;
-        ctx->pending.valid = false;
-        const size_t qBytes = (size_t)n_frames * dict->set.dim * (ctx->dtype == SSYM_DTYPE_F32 ? sizeof(float) : sizeof(double));
-        char *qPinned = stage_take(ctx, qBytes ? qBytes : 8);
-        char *outPinned = stage_take(ctx, 16);
-        if (qPinned && outPinned) {
-            if (qBytes)
-                memcpy(qPinned, feats, qBytes);
-            hipEvent_t *ev = ctx->ev;
-            SSYM_HIP_CHECK(ctx, hipEventRecord(ev[0], ctx->stream));
-            int32_t rc = launch_refcos_match_one(ctx, dict->set, qPinned, n_frames, distance, outPinned);
-            if (rc != SSYM_OK)
-                return rc;
-            SSYM_HIP_CHECK(ctx, hipEventRecord(ev[1], ctx->stream));
-            SSYM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-            *out_idx = *(const uint32_t *)(outPinned + 8);
-            if (out_cost)
-                *out_cost = *(const double *)outPinned;
-            ssym_timings tm{};
-            tm.n_pairs = dict->set.n;
-            tm.main_ms = tm.total_ms = ev_ms(ev[0], ev[1]);
-            tm.main_launches = 1;
-            ctx->timings = tm;
-            return SSYM_OK;
-        }
-    }
     const uint64_t off[2] = {0, n_frames};
     return ssym_match_batch(ctx, dict, feats, off, 1, &distance, out_idx, out_cost);
 }

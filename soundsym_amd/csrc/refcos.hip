@@ -163,13 +163,27 @@ __global__ __launch_bounds__(256) void refcos_sims_kernel(
 // reference's start value (0, 2.0) and writes index and value back into pinned memory.
 constexpr int kOneMaxVals = 4096;           // query values held in LDS
 constexpr int kOneEntries = 32;             // dictionary entries per 256-thread workgroup
+constexpr uint32_t kFewMaxQueries = 64;     // queries per call on this path
 
 __global__ __launch_bounds__(256) void refcos_match_one_kernel(
     const double *__restrict__ srcRaw, const uint64_t *__restrict__ srcOff, const double *__restrict__ srcNorm,
-    uint32_t nSrc, uint32_t dim, const void *__restrict__ query, int queryIsF32, uint32_t qLen, double distance,
-    double *__restrict__ partVal, uint32_t *__restrict__ partIdx, unsigned *__restrict__ ticket,
-    uint32_t *__restrict__ outIdx, double *__restrict__ outVal)
+    uint32_t nSrc, uint32_t dim, const void *__restrict__ queries, const uint64_t *__restrict__ qOff /* frames */,
+    int queryIsF32, const double *__restrict__ distances /* NULL: defaultDist */, double defaultDist,
+    double *__restrict__ partValAll, uint32_t *__restrict__ partIdxAll, unsigned *__restrict__ tickets,
+    uint32_t *__restrict__ outIdxAll, double *__restrict__ outValAll)
 {
+    // blockIdx.y = the query (a handful per call: ssym_match_one, small ssym_match_batch calls)
+    const uint32_t y = blockIdx.y;
+    const unsigned long long qBase = qOff[y] * dim;
+    const uint32_t qLen = (uint32_t)((qOff[y + 1] - qOff[y]) * dim);
+    const void *query = queryIsF32 ? (const void *)(static_cast<const float *>(queries) + qBase)
+                                   : (const void *)(static_cast<const double *>(queries) + qBase);
+    const double distance = distances ? distances[y] : defaultDist;
+    double *partVal = partValAll + (size_t)y * gridDim.x;
+    uint32_t *partIdx = partIdxAll + (size_t)y * gridDim.x;
+    unsigned *ticket = tickets + y;
+    uint32_t *outIdx = outIdxAll + y;
+    double *outVal = outValAll + y;
     __shared__ double sq[kOneMaxVals];
     __shared__ double normQ;
     __shared__ double cv[kOneEntries];
@@ -257,33 +271,37 @@ __global__ __launch_bounds__(256) void refcos_match_one_kernel(
     }
 }
 
-bool refcos_one_supported(const ssym_ctx *ctx, const SegmentSet &src, uint64_t n_frames)
+bool refcos_few_supported(const ssym_ctx *ctx, const SegmentSet &src, const uint64_t *q_off, uint32_t n_queries)
 {
-    return ctx->metric == SSYM_METRIC_REFCOS && src.n > 0 && n_frames * src.dim <= (uint64_t)kOneMaxVals;
+    if (ctx->metric != SSYM_METRIC_REFCOS || src.n == 0 || n_queries == 0 || n_queries > kFewMaxQueries || !q_off)
+        return false;
+    for (uint32_t i = 0; i < n_queries; ++i)
+        if (q_off[i + 1] < q_off[i] || (q_off[i + 1] - q_off[i]) * src.dim > (uint64_t)kOneMaxVals)
+            return false;
+    return true;
 }
 
-// query_dev: device-accessible (pinned) copy of the query in the context's dtype; out_pinned: 16 bytes, value then index
-int32_t launch_refcos_match_one(ssym_ctx *ctx, const SegmentSet &src, const void *query_dev, uint64_t n_frames,
-                                double distance, void *out_pinned)
+// queries / q_off / distances: device-accessible (pinned) copies -- features in the context's dtype, offsets in frames
+// rebased to 0, distances or NULL; out_val / out_idx: pinned, n_queries entries each
+int32_t launch_refcos_match_few(ssym_ctx *ctx, const SegmentSet &src, const void *queries, const uint64_t *q_off,
+                                uint32_t n_queries, const double *distances, double default_dist, double *out_val,
+                                uint32_t *out_idx)
 {
     const uint32_t nb = (src.n + kOneEntries - 1) / kOneEntries;
-    int32_t rc = ensure(ctx, ctx->part, (sizeof(double) + sizeof(uint32_t)) * (size_t)nb + 256);
+    int32_t rc = ensure(ctx, ctx->part, (sizeof(double) + sizeof(uint32_t)) * (size_t)nb * n_queries + 256);
     if (rc != SSYM_OK)
         return rc;
     if (!ctx->one_ticket.ptr) {
-        rc = ensure(ctx, ctx->one_ticket, 256);
+        rc = ensure(ctx, ctx->one_ticket, sizeof(unsigned) * kFewMaxQueries);
         if (rc != SSYM_OK)
             return rc;
-        SSYM_HIP_CHECK(ctx, hipMemsetAsync(ctx->one_ticket.ptr, 0, 256, ctx->stream));
+        SSYM_HIP_CHECK(ctx, hipMemsetAsync(ctx->one_ticket.ptr, 0, sizeof(unsigned) * kFewMaxQueries, ctx->stream));
     }
     double *partVal = (double *)ctx->part.ptr;
-    uint32_t *partIdx = (uint32_t *)(partVal + nb);
-    double *outVal = (double *)out_pinned;
-    uint32_t *outIdx = (uint32_t *)(outVal + 1);
-    refcos_match_one_kernel<<<nb, 256, 0, ctx->stream>>>(src.raw, src.off, src.norm, src.n, src.dim, query_dev,
-                                                         ctx->dtype == SSYM_DTYPE_F32 ? 1 : 0,
-                                                         (uint32_t)(n_frames * src.dim), distance, partVal, partIdx,
-                                                         (unsigned *)ctx->one_ticket.ptr, outIdx, outVal);
+    uint32_t *partIdx = (uint32_t *)(partVal + (size_t)nb * n_queries);
+    refcos_match_one_kernel<<<dim3(nb, n_queries), 256, 0, ctx->stream>>>(
+        src.raw, src.off, src.norm, src.n, src.dim, queries, q_off, ctx->dtype == SSYM_DTYPE_F32 ? 1 : 0, distances,
+        default_dist, partVal, partIdx, (unsigned *)ctx->one_ticket.ptr, out_idx, out_val);
     SSYM_HIP_CHECK(ctx, hipGetLastError());
     return SSYM_OK;
 }

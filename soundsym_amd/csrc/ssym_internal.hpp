@@ -263,9 +263,10 @@ int32_t launch_chain_pairs(ssym_ctx *ctx, const uint32_t *cur, uint32_t n, uint2
 int32_t launch_refcos_sims(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt,
                            double *sims /*[n_src][n_tgt]*/);
 // one query, one launch (ssym_match_one with the refcos metric)
-bool refcos_one_supported(const ssym_ctx *ctx, const SegmentSet &src, uint64_t n_frames);
-int32_t launch_refcos_match_one(ssym_ctx *ctx, const SegmentSet &src, const void *query_dev, uint64_t n_frames,
-                                double distance, void *out_pinned);
+bool refcos_few_supported(const ssym_ctx *ctx, const SegmentSet &src, const uint64_t *q_off, uint32_t n_queries);
+int32_t launch_refcos_match_few(ssym_ctx *ctx, const SegmentSet &src, const void *queries, const uint64_t *q_off,
+                                uint32_t n_queries, const double *distances, double default_dist, double *out_val,
+                                uint32_t *out_idx);
 char *stage_take(ssym_ctx *ctx, size_t bytes);      // pack.hip: room in the call's pinned window (NULL: none)
 int32_t launch_refcos_argmin(ssym_ctx *ctx, uint32_t n_src, uint32_t n_tgt, const double *sims,
                              const double *dist_dev, uint32_t index_base, uint32_t k_top,

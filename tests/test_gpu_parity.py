@@ -647,4 +647,17 @@ def test_refcos_match_one_single_launch_equals_the_batched_path(oracle, dtype):
             wi, wv = oracle.refcos_match_all(sf.astype(np.float64), so, tf.astype(np.float64), to, dim, np.array([dist]))
             assert idx == int(bi[0]) == int(wi[0]), (qi, dist)
             assert np.array_equal(np.array([val]), bv) and np.array_equal(bv, wv), (qi, dist, val, bv, wv)
+    # the same kernel takes a small batch (ssym_match_batch with up to 64 short queries), with and without distances
+    tf, to = pack_segments(queries, dim, npdt)
+    for dist in (None, 0.2 + 0.1 * np.arange(len(queries))):
+        bi, bv = e.match_batch(d, tf, to, dist)
+        assert e.timings()["main_launches"] == 1
+        ri, rv = e.match(d, e.queries(tf, to, dim), distance=dist)            # resident queries: the tiled path
+        wi, wv = oracle.refcos_match_all(sf.astype(np.float64), so, tf.astype(np.float64), to, dim, dist)
+        assert np.array_equal(bi, ri) and np.array_equal(bi, wi)
+        assert np.array_equal(bv, rv) and np.array_equal(bv, wv)
+    # offsets that do not start at 0 (frame_offsets index into the buffer they come with)
+    full_i, full_v = e.match_batch(d, tf, to, None)
+    bi2, bv2 = e.match_batch(d, tf, to[3:], None)
+    assert np.array_equal(bi2, full_i[3:]) and np.array_equal(bv2, full_v[3:])
     e.close()
