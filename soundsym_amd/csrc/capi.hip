@@ -750,9 +750,12 @@ int32_t ssym_match_batch(ssym_ctx *ctx, const ssym_dict *dict, const void *tgt_f
         return SSYM_E_EMPTY_DICT;
     }
     StageScope stageScope(ctx);       // one staging window for the pack and the match
-    // refcos, up to 64 short queries: the whole call in ONE launch (refcos.hip, refcos_match_one_kernel) -- queries,
-    // offsets and distances go into the pinned window, which the kernel reads and answers into directly
-    if (out_idx && tgt_feats && refcos_few_supported(ctx, dict->set, tgt_frame_offsets, n_targets)) {
+    // refcos, up to 64 short queries -- or dtw, up to 4 short queries against short entries: the whole call in ONE launch
+    // (refcos_match_one_kernel / dtw_match_few_kernel); queries, offsets and distances go into the pinned window,
+    // which the kernel reads and answers into directly
+    const bool fewRefcos = out_idx && tgt_feats && refcos_few_supported(ctx, dict->set, tgt_frame_offsets, n_targets);
+    const bool fewDtw = out_idx && tgt_feats && dtw_few_supported(ctx, dict->set, tgt_frame_offsets, n_targets);
+    if (fewRefcos || fewDtw) {
         const size_t esz = ctx->dtype == SSYM_DTYPE_F32 ? sizeof(float) : sizeof(double);
         const uint64_t f0 = tgt_frame_offsets[0], f1 = tgt_frame_offsets[n_targets];
         const size_t qBytes = (size_t)(f1 - f0) * dict->set.dim * esz;
@@ -773,7 +776,8 @@ int32_t ssym_match_batch(ssym_ctx *ctx, const ssym_dict *dict, const void *tgt_f
                 memcpy(distP, distance, sizeof(double) * n_targets);
             hipEvent_t *ev = ctx->ev;
             SSYM_HIP_CHECK(ctx, hipEventRecord(ev[0], ctx->stream));
-            int32_t rcf = launch_refcos_match_few(ctx, dict->set, qP, offP, n_targets, distP, 1.0, valP, idxP);
+            int32_t rcf = fewRefcos ? launch_refcos_match_few(ctx, dict->set, qP, offP, n_targets, distP, 1.0, valP, idxP)
+                                    : launch_dtw_match_few(ctx, dict->set, qP, offP, n_targets, distP, valP, idxP);
             if (rcf != SSYM_OK)
                 return rcf;
             SSYM_HIP_CHECK(ctx, hipEventRecord(ev[1], ctx->stream));

@@ -561,6 +561,175 @@ __global__ __launch_bounds__(512) void dtw_exact_pipe_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// A handful of short queries against a dictionary of short entries in ONE launch (ssym_match_one / small
+// ssym_match_batch calls with the dtw metric: the reference's one-query-at-a-time pattern).  One wave per
+// (entry, query) pair: lane = entry frame (entries of at most 64 frames: one chunk, no boundary rows), the
+// entry's frame in registers, the query's frames zero-padded to 16 values in LDS, the same wavefront and the
+// same operations per cell as the kernels above; then |cost - distance| is folded to the first minimum per
+// workgroup, and the last workgroup of a query folds the workgroups in index order and writes index and cost
+// into pinned memory.  The queries are read from the pinned staging window: no pack, no copies.
+constexpr int kFewDim = 16;                 // values per frame (zero-padded)
+constexpr int kFewQVals = 2048;             // query frames x 16 held in LDS
+constexpr int kFewWaves = 16;               // entries per workgroup (every workgroup pulls the query over PCIe: few, large ones)
+
+__global__ __launch_bounds__(64 * kFewWaves) void dtw_match_few_kernel(
+    const double *__restrict__ srcRaw, const uint64_t *__restrict__ srcOff, uint32_t nSrc, uint32_t dim,
+    const void *__restrict__ queries, const uint64_t *__restrict__ qOff, int queryIsF32,
+    const double *__restrict__ distances, int band, int squared, double *__restrict__ partKeyAll,
+    double *__restrict__ partCostAll, uint32_t *__restrict__ partIdxAll, unsigned *__restrict__ tickets,
+    uint32_t *__restrict__ outIdxAll, double *__restrict__ outCostAll)
+{
+    __shared__ __attribute__((aligned(16))) double sq[kFewQVals];
+    __shared__ double ck[kFewWaves], cc[kFewWaves];
+    __shared__ bool last;
+    const double INF = __builtin_inf();
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t y = blockIdx.y;
+    const int Fb = (int)(qOff[y + 1] - qOff[y]);
+    const unsigned long long qBase = qOff[y] * dim;
+    for (int i = tid; i < Fb * kFewDim; i += 64 * kFewWaves) {
+        const int fr = i / kFewDim, e = i % kFewDim;
+        double v = 0.0;
+        if (e < (int)dim)
+            v = queryIsF32 ? (double)static_cast<const float *>(queries)[qBase + (size_t)fr * dim + e]
+                           : static_cast<const double *>(queries)[qBase + (size_t)fr * dim + e];
+        sq[i] = v;
+    }
+    __syncthreads();
+
+    const uint32_t s = blockIdx.x * kFewWaves + wave;
+    const int Fa = s < nSrc ? (int)(srcOff[s + 1] - srcOff[s]) : 0;
+    double result = INF;
+    if (Fa > 0 && Fb > 0) {
+        const bool rowValid = lane < Fa;
+        double ar[kFewDim];
+        {
+            const double *arow = srcRaw + (srcOff[s] + (rowValid ? lane : 0)) * dim;
+#pragma unroll
+            for (int e = 0; e < kFewDim; ++e)
+                ar[e] = e < (int)dim ? arow[e] : 0.0;
+        }
+        int jlo = 0, jhi = Fb - 1;
+        if (band >= 0)
+            jhi = min(Fb - 1, Fa - 1 + band);
+        double mine = INF, diagReg = INF;
+        const int tauEnd = jhi + Fa;
+        for (int tau = jlo; tau < tauEnd; ++tau) {
+            const int j = tau - lane;
+            double fromAbove = shfl_up1(mine);
+            double diagv = diagReg;
+            if (lane == 0) {
+                fromAbove = INF;
+                diagv = (j == 0) ? 0.0 : INF;             // virtual D(-1,-1) = 0
+            }
+            const bool active = rowValid && j >= 0 && j < Fb;
+            if (active) {
+                double cur = INF;
+                const int dij = lane - j;
+                if (band < 0 || (dij <= band && -dij <= band)) {
+                    const double *bj = sq + (size_t)j * kFewDim;
+                    double acc = 0.0;                     // sum_k (a_k - b_k)^2, k ascending; (0 - 0)^2 = +0 changes nothing
+#pragma unroll
+                    for (int e = 0; e < kFewDim; ++e) {
+                        const double df = __dsub_rn(ar[e], bj[e]);
+                        acc = __dadd_rn(acc, __dmul_rn(df, df));
+                    }
+                    const double c = squared ? acc : sqrt(acc);
+                    double best = fromAbove;
+                    if (mine < best) best = mine;
+                    if (diagv < best) best = diagv;
+                    cur = __dadd_rn(c, best);
+                }
+                if (lane == Fa - 1 && j == Fb - 1)
+                    result = cur;
+                mine = cur;
+            }
+            diagReg = fromAbove;
+        }
+    }
+    // the pair's cost sits in lane Fa - 1 (or nowhere: +inf)
+    const int owner = Fa > 0 ? Fa - 1 : 0;
+    const double cost = __shfl(result, owner);
+    const double distance = distances ? distances[y] : 0.0;
+    if (lane == 0) {
+        cc[wave] = s < nSrc ? cost : INF;
+        ck[wave] = s < nSrc ? fabs(__dsub_rn(cost, distance)) : INF;
+    }
+    __syncthreads();
+    const uint32_t nb = gridDim.x;
+    double *partKey = partKeyAll + (size_t)y * nb, *partCost = partCostAll + (size_t)y * nb;
+    uint32_t *partIdx = partIdxAll + (size_t)y * nb;
+    if (tid == 0) {
+        double best = INF, bc = INF;
+        uint32_t bi = 0xffffffffu;
+        for (int w = 0; w < kFewWaves; ++w)
+            if (ck[w] < best) {                           // first minimum in index order, NaN never wins
+                best = ck[w];
+                bc = cc[w];
+                bi = blockIdx.x * kFewWaves + w;
+            }
+        partKey[blockIdx.x] = best;
+        partCost[blockIdx.x] = bc;
+        partIdx[blockIdx.x] = bi;
+        __threadfence();
+        last = atomicAdd(&tickets[y], 1u) == nb - 1;
+    }
+    __syncthreads();
+    if (last && tid == 0) {
+        __threadfence();
+        uint32_t minIdx = 0;                              // the fold's start for dtw: (0, +inf)
+        double minKey = INF, minCost = INF;
+        for (uint32_t b = 0; b < nb; ++b) {
+            const double pk = static_cast<volatile double *>(partKey)[b];
+            if (pk < minKey) {
+                minKey = pk;
+                minCost = static_cast<volatile double *>(partCost)[b];
+                minIdx = static_cast<volatile uint32_t *>(partIdx)[b];
+            }
+        }
+        outIdxAll[y] = minIdx;
+        outCostAll[y] = minCost;                          // dtw reports the winner's cost itself (+inf: nothing finite)
+        tickets[y] = 0;
+        __threadfence_system();
+    }
+}
+
+bool dtw_few_supported(const ssym_ctx *ctx, const SegmentSet &src, const uint64_t *q_off, uint32_t n_queries)
+{
+    if (ctx->metric != SSYM_METRIC_DTW || src.n == 0 || n_queries == 0 || n_queries > 4 || !q_off || src.dim > (uint32_t)kFewDim ||
+        src.max_frames > 64 || (uint64_t)src.n * n_queries > 8192)
+        return false;
+    for (uint32_t i = 0; i < n_queries; ++i)
+        if (q_off[i + 1] < q_off[i] || (q_off[i + 1] - q_off[i]) * kFewDim > (uint64_t)kFewQVals)
+            return false;
+    return true;
+}
+
+// queries / q_off / distances / outputs: pinned, as for launch_refcos_match_few
+int32_t launch_dtw_match_few(ssym_ctx *ctx, const SegmentSet &src, const void *queries, const uint64_t *q_off,
+                             uint32_t n_queries, const double *distances, double *out_cost, uint32_t *out_idx)
+{
+    const uint32_t nb = (src.n + kFewWaves - 1) / kFewWaves;
+    int32_t rc = ensure(ctx, ctx->part, (2 * sizeof(double) + sizeof(uint32_t)) * (size_t)nb * n_queries + 256);
+    if (rc != SSYM_OK)
+        return rc;
+    if (!ctx->one_ticket.ptr) {
+        rc = ensure(ctx, ctx->one_ticket, 256);
+        if (rc != SSYM_OK)
+            return rc;
+        SSYM_HIP_CHECK(ctx, hipMemsetAsync(ctx->one_ticket.ptr, 0, 256, ctx->stream));
+    }
+    double *partKey = (double *)ctx->part.ptr;
+    double *partCost = partKey + (size_t)nb * n_queries;
+    uint32_t *partIdx = (uint32_t *)(partCost + (size_t)nb * n_queries);
+    dtw_match_few_kernel<<<dim3(nb, n_queries), 64 * kFewWaves, 0, ctx->stream>>>(
+        src.raw, src.off, src.n, src.dim, queries, q_off, ctx->dtype == SSYM_DTYPE_F32 ? 1 : 0, distances, ctx->band,
+        ctx->squared, partKey, partCost, partIdx, (unsigned *)ctx->one_ticket.ptr, out_idx, out_cost);
+    SSYM_HIP_CHECK(ctx, hipGetLastError());
+    return SSYM_OK;
+}
+
 int32_t launch_dtw_exact(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt,
                          const uint2 *pairs, const uint32_t *count_dev, uint32_t max_pairs,
                          double *out)

@@ -267,6 +267,9 @@ bool refcos_few_supported(const ssym_ctx *ctx, const SegmentSet &src, const uint
 int32_t launch_refcos_match_few(ssym_ctx *ctx, const SegmentSet &src, const void *queries, const uint64_t *q_off,
                                 uint32_t n_queries, const double *distances, double default_dist, double *out_val,
                                 uint32_t *out_idx);
+bool dtw_few_supported(const ssym_ctx *ctx, const SegmentSet &src, const uint64_t *q_off, uint32_t n_queries);
+int32_t launch_dtw_match_few(ssym_ctx *ctx, const SegmentSet &src, const void *queries, const uint64_t *q_off,
+                             uint32_t n_queries, const double *distances, double *out_cost, uint32_t *out_idx);
 char *stage_take(ssym_ctx *ctx, size_t bytes);      // pack.hip: room in the call's pinned window (NULL: none)
 int32_t launch_refcos_argmin(ssym_ctx *ctx, uint32_t n_src, uint32_t n_tgt, const double *sims,
                              const double *dist_dev, uint32_t index_base, uint32_t k_top,

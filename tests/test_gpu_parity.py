@@ -661,3 +661,50 @@ def test_refcos_match_one_single_launch_equals_the_batched_path(oracle, dtype):
     bi2, bv2 = e.match_batch(d, tf, to[3:], None)
     assert np.array_equal(bi2, full_i[3:]) and np.array_equal(bv2, full_v[3:])
     e.close()
+
+
+@pytest.mark.parametrize("dtype,dim,band,squared", [("f64", 12, -1, False), ("f32", 13, -1, False), ("f64", 16, 5, False),
+                                                    ("f32", 5, -1, True), ("f64", 13, 0, True)])
+def test_dtw_few_queries_single_launch_equals_the_batched_path(oracle, dtype, dim, band, squared):
+    # ssym_match_one / ssym_match_batch with up to 4 short dtw queries against short entries is one kernel
+    # (dtw_match_few_kernel): same indices and costs as the resident-queries path and as the oracle
+    st = synth.Stream(0x5EED6200 + dim + band)
+    n = 257
+    lens = st.integers(n, 65)
+    lens[[3, 100]] = 0
+    lens[7] = 64
+    src = [st.normal(int(f) * dim).reshape(int(f), dim) * synth.sigma(dim) for f in lens]
+    src[20] = src[11].copy()                                   # a tie: the lower index wins
+    npdt = np.float64 if dtype == "f64" else np.float32
+    sf, so = pack_segments(src, dim, npdt)
+    e = Engine(metric="dtw", dtype=dtype, band=band, squared=squared)
+    d = e.dictionary(sf, so, dim)
+    queries = [st.normal(int(f) * dim).reshape(int(f), dim) * synth.sigma(dim) for f in [0, 1, 9, 33, 64, 100, 128]]
+    queries.append(src[11].astype(npdt).astype(np.float64))
+    queries.append(src[7][:40].astype(npdt).astype(np.float64) + 0.01)
+    for qi, qf in enumerate(queries):
+        qv = np.ascontiguousarray(qf, dtype=npdt).reshape(-1)
+        for dist in (0.0, 25.0):
+            idx, val = e.match_one(d, qv, dist)
+            assert e.timings()["main_launches"] == 1, qi
+            tf, to = pack_segments([qf], dim, npdt)
+            bi, bv = e.match(d, e.queries(tf, to, dim), distance=np.array([dist]), force_exact=True)
+            assert idx == int(bi[0]), (qi, dist, idx, bi)
+            assert np.array_equal(np.array([val]), bv), (qi, dist, val, bv)
+            _, _, mat = oracle.dtw_match_all(sf.astype(np.float64), so, tf.astype(np.float64), to, dim, band=band,
+                                             squared=squared, want_matrix=True)
+            key = np.abs(mat[:, 0] - dist)
+            key = np.where(np.isnan(key), np.inf, key)
+            if np.isfinite(key).any():
+                assert idx == int(key.argmin()) and np.isclose(val, mat[idx, 0], rtol=1e-12, atol=0)
+            else:
+                assert idx == 0 and np.isinf(val)
+    # four queries at once, per-query distances
+    four = queries[2:6]
+    tf, to = pack_segments(four, dim, npdt)
+    dist = np.array([0.0, 10.0, 0.0, 40.0])
+    bi, bv = e.match_batch(d, tf, to, dist)
+    assert e.timings()["main_launches"] == 1
+    ri, rv = e.match(d, e.queries(tf, to, dim), distance=dist, force_exact=True)
+    assert np.array_equal(bi, ri) and np.array_equal(bv, rv)
+    e.close()
