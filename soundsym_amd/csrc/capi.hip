@@ -405,7 +405,7 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
         // 81 us against 227 us per call; from 16 queries on the filter path is the shorter one)
         const bool fewPairs = (flags & kFlagFewTargets) && (uint64_t)N * M <= 8192 && src.max_frames + tgt.max_frames <= 128;
         const bool useFilter = !(flags & SSYM_DTW_FORCE_EXACT) && !fewPairs && filter_supported(ctx, src, tgt) &&
-                               (!wide || (k_top == 1 && !(phase == 2 ? ctx->pending.has_dist : distance != nullptr)));
+                               (!wide || !(phase == 2 ? ctx->pending.has_dist : distance != nullptr));
         tm.used_filter = useFilter ? 1 : 0;
         if (useFilter) {
             rc = ensure(ctx, ctx->cmat, sizeof(float) * (size_t)src.n_pad * tgt.n_pad);
@@ -439,7 +439,7 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
                 if (prune)
                     SSYM_HIP_CHECK(ctx, hipMemcpyAsync(&ctx->pruned_cells, colCtr, sizeof(*colCtr),
                                                        hipMemcpyDeviceToHost, st));
-                rc = wide ? launch_dtw_bounds_partial(ctx, src, tgt, cmat, prune ? (const double *)ctx->prune_cost.ptr : nullptr)
+                rc = wide ? launch_dtw_bounds_partial(ctx, src, tgt, cmat, prune ? (const double *)ctx->prune_cost.ptr : nullptr, k_top)
                           : launch_dtw_bounds(ctx, src, tgt, cmat, distDev, k_top,
                                               prune ? (const double *)ctx->prune_cost.ptr : nullptr);
                 if (rc != SSYM_OK)

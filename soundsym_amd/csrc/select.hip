@@ -654,6 +654,62 @@ __global__ __launch_bounds__(256) void dtw_partial_argmin_kernel(const float *__
     pairs[t] = make_uint2(permS[bs], permT[t]);                    // exact kernel: the caller's indices
 }
 
+// top-k on wide frames: the k pairs the filter likes best per target (their exact costs bound the k-th best from above)
+constexpr int kPartialKMax = (int)SSYM_TOPK_MAX;
+__global__ __launch_bounds__(256) void dtw_partial_topk_kernel(const float *__restrict__ cmat, uint32_t nSrc, uint32_t nTgt,
+                                                               uint32_t mPad, const uint32_t *__restrict__ permS,
+                                                               const uint32_t *__restrict__ permT, uint32_t k,
+                                                               uint32_t *__restrict__ hdr, uint2 *__restrict__ pairs,
+                                                               uint32_t *__restrict__ found)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;      // target slot
+    if (t == 0)
+        hdr[0] = nTgt * k, hdr[1] = 0;
+    if (t >= nTgt)
+        return;
+    float bc[kPartialKMax];
+    uint32_t bs[kPartialKMax];
+    uint32_t cnt = 0;
+    for (uint32_t s = 0; s < nSrc; ++s) {
+        const float c = cmat[(size_t)s * mPad + t];
+        if (!(c < __builtin_inff()))
+            continue;
+        if (cnt == k && !(c < bc[k - 1]))
+            continue;
+        uint32_t pos = cnt < k ? cnt : k - 1;                    // insertion into the ascending list of at most k
+        while (pos > 0 && c < bc[pos - 1]) {
+            bc[pos] = bc[pos - 1];
+            bs[pos] = bs[pos - 1];
+            --pos;
+        }
+        bc[pos] = c;
+        bs[pos] = s;
+        if (cnt < k)
+            ++cnt;
+    }
+    for (uint32_t r = 0; r < k; ++r)                                // (short lists repeat a pair: the threshold is +inf then)
+        pairs[(size_t)t * k + r] = make_uint2(permS[r < cnt ? bs[r] : (cnt ? bs[0] : 0)], permT[t]);
+    found[t] = cnt;
+}
+
+__global__ void dtw_partial_topk_threshold_kernel(const double *__restrict__ exact, const uint32_t *__restrict__ found,
+                                                  uint32_t nTgt, uint32_t k, unsigned long long *__restrict__ ub)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nTgt)
+        return;
+    double worst = 0.0;
+    bool ok = found[t] >= k;
+    for (uint32_t r = 0; r < k && ok; ++r) {
+        const double c = exact[(size_t)t * k + r];
+        if (!(c < __builtin_inf()))
+            ok = false;                                             // NaN / +inf: no bound from this pair
+        else
+            worst = c > worst ? c : worst;
+    }
+    ub[t] = ok ? (unsigned long long)__double_as_longlong(worst) : kInfBits;
+}
+
 __global__ void dtw_partial_threshold_kernel(const double *__restrict__ exact, const double *__restrict__ seed,
                                              uint32_t nTgt, unsigned long long *__restrict__ ub)
 {
@@ -672,8 +728,36 @@ __global__ void dtw_partial_threshold_kernel(const double *__restrict__ exact, c
 }
 
 int32_t launch_dtw_bounds_partial(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, const float *cmat,
-                                  const double *seed_by_slot)
+                                  const double *seed_by_slot, uint32_t k_top)
 {
+    if (k_top > 1) {
+        // the k-th best cost of a target is at most the largest exact cost among ANY k of its pairs: take the k the
+        // filter likes best
+        hipStream_t st = ctx->stream;
+        const size_t nk = (size_t)tgt.n * k_top;
+        int32_t rc = ensure(ctx, ctx->tmin, sizeof(unsigned long long) * tgt.n);
+        if (rc == SSYM_OK)
+            rc = ensure(ctx, ctx->cand2, sizeof(uint32_t) * 2 + sizeof(uint2) * nk);
+        if (rc == SSYM_OK)
+            rc = ensure(ctx, ctx->cand_cost, sizeof(double) * nk);
+        if (rc == SSYM_OK)
+            rc = ensure(ctx, ctx->selcnt, sizeof(uint32_t) * 2 * (size_t)tgt.n);
+        if (rc != SSYM_OK)
+            return rc;
+        uint32_t *hdr = (uint32_t *)ctx->cand2.ptr;
+        uint2 *pairs = (uint2 *)(hdr + 2);
+        uint32_t *found = (uint32_t *)ctx->selcnt.ptr;
+        const unsigned tb = (tgt.n + 255) / 256;
+        dtw_partial_topk_kernel<<<tb, 256, 0, st>>>(cmat, src.n, tgt.n, tgt.n_pad, src.perm, tgt.perm, k_top, hdr, pairs, found);
+        SSYM_HIP_CHECK(ctx, hipGetLastError());
+        rc = launch_dtw_exact(ctx, src, tgt, pairs, hdr, (uint32_t)nk, (double *)ctx->cand_cost.ptr);
+        if (rc != SSYM_OK)
+            return rc;
+        dtw_partial_topk_threshold_kernel<<<tb, 256, 0, st>>>((const double *)ctx->cand_cost.ptr, found, tgt.n, k_top,
+                                                              (unsigned long long *)ctx->tmin.ptr);
+        SSYM_HIP_CHECK(ctx, hipGetLastError());
+        return SSYM_OK;
+    }
     hipStream_t st = ctx->stream;
     int32_t rc = ensure(ctx, ctx->tmin, sizeof(unsigned long long) * tgt.n);
     if (rc == SSYM_OK)

@@ -568,7 +568,7 @@ def test_dtw_wide_frames_use_the_filter_as_a_lower_bound(oracle, dim, band):
         assert np.all(fm[ok] <= mat[ok] + 2e-3 * (1.0 + mat[ok]) + 2.0 ** -11 * 2 * 12.0 * lens[ok])
     else:
         assert tm["used_filter"] == 0                        # band beyond the filter's reach: exact kernel
-    # per-target distances and top-k on wide frames go through the exact kernel on every pair
+    # per-target distances on wide frames go through the exact kernel on every pair (top-k: tests/test_gpu_topk.py)
     dist = np.nanmedian(np.where(np.isfinite(mat), mat, np.nan), axis=0)
     dist = np.nan_to_num(dist, nan=1.0)
     i2, c2 = e.match(d, q, distance=dist)

@@ -140,3 +140,31 @@ def test_dtw_topk_medium_unplanted(dtw, oracle):
     want_idx, _ = oracle.topk(mat, k, default_distance=0.0, fold_start=float("inf"))
     want_cost = mat[want_idx, np.arange(m)[:, None]]
     _check_rows(idx, cost, want_idx, want_cost, exact=False)
+
+
+@pytest.mark.parametrize("dim,f,k,band", [(50, 40, 3, -1), (64, 70, 5, -1), (90, 33, 2, -1), (64, 48, 4, 12)])
+def test_dtw_topk_on_wide_frames_uses_the_lower_bound_cascade(oracle, dim, f, k, band):
+    # frames wider than the filter takes in: the k pairs the filter likes best are scored exactly, the largest of
+    # their costs bounds the k-th best from above, and every pair whose lower bound stays below it is re-scored
+    g = synth.make_grid(96, 256 if band >= 0 else 80, f, dim, 0x5EED0700 + dim)
+    src = [x for x in g.sources.astype(np.float64)]
+    tgt = [x for x in g.targets.astype(np.float64)]
+    src[17] = src[5].copy()                                    # ties inside the top k: index order decides
+    tgt[3] = src[5].copy()
+    tgt[4] = np.zeros((0, dim))
+    sf, so = pack_segments(src, dim, np.float32)
+    tf, to = pack_segments(tgt, dim, np.float32)
+    e = Engine(metric="dtw", dtype="f32", band=band)
+    d, q = e.dictionary(sf, so, dim), e.queries(tf, to, dim)
+    idx, cost = e.match_topk(d, q, k)
+    assert e.timings()["used_filter"] == 1
+    _, _, mat = oracle.dtw_match_all(sf.astype(np.float64), so, tf.astype(np.float64), to, dim, band=band, want_matrix=True,
+                                     nthreads=oracle.max_threads())
+    want_idx, _ = oracle.topk(mat, k, default_distance=0.0, fold_start=float("inf"))
+    want_val = np.where(want_idx >= 0, mat[np.maximum(want_idx, 0), np.arange(len(tgt))[:, None]], np.nan)
+    _check_rows(idx, cost, want_idx, want_val, exact=False)
+    # fewer finite pairs than k: the rest of the row says so
+    few = e.dictionary(sf[: int(so[2]) * dim], so[:3], dim)
+    i2, c2 = e.match_topk(few, q, k)
+    assert (i2[0, 2:] == NO_MATCH).all() and np.isnan(c2[0, 2:]).all()
+    e.close()

@@ -32,6 +32,11 @@ for dim in (64, 90):
         print(f"   with early abandoning: total {tp['total_ms']:.1f} ms (thresholds {tp['prune_ms']:.1f}, filter {tp['main_ms']:.1f}, "
               f"select {tp['select_ms']:.1f}, refine {tp['refine_ms']:.1f}), same answers: "
               f"{bool(np.array_equal(pi, idx) and np.array_equal(pc, cost))}")
+        e.match_topk(d, q, 3)
+        ti, tc = e.match_topk(d, q, 3)
+        tk = e.timings()
+        print(f"   top-3: total {tk['total_ms']:.1f} ms (filter {tk['main_ms']:.1f}, select {tk['select_ms']:.1f}, refine {tk['refine_ms']:.1f}), "
+              f"refined {tk['n_refined']}, best of three equals the match: {bool(np.array_equal(ti[:, 0], idx))}")
         if dim == 64 and planted:
             m = 256
             qs = e.queries(tgt[:m].reshape(-1), off[:m + 1], dim)
