@@ -100,6 +100,20 @@ def secondary_metrics(device: int, with_cpu: bool) -> dict:
     e.chain(d, g.targets[0].astype(np.float64).reshape(-1), dist_)
     out["chain"] = {"value": (time.perf_counter() - t0) / dist_.size * 1e6, "unit": "us/step",
                     "workload": f"from_distances, 256 steps on the {n}-entry dictionary (refcos)"}
+    # the reference's own call pattern: at_distance / match_sound ONE query at a time (src/sound.rs:453-454), against a
+    # 1024-entry dictionary of 5...40-frame segments (through the Python binding, a few us of ctypes included)
+    from soundsym_amd.engine import pack_segments
+    rsrc, rtgt = synth.make_ragged(1024, 32, 5, 40, dd, 0x5EED0700)
+    sf1, so1 = pack_segments([s_.astype(np.float64) * 0.05 for s_ in rsrc], dd)
+    d1 = e.dictionary(sf1, so1, dd)
+    qs = [t_.astype(np.float64).reshape(-1) * 0.05 for t_ in rtgt]
+    e.match_one(d1, qs[0], 1.0)
+    t0 = time.perf_counter()
+    for _ in range(8):
+        for q1 in qs:
+            e.match_one(d1, q1, 1.0)
+    out["match_one"] = {"value": (time.perf_counter() - t0) / (8 * len(qs)) * 1e6, "unit": "us/query",
+                        "workload": "ssym_match_one (refcos), 1024-entry dictionary, queries of 5...40 frames x 12 dims"}
     rate = 44100.0
     x = np.sin(2 * np.pi * 440.0 * np.arange(int(rate * 120)) / rate)
     e.mfcc(x[:44100], rate)

@@ -42,4 +42,4 @@ def test_bench_early_abandon_leg_is_identical_to_the_full_search():
     ea = line["early_abandon"]
     assert ea["identical_to_full_search"] is True and ea["value"] > 0
     assert 0 < ea["filter_cells_swept_frac"] <= 1
-    assert set(line["secondary"]) >= {"refcos", "chain", "mfcc"}
+    assert set(line["secondary"]) >= {"refcos", "chain", "mfcc", "match_one"}
