@@ -404,8 +404,9 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
         // thousand waves, the filter path a chain of ~20 launches (1 query x 1024 entries of 5...40 frames:
         // 81 us against 227 us per call; from 16 queries on the filter path is the shorter one)
         const bool fewPairs = (flags & kFlagFewTargets) && (uint64_t)N * M <= 8192 && src.max_frames + tgt.max_frames <= 128;
+        // (sharded runs on wide frames exchange bounds in cost space: no per-target distances there)
         const bool useFilter = !(flags & SSYM_DTW_FORCE_EXACT) && !fewPairs && filter_supported(ctx, src, tgt) &&
-                               (!wide || !(phase == 2 ? ctx->pending.has_dist : distance != nullptr));
+                               (!wide || phase == 0 || !(phase == 2 ? ctx->pending.has_dist : distance != nullptr));
         tm.used_filter = useFilter ? 1 : 0;
         if (useFilter) {
             rc = ensure(ctx, ctx->cmat, sizeof(float) * (size_t)src.n_pad * tgt.n_pad);
@@ -439,7 +440,7 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
                 if (prune)
                     SSYM_HIP_CHECK(ctx, hipMemcpyAsync(&ctx->pruned_cells, colCtr, sizeof(*colCtr),
                                                        hipMemcpyDeviceToHost, st));
-                rc = wide ? launch_dtw_bounds_partial(ctx, src, tgt, cmat, prune ? (const double *)ctx->prune_cost.ptr : nullptr, k_top)
+                rc = wide ? launch_dtw_bounds_partial(ctx, src, tgt, cmat, prune ? (const double *)ctx->prune_cost.ptr : nullptr, k_top, distDev)
                           : launch_dtw_bounds(ctx, src, tgt, cmat, distDev, k_top,
                                               prune ? (const double *)ctx->prune_cost.ptr : nullptr);
                 if (rc != SSYM_OK)

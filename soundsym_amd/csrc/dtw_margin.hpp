@@ -9,6 +9,7 @@ struct MarginParams {
     double inv_scale2;  // 1 / s^2
     double in_round;    // relative rounding of the operands the filter sees: 2^-22 (two f16 pieces) or 2^-11
     int squared;
+    int lower_only;     // frames wider than the filter takes in: its cost bounds a pair's cost from BELOW only
 };
 
 // worst error of one local cost of the pair (xmin = the pair's certificate, 0 = none)
@@ -43,7 +44,7 @@ __device__ __forceinline__ void dtw_key_interval(const MarginParams &mp, double 
     const double cell = dtw_cell_error(mp, xmin, na, nb);
     const double L = (double)(fa + fb - 1);
     const double err = 1.02 * L * cell + (L + 6.0) * u * cst + 1e-300;
-    const double lo = fmax(cst - err, 0.0), hi = cst + err;
+    const double lo = fmax(cst - err, 0.0), hi = mp.lower_only ? INF : cst + err;
     key_lo = fmax(fmax(lo - delta, delta - hi), 0.0);
     key_hi = fmax(fabs(lo - delta), fabs(hi - delta));
 }
@@ -54,6 +55,7 @@ inline MarginParams margin_params(const ssym_ctx *ctx, const SegmentSet &src)
     mp.inv_scale2 = src.rec_scale > 0.0 ? 1.0 / (src.rec_scale * src.rec_scale) : 1.0;
     mp.in_round = filter_pieces(filter_dim_used((int)src.dim)) == 2 ? 2.384185791015625e-07 : 4.8828125e-04;
     mp.squared = ctx->squared;
+    mp.lower_only = (int)src.dim > filter_dim_used((int)src.dim) ? 1 : 0;
     return mp;
 }
 

@@ -634,6 +634,7 @@ __global__ __launch_bounds__(256) void dtw_partial_argmin_kernel(const float *__
                                                                  uint32_t nTgt, uint32_t mPad,
                                                                  const uint32_t *__restrict__ permS,
                                                                  const uint32_t *__restrict__ permT,
+                                                                 const double *__restrict__ dist,
                                                                  uint32_t *__restrict__ hdr,
                                                                  uint2 *__restrict__ pairs)
 {
@@ -642,10 +643,14 @@ __global__ __launch_bounds__(256) void dtw_partial_argmin_kernel(const float *__
         hdr[0] = nTgt, hdr[1] = 0;
     if (t >= nTgt)
         return;
+    // (with a per-target distance: the pair whose lower bound lies nearest to it -- any pair gives a valid bound,
+    //  this one is the best guess)
+    const float delta = dist ? (float)dist[permT[t]] : 0.0f;
     float best = __builtin_inff();
     uint32_t bs = 0;
     for (uint32_t s = 0; s < nSrc; ++s) {
-        const float c = cmat[(size_t)s * mPad + t];
+        const float c0 = cmat[(size_t)s * mPad + t];
+        const float c = c0 < __builtin_inff() ? __builtin_fabsf(c0 - delta) : c0;
         if (c < best) {
             best = c;
             bs = s;
@@ -658,7 +663,8 @@ __global__ __launch_bounds__(256) void dtw_partial_argmin_kernel(const float *__
 constexpr int kPartialKMax = (int)SSYM_TOPK_MAX;
 __global__ __launch_bounds__(256) void dtw_partial_topk_kernel(const float *__restrict__ cmat, uint32_t nSrc, uint32_t nTgt,
                                                                uint32_t mPad, const uint32_t *__restrict__ permS,
-                                                               const uint32_t *__restrict__ permT, uint32_t k,
+                                                               const uint32_t *__restrict__ permT,
+                                                               const double *__restrict__ dist, uint32_t k,
                                                                uint32_t *__restrict__ hdr, uint2 *__restrict__ pairs,
                                                                uint32_t *__restrict__ found)
 {
@@ -670,10 +676,12 @@ __global__ __launch_bounds__(256) void dtw_partial_topk_kernel(const float *__re
     float bc[kPartialKMax];
     uint32_t bs[kPartialKMax];
     uint32_t cnt = 0;
+    const float delta = dist ? (float)dist[permT[t]] : 0.0f;
     for (uint32_t s = 0; s < nSrc; ++s) {
-        const float c = cmat[(size_t)s * mPad + t];
-        if (!(c < __builtin_inff()))
+        const float c0 = cmat[(size_t)s * mPad + t];
+        if (!(c0 < __builtin_inff()))
             continue;
+        const float c = __builtin_fabsf(c0 - delta);
         if (cnt == k && !(c < bc[k - 1]))
             continue;
         uint32_t pos = cnt < k ? cnt : k - 1;                    // insertion into the ascending list of at most k
@@ -693,30 +701,39 @@ __global__ __launch_bounds__(256) void dtw_partial_topk_kernel(const float *__re
 }
 
 __global__ void dtw_partial_topk_threshold_kernel(const double *__restrict__ exact, const uint32_t *__restrict__ found,
-                                                  uint32_t nTgt, uint32_t k, unsigned long long *__restrict__ ub)
+                                                  uint32_t nTgt, uint32_t k, const double *__restrict__ dist,
+                                                  const uint32_t *__restrict__ permT, unsigned long long *__restrict__ ub)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nTgt)
         return;
+    const double delta = dist ? dist[permT[t]] : 0.0;
     double worst = 0.0;
     bool ok = found[t] >= k;
     for (uint32_t r = 0; r < k && ok; ++r) {
         const double c = exact[(size_t)t * k + r];
         if (!(c < __builtin_inf()))
             ok = false;                                             // NaN / +inf: no bound from this pair
-        else
-            worst = c > worst ? c : worst;
+        else {
+            const double key = fabs(c - delta);
+            worst = key > worst ? key : worst;
+        }
     }
-    ub[t] = ok ? (unsigned long long)__double_as_longlong(worst) : kInfBits;
+    // fewer than k bounds: every finite pair stays (the largest finite double, as in the top-k rounds of the bounds
+    // kernel -- +inf would mean "no pair at all")
+    ub[t] = ok ? (unsigned long long)__double_as_longlong(worst) : kDblMaxBits;
 }
 
 __global__ void dtw_partial_threshold_kernel(const double *__restrict__ exact, const double *__restrict__ seed,
-                                             uint32_t nTgt, unsigned long long *__restrict__ ub)
+                                             uint32_t nTgt, const double *__restrict__ dist,
+                                             const uint32_t *__restrict__ permT, unsigned long long *__restrict__ ub)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nTgt)
         return;
     double c = exact[t];
+    if (dist)
+        c = fabs(c - dist[permT[t]]);           // the threshold lives in key space: |cost - distance|
     if (seed) {
         // early abandoning: the candidate's exact cost is an upper bound too.  (It does not replace the pair the
         // filter likes best: without close pairs the centroid candidate is a poor bound and the lower-bound
@@ -728,7 +745,7 @@ __global__ void dtw_partial_threshold_kernel(const double *__restrict__ exact, c
 }
 
 int32_t launch_dtw_bounds_partial(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, const float *cmat,
-                                  const double *seed_by_slot, uint32_t k_top)
+                                  const double *seed_by_slot, uint32_t k_top, const double *dist_dev)
 {
     if (k_top > 1) {
         // the k-th best cost of a target is at most the largest exact cost among ANY k of its pairs: take the k the
@@ -748,13 +765,14 @@ int32_t launch_dtw_bounds_partial(ssym_ctx *ctx, const SegmentSet &src, const Se
         uint2 *pairs = (uint2 *)(hdr + 2);
         uint32_t *found = (uint32_t *)ctx->selcnt.ptr;
         const unsigned tb = (tgt.n + 255) / 256;
-        dtw_partial_topk_kernel<<<tb, 256, 0, st>>>(cmat, src.n, tgt.n, tgt.n_pad, src.perm, tgt.perm, k_top, hdr, pairs, found);
+        dtw_partial_topk_kernel<<<tb, 256, 0, st>>>(cmat, src.n, tgt.n, tgt.n_pad, src.perm, tgt.perm, dist_dev, k_top, hdr, pairs,
+                                                    found);
         SSYM_HIP_CHECK(ctx, hipGetLastError());
         rc = launch_dtw_exact(ctx, src, tgt, pairs, hdr, (uint32_t)nk, (double *)ctx->cand_cost.ptr);
         if (rc != SSYM_OK)
             return rc;
-        dtw_partial_topk_threshold_kernel<<<tb, 256, 0, st>>>((const double *)ctx->cand_cost.ptr, found, tgt.n, k_top,
-                                                              (unsigned long long *)ctx->tmin.ptr);
+        dtw_partial_topk_threshold_kernel<<<tb, 256, 0, st>>>((const double *)ctx->cand_cost.ptr, found, tgt.n, k_top, dist_dev,
+                                                              tgt.perm, (unsigned long long *)ctx->tmin.ptr);
         SSYM_HIP_CHECK(ctx, hipGetLastError());
         return SSYM_OK;
     }
@@ -769,12 +787,12 @@ int32_t launch_dtw_bounds_partial(ssym_ctx *ctx, const SegmentSet &src, const Se
     uint32_t *hdr = (uint32_t *)ctx->cand2.ptr;
     uint2 *pairs = (uint2 *)(hdr + 2);
     const unsigned tb = (tgt.n + 255) / 256;
-    dtw_partial_argmin_kernel<<<tb, 256, 0, st>>>(cmat, src.n, tgt.n, tgt.n_pad, src.perm, tgt.perm, hdr, pairs);
+    dtw_partial_argmin_kernel<<<tb, 256, 0, st>>>(cmat, src.n, tgt.n, tgt.n_pad, src.perm, tgt.perm, dist_dev, hdr, pairs);
     SSYM_HIP_CHECK(ctx, hipGetLastError());
     rc = launch_dtw_exact(ctx, src, tgt, pairs, hdr, tgt.n, (double *)ctx->cand_cost.ptr);
     if (rc != SSYM_OK)
         return rc;
-    dtw_partial_threshold_kernel<<<tb, 256, 0, st>>>((const double *)ctx->cand_cost.ptr, seed_by_slot, tgt.n,
+    dtw_partial_threshold_kernel<<<tb, 256, 0, st>>>((const double *)ctx->cand_cost.ptr, seed_by_slot, tgt.n, dist_dev, tgt.perm,
                                                      (unsigned long long *)ctx->tmin.ptr);
     SSYM_HIP_CHECK(ctx, hipGetLastError());
     return SSYM_OK;

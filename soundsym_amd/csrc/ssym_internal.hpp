@@ -234,7 +234,8 @@ int32_t launch_dtw_bounds(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
 // wide frames: the filter cost is only a lower bound; the threshold is the EXACT cost of the pair the
 // filter likes best per target (one exact evaluation per target) -> ctx->tmin
 int32_t launch_dtw_bounds_partial(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, const float *cmat,
-                                  const double *seed_by_slot = nullptr, uint32_t k_top = 1);
+                                  const double *seed_by_slot = nullptr, uint32_t k_top = 1,
+                                  const double *dist_dev = nullptr /* per-target distances, caller's order */);
 int32_t launch_dtw_select(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt,
                           const float *cmat, const double *dist_dev, uint32_t cap);
 // stage 2: per-pair intervals from the certificates of list 1 -> ctx->cand2 (list 2, same capacity)

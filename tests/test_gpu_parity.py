@@ -568,13 +568,22 @@ def test_dtw_wide_frames_use_the_filter_as_a_lower_bound(oracle, dim, band):
         assert np.all(fm[ok] <= mat[ok] + 2e-3 * (1.0 + mat[ok]) + 2.0 ** -11 * 2 * 12.0 * lens[ok])
     else:
         assert tm["used_filter"] == 0                        # band beyond the filter's reach: exact kernel
-    # per-target distances on wide frames go through the exact kernel on every pair (top-k: tests/test_gpu_topk.py)
-    dist = np.nanmedian(np.where(np.isfinite(mat), mat, np.nan), axis=0)
-    dist = np.nan_to_num(dist, nan=1.0)
-    i2, c2 = e.match(d, q, distance=dist)
-    assert e.timings()["used_filter"] == 0
-    key = np.where(np.isfinite(mat), np.abs(mat - dist[None, :]), np.inf)
-    assert np.array_equal(i2, np.where(np.isfinite(key).any(axis=0), key.argmin(axis=0), 0))
+    # per-target distances on wide frames: the same cascade with key intervals that are open above (the filter's cost
+    # bounds a pair from below only); distances in the middle of the costs, near zero and beyond everything
+    med = np.nan_to_num(np.nanmedian(np.where(np.isfinite(mat), mat, np.nan), axis=0), nan=1.0)
+    for dist in (med, 0.05 * med, 3.0 * med + 1.0):
+        i2, c2 = e.match(d, q, distance=dist)
+        assert e.timings()["used_filter"] == (1 if band <= 47 else 0)
+        key = np.where(np.isfinite(mat), np.abs(mat - dist[None, :]), np.inf)
+        want = np.where(np.isfinite(key).any(axis=0), key.argmin(axis=0), 0)
+        assert np.array_equal(i2, want)
+        have = np.isfinite(key).any(axis=0)
+        assert np.allclose(c2[have], mat[want, np.arange(len(tgt))][have], rtol=EXACT_RTOL, atol=0)
+    # ... and with top-k
+    ti, tc = e.match_topk(d, q, 3, med)
+    o_idx, _ = oracle.topk(mat, 3, distance=med, default_distance=0.0, fold_start=float("inf"))
+    from soundsym_amd._native import NO_MATCH
+    assert np.array_equal(np.where(ti == NO_MATCH, -1, ti.astype(np.int64)), o_idx)
     e.close()
 
 
