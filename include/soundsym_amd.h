@@ -206,7 +206,8 @@ SSYM_API int32_t ssym_chain(ssym_ctx *ctx, ssym_dict *dict, const void *start_fe
 /* The whole [n_sources][n_targets] matrix in HOST memory, row-major, f64:
  *   refcos: cosine_sim(source, target) (src/sound.rs:22-33), bit for bit;
  *   dtw:    exact = 0 -> the f32 MFMA filter's costs (frames wider than 42 values: of their first 42
- *           values only, i.e. a lower bound of every pair's cost); exact = 1 -> the exact f64 costs. */
+ *           values only; a Sakoe-Chiba band beyond the banded kernel, r > 47: the unbanded cost --
+ *           either way a lower bound of every pair's cost); exact = 1 -> the exact f64 costs. */
 SSYM_API int32_t ssym_pair_matrix(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queries *q,
                          int32_t exact, double *out_matrix);
 

@@ -399,7 +399,7 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
     } else {
         // frames wider than the filter's 42 values: the filter scores the first 42 and bounds the cost from
         // below; that supports the plain first-minimum search (no per-target distances, k = 1)
-        const bool wide = (int)src.dim > filter_dim_used((int)src.dim);
+        const bool wide = filter_lower_bound_only(ctx, src, tgt);
         // few short queries against a small dictionary: the exact kernel on every pair is one launch of a few
         // thousand waves, the filter path a chain of ~20 launches (1 query x 1024 entries of 5...40 frames:
         // 81 us against 227 us per call; from 16 queries on the filter path is the shorter one)
@@ -613,7 +613,7 @@ int32_t ssym_match_topk(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queries
 // bounds with +inf when the filter does not apply; the all-reduce then changes nothing.
 static bool prune_applies(const ssym_ctx *ctx, const ssym_dict *dict, const ssym_queries *q)
 {
-    const bool wideFrames = (int)dict->set.dim > filter_dim_used((int)dict->set.dim);
+    const bool wideFrames = filter_lower_bound_only(ctx, dict->set, q->set);
     return ctx->metric == SSYM_METRIC_DTW && q->set.n > 0 && !wideFrames && filter_supported(ctx, dict->set, q->set);
 }
 
@@ -679,7 +679,7 @@ static int32_t match_begin_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym
     const uint32_t M = q->set.n;
     if (distance)
         pd.dist_host.assign(distance, distance + M);
-    const bool wideFrames = (int)dict->set.dim > filter_dim_used((int)dict->set.dim);
+    const bool wideFrames = filter_lower_bound_only(ctx, dict->set, q->set);
     pd.filter = ctx->metric == SSYM_METRIC_DTW && M > 0 && filter_supported(ctx, dict->set, q->set) &&
                 (!wideFrames || !distance);
     if (pd.filter) {

@@ -105,21 +105,25 @@ static size_t band_lds_bytes(int radius, const SegmentSet &src, const SegmentSet
     return (size_t)2 * band_slots(radius, src, tgt) * kFilterRecHalfs * sizeof(_Float16);
 }
 
+// A Sakoe-Chiba band the banded kernel cannot take -- more than 6 tiles of diagonals (r > 47), or a source pair that
+// does not fit the LDS -- is served by the UNBANDED filter: a band only removes paths, so the unbanded cost bounds the
+// banded one from below, and the lower-bound cascade (select.hip, "wide frames") with the banded exact kernel does
+// the rest.
+bool filter_band_as_bound(const ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt)
+{
+    if (ctx->band < 0)
+        return false;
+    return 2 * ctx->band + 1 > 6 * 16 || band_lds_bytes(ctx->band, src, tgt) > 160 * 1024 - 64;   // (+ the kernel's few static bytes)
+}
+
 bool filter_supported(const ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt)
 {
     if (src.light || tgt.light)
         return false;   // packed for the exact kernels only
     if (src.dim != tgt.dim)
         return false;   // (frames wider than 42 values: capi.hip decides, the filter is then a lower bound only)
-    if (ctx->band >= 0) {
-        // banded kernel: 2r+1 diagonals in registers (<= 6 tiles) and the source pair in LDS
-        if (2 * ctx->band + 1 > 6 * 16)
-            return false;
-        if (band_lds_bytes(ctx->band, src, tgt) > 160 * 1024 - 64)      // + the kernel's few static bytes
-            return false;
-    } else if (filter_shape((int)src.max_frames).nt == 0) {
+    if ((ctx->band < 0 || filter_band_as_bound(ctx, src, tgt)) && filter_shape((int)src.max_frames).nt == 0)
         return false;   // more than 4096 source frames
-    }
     if (!std::isfinite(src.max_abs) || !std::isfinite(tgt.max_abs))
         return false;   // inf / NaN features: exact kernel keeps IEEE semantics
     return src.n > 0 && tgt.n > 0;
@@ -283,8 +287,9 @@ static int32_t launch_dtw_filter_banded(ssym_ctx *ctx, const SegmentSet &src, co
 int32_t ensure_filter_records(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, double *scale_out)
 {
     const double scale = common_scale(src, tgt);
-    int32_t rc = ctx->band >= 0 ? ensure_records(ctx, src, scale, band_slots(ctx->band, src, tgt), ctx->band)
-                                : ensure_records(ctx, src, scale, src.frames_pad, -1);
+    int32_t rc = ctx->band >= 0 && !filter_band_as_bound(ctx, src, tgt)
+                     ? ensure_records(ctx, src, scale, band_slots(ctx->band, src, tgt), ctx->band)
+                     : ensure_records(ctx, src, scale, src.frames_pad, -1);
     if (rc == SSYM_OK)
         rc = ensure_records(ctx, tgt, scale, tgt.frames_pad, 0);
     if (scale_out)
@@ -295,7 +300,7 @@ int32_t ensure_filter_records(ssym_ctx *ctx, const SegmentSet &src, const Segmen
 int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, float *cmat,
                           const float *abandon, unsigned long long *colCtr, const uint32_t *candSlot)
 {
-    if (ctx->band >= 0)
+    if (ctx->band >= 0 && !filter_band_as_bound(ctx, src, tgt))
         return launch_dtw_filter_banded(ctx, src, tgt, cmat, abandon, colCtr, candSlot);
     FilterShape shape = filter_shape((int)src.max_frames);
     if (shape.nt == 0 || (int)src.frames_pad != shape.rows() || src.n_pad % 8 != 0 || tgt.n_pad % 32 != 0) {

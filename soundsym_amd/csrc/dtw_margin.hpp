@@ -49,13 +49,13 @@ __device__ __forceinline__ void dtw_key_interval(const MarginParams &mp, double 
     key_hi = fmax(fabs(lo - delta), fabs(hi - delta));
 }
 
-inline MarginParams margin_params(const ssym_ctx *ctx, const SegmentSet &src)
+inline MarginParams margin_params(const ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt)
 {
     MarginParams mp;
     mp.inv_scale2 = src.rec_scale > 0.0 ? 1.0 / (src.rec_scale * src.rec_scale) : 1.0;
     mp.in_round = filter_pieces(filter_dim_used((int)src.dim)) == 2 ? 2.384185791015625e-07 : 4.8828125e-04;
     mp.squared = ctx->squared;
-    mp.lower_only = (int)src.dim > filter_dim_used((int)src.dim) ? 1 : 0;
+    mp.lower_only = filter_lower_bound_only(ctx, src, tgt) ? 1 : 0;
     return mp;
 }
 

@@ -272,7 +272,7 @@ int32_t launch_dtw_prune_thresholds(ssym_ctx *ctx, const SegmentSet &src, const 
         rc = ensure(ctx, ctx->abandon, (sizeof(float) * tgt.n_pad + 15) / 8 * 8 + sizeof(unsigned long long));
     if (rc != SSYM_OK)
         return rc;
-    const MarginParams mp = margin_params(ctx, src);
+    const MarginParams mp = margin_params(ctx, src, tgt);
     const double outScale = ctx->squared ? 1.0 / (scale * scale) : 1.0 / scale;
     prune_threshold_kernel<<<(tgt.n_pad + 255) / 256, 256, 0, st>>>(
         cost_by_target ? cost_by_target : (const double *)ctx->prune_cost.ptr, cost_by_target ? tgt.perm : nullptr,

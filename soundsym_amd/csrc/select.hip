@@ -534,7 +534,7 @@ int32_t launch_dtw_select2(ssym_ctx *ctx, const SegmentSet &src, const SegmentSe
                            bool lower_bound_only, const uint32_t *known_src)
 {
     hipStream_t st = ctx->stream;
-    const MarginParams mp = margin_params(ctx, src);
+    const MarginParams mp = margin_params(ctx, src, tgt);
     // (+ tgt.n: room for the early-abandoning candidates that join after the exact kernel)
     int32_t rc = ensure(ctx, ctx->cand2, sizeof(uint32_t) * 2 + sizeof(uint2) * ((size_t)cap + tgt.n));
     if (rc != SSYM_OK)
@@ -594,7 +594,7 @@ int32_t launch_dtw_bounds(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
                           const double *dist_dev, uint32_t k_top, const double *seed_by_slot)
 {
     hipStream_t st = ctx->stream;
-    const MarginParams mp = margin_params(ctx, src);
+    const MarginParams mp = margin_params(ctx, src, tgt);
     int32_t rc = ensure(ctx, ctx->tmin, sizeof(unsigned long long) * tgt.n);
     if (rc != SSYM_OK)
         return rc;
@@ -635,6 +635,8 @@ __global__ __launch_bounds__(256) void dtw_partial_argmin_kernel(const float *__
                                                                  const uint32_t *__restrict__ permS,
                                                                  const uint32_t *__restrict__ permT,
                                                                  const double *__restrict__ dist,
+                                                                 const int *__restrict__ srcLen,
+                                                                 const int *__restrict__ tgtLen, int band,
                                                                  uint32_t *__restrict__ hdr,
                                                                  uint2 *__restrict__ pairs)
 {
@@ -648,7 +650,10 @@ __global__ __launch_bounds__(256) void dtw_partial_argmin_kernel(const float *__
     const float delta = dist ? (float)dist[permT[t]] : 0.0f;
     float best = __builtin_inff();
     uint32_t bs = 0;
+    const int fb = tgtLen[t];
     for (uint32_t s = 0; s < nSrc; ++s) {
+        if (band >= 0 && abs(srcLen[s] - fb) > band)
+            continue;               // inside the band this pair has no path at all (the unbanded filter would not know)
         const float c0 = cmat[(size_t)s * mPad + t];
         const float c = c0 < __builtin_inff() ? __builtin_fabsf(c0 - delta) : c0;
         if (c < best) {
@@ -664,9 +669,10 @@ constexpr int kPartialKMax = (int)SSYM_TOPK_MAX;
 __global__ __launch_bounds__(256) void dtw_partial_topk_kernel(const float *__restrict__ cmat, uint32_t nSrc, uint32_t nTgt,
                                                                uint32_t mPad, const uint32_t *__restrict__ permS,
                                                                const uint32_t *__restrict__ permT,
-                                                               const double *__restrict__ dist, uint32_t k,
-                                                               uint32_t *__restrict__ hdr, uint2 *__restrict__ pairs,
-                                                               uint32_t *__restrict__ found)
+                                                               const double *__restrict__ dist,
+                                                               const int *__restrict__ srcLen, const int *__restrict__ tgtLen,
+                                                               int band, uint32_t k, uint32_t *__restrict__ hdr,
+                                                               uint2 *__restrict__ pairs, uint32_t *__restrict__ found)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;      // target slot
     if (t == 0)
@@ -677,9 +683,10 @@ __global__ __launch_bounds__(256) void dtw_partial_topk_kernel(const float *__re
     uint32_t bs[kPartialKMax];
     uint32_t cnt = 0;
     const float delta = dist ? (float)dist[permT[t]] : 0.0f;
+    const int fb = tgtLen[t];
     for (uint32_t s = 0; s < nSrc; ++s) {
         const float c0 = cmat[(size_t)s * mPad + t];
-        if (!(c0 < __builtin_inff()))
+        if (!(c0 < __builtin_inff()) || (band >= 0 && abs(srcLen[s] - fb) > band))
             continue;
         const float c = __builtin_fabsf(c0 - delta);
         if (cnt == k && !(c < bc[k - 1]))
@@ -741,7 +748,8 @@ __global__ void dtw_partial_threshold_kernel(const double *__restrict__ exact, c
         const double s = seed[t];
         c = (s >= 0.0 && (s < c || c != c)) ? s : c;
     }
-    ub[t] = c == c ? (unsigned long long)__double_as_longlong(c < 0.0 ? 0.0 : c) : kInfBits;   // NaN: nothing can win
+    // (no finite bound from the scored pair -- an empty side, NaN: every pair with a finite lower bound stays in)
+    ub[t] = c < __builtin_inf() ? (unsigned long long)__double_as_longlong(c < 0.0 ? 0.0 : c) : kDblMaxBits;
 }
 
 int32_t launch_dtw_bounds_partial(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, const float *cmat,
@@ -765,8 +773,8 @@ int32_t launch_dtw_bounds_partial(ssym_ctx *ctx, const SegmentSet &src, const Se
         uint2 *pairs = (uint2 *)(hdr + 2);
         uint32_t *found = (uint32_t *)ctx->selcnt.ptr;
         const unsigned tb = (tgt.n + 255) / 256;
-        dtw_partial_topk_kernel<<<tb, 256, 0, st>>>(cmat, src.n, tgt.n, tgt.n_pad, src.perm, tgt.perm, dist_dev, k_top, hdr, pairs,
-                                                    found);
+        dtw_partial_topk_kernel<<<tb, 256, 0, st>>>(cmat, src.n, tgt.n, tgt.n_pad, src.perm, tgt.perm, dist_dev, src.len, tgt.len,
+                                                    ctx->band, k_top, hdr, pairs, found);
         SSYM_HIP_CHECK(ctx, hipGetLastError());
         rc = launch_dtw_exact(ctx, src, tgt, pairs, hdr, (uint32_t)nk, (double *)ctx->cand_cost.ptr);
         if (rc != SSYM_OK)
@@ -787,7 +795,8 @@ int32_t launch_dtw_bounds_partial(ssym_ctx *ctx, const SegmentSet &src, const Se
     uint32_t *hdr = (uint32_t *)ctx->cand2.ptr;
     uint2 *pairs = (uint2 *)(hdr + 2);
     const unsigned tb = (tgt.n + 255) / 256;
-    dtw_partial_argmin_kernel<<<tb, 256, 0, st>>>(cmat, src.n, tgt.n, tgt.n_pad, src.perm, tgt.perm, dist_dev, hdr, pairs);
+    dtw_partial_argmin_kernel<<<tb, 256, 0, st>>>(cmat, src.n, tgt.n, tgt.n_pad, src.perm, tgt.perm, dist_dev, src.len, tgt.len,
+                                                  ctx->band, hdr, pairs);
     SSYM_HIP_CHECK(ctx, hipGetLastError());
     rc = launch_dtw_exact(ctx, src, tgt, pairs, hdr, tgt.n, (double *)ctx->cand_cost.ptr);
     if (rc != SSYM_OK)
@@ -803,7 +812,7 @@ int32_t launch_dtw_select(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
                           const float *cmat, const double *dist_dev, uint32_t cap)
 {
     hipStream_t st = ctx->stream;
-    const MarginParams mp = margin_params(ctx, src);
+    const MarginParams mp = margin_params(ctx, src, tgt);
     int32_t rc = ensure(ctx, ctx->cand, sizeof(uint32_t) * 2 + sizeof(uint2) * (size_t)cap);
     if (rc != SSYM_OK)
         return rc;

@@ -199,6 +199,13 @@ struct StageScope {                    // one per public entry point that moves 
 
 // dtw_filter.hip
 bool filter_supported(const ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt);
+// a band the banded kernel cannot take: the unbanded filter runs instead and bounds the banded cost from below
+bool filter_band_as_bound(const ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt);
+// the filter's cost is only a lower bound of the pair's cost (frames wider than 42 values, or such a band)
+inline bool filter_lower_bound_only(const ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt)
+{
+    return (int)src.dim > filter_dim_used((int)src.dim) || filter_band_as_bound(ctx, src, tgt);
+}
 // abandon != NULL: early abandoning against per-target-slot thresholds in accumulator units (prune.hip)
 int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt,
                           float *cmat /*[src.n_pad][tgt.n_pad]*/, const float *abandon = nullptr,

@@ -347,8 +347,9 @@ def test_dtw_banded_ragged_lengths(oracle):
 
 def test_dtw_very_wide_bands_use_the_exact_kernel_and_wide_frames_the_bound(oracle):
     # more than 42 values per frame: the filter bounds the cost from below (its first 42 values); a band
-    # wider than 6 tiles of diagonals is outside the filter: exact f64 kernel on every pair, including
-    # its own 64-row chunking (150 frames = 3 chunks)
+    # wider than 6 tiles of diagonals is outside the BANDED kernel: the unbanded filter bounds the banded cost from
+    # below, the banded exact kernel scores the survivors; forced exact: every pair, including the exact kernel's
+    # own 64-row chunking (150 frames = 3 chunks)
     g = synth.make_grid(5, 4, 20, 50, 0x5EED0323)
     sf, so = g.flat("sources")
     tf, to = g.flat("targets")
@@ -363,7 +364,7 @@ def test_dtw_very_wide_bands_use_the_exact_kernel_and_wide_frames_the_bound(orac
     tf, to = g.flat("targets")
     eb = Engine(metric="dtw", dtype="f32", band=60)
     idx, cost = eb.match(eb.dictionary(sf, so, 13), eb.queries(tf, to, 13))
-    assert eb.timings()["used_filter"] == 0
+    assert eb.timings()["used_filter"] == 1
     want_idx, want_cost = oracle.dtw_match_all(sf.astype(np.float64), so, tf.astype(np.float64), to, 13, band=60)
     assert np.array_equal(idx, want_idx) and np.allclose(cost, want_cost, rtol=EXACT_RTOL, atol=0)
     eb.close()
@@ -559,21 +560,20 @@ def test_dtw_wide_frames_use_the_filter_as_a_lower_bound(oracle, dim, band):
     assert np.array_equal(idx, want_idx)
     fin = np.isfinite(want_cost)
     assert np.allclose(cost[fin], want_cost[fin], rtol=EXACT_RTOL, atol=0) and np.isinf(cost[~fin]).all()
+    assert tm["used_filter"] == 1                            # (a band beyond the banded kernel: the unbanded filter as a bound)
     if band <= 47:
-        assert tm["used_filter"] == 1 and tm["n_refined"] < len(src) * len(tgt) // 2
+        assert tm["n_refined"] < len(src) * len(tgt) // 2
         # the filter matrix never exceeds the exact cost by more than its own error
         fm = e.pair_matrix(d, q)
         ok = np.isfinite(mat)
         lens = np.diff(so).astype(np.float64)[:, None] + np.diff(to).astype(np.float64)[None, :]
         assert np.all(fm[ok] <= mat[ok] + 2e-3 * (1.0 + mat[ok]) + 2.0 ** -11 * 2 * 12.0 * lens[ok])
-    else:
-        assert tm["used_filter"] == 0                        # band beyond the filter's reach: exact kernel
     # per-target distances on wide frames: the same cascade with key intervals that are open above (the filter's cost
     # bounds a pair from below only); distances in the middle of the costs, near zero and beyond everything
     med = np.nan_to_num(np.nanmedian(np.where(np.isfinite(mat), mat, np.nan), axis=0), nan=1.0)
     for dist in (med, 0.05 * med, 3.0 * med + 1.0):
         i2, c2 = e.match(d, q, distance=dist)
-        assert e.timings()["used_filter"] == (1 if band <= 47 else 0)
+        assert e.timings()["used_filter"] == 1
         key = np.where(np.isfinite(mat), np.abs(mat - dist[None, :]), np.inf)
         want = np.where(np.isfinite(key).any(axis=0), key.argmin(axis=0), 0)
         assert np.array_equal(i2, want)
