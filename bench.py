@@ -2,14 +2,21 @@
 """bench.py -- segment-pairs/sec of the DTW matching hot path (BASELINE.json metric).
 
 One step = one pass of the hot path over one batch: every (source, target) pair's DTW cost on the
-f32 MFMA filter kernel, candidate selection, exact f64 re-scoring of the candidates and the
-per-target argmin (ssym_match_queries), plus -- with more than one GPU -- the all-gather of the
-per-target (cost, index) candidates and the merge kernel.  Features are resident in HBM before
-the timed region.
+f16-MFMA filter kernel, candidate selection, exact f64 re-scoring of the candidates and the
+per-target argmin (ssym_match_queries) -- with more than one GPU ONE call of ssym_match_sharded per
+rank: the same on the rank's source shard plus the RCCL all-reduce(MIN) of the per-target bounds,
+the RCCL all-gather of the per-target (cost, index) and the merge kernel, all on the library's
+stream.  Features are resident in HBM before the timed region.
 
-N = 1: BASELINE.json configs[2], 4096 x 4096 segments, 128 frames x 13 dims, f32 ("the roofline
-run"; the metric is quoted on it).  N > 1: source-axis sharding with 4096 sources per GPU and all
-4096 targets on every GPU (weak scaling; 8 GPUs = 32768 x 4096).
+Workloads (BASELINE.json `configs`), picked with --workload:
+  c3 (default)  configs[2]: 4096 x 4096 segments, 128 frames x 13 dims, f32 -- the configuration the
+                metric is quoted on ("the roofline run").  With N GPUs the 4096 sources are split N
+                ways (STRONG scaling: "4096x4096 ... 1/2/4/8 GPU").
+  c4            configs[3]: 16384 x 4096 segments, 128 frames x 13 dims, source-sharded (2048 per GPU at 8)
+  c5            configs[4]: 4096 x 4096 segments, 256 frames x 40 dims, Sakoe-Chiba r = 32, source-sharded
+  c2            configs[1]: 1024 x 1024 segments, 64 frames x 13 dims
+--src-per-gpu K switches to WEAK scaling (K sources per GPU, the round-1 mode), --targets / --frames /
+--dim / --band override single fields for experiments.
 """
 import argparse
 import glob
@@ -23,16 +30,18 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-SRC_PER_GPU = 4096
-N_TGT = 4096
-FRAMES = 128
-DIM = 13
+WORKLOADS = {
+    "c2": dict(n_src=1024, n_tgt=1024, frames=64, dim=13, band=-1, config="configs[1]"),
+    "c3": dict(n_src=4096, n_tgt=4096, frames=128, dim=13, band=-1, config="configs[2]"),
+    "c4": dict(n_src=16384, n_tgt=4096, frames=128, dim=13, band=-1, config="configs[3]"),
+    "c5": dict(n_src=4096, n_tgt=4096, frames=256, dim=40, band=32, config="configs[4]"),
+}
 SEED = 0x5EED0003
-PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA peak
+PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16/f16 MFMA peak (the cost block runs on the f16 pipe)
 PEAK_HBM_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
-def _oracle_sample(o, grid, gpu_idx, n_src, n_tgt, threads):
+def _oracle_sample(o, grid, gpu_idx, n_src, n_tgt, threads, band):
     tsel = np.arange(n_tgt)
     # keep each sampled target's planted source inside the sampled source block
     planted = grid.planted[tsel]
@@ -43,29 +52,36 @@ def _oracle_sample(o, grid, gpu_idx, n_src, n_tgt, threads):
     so = np.arange(ssel.size + 1, dtype=np.uint64) * grid.frames
     to = np.arange(tsel.size + 1, dtype=np.uint64) * grid.frames
     t0 = time.perf_counter()
-    idx, _ = o.dtw_match_all(sf, so, tf, to, grid.dim, nthreads=threads)
+    idx, _ = o.dtw_match_all(sf, so, tf, to, grid.dim, band=band, nthreads=threads)
     dt = time.perf_counter() - t0
     ok = bool(np.array_equal(ssel[idx], gpu_idx[tsel])) if gpu_idx is not None else None
     return ssel.size * tsel.size, dt, ok
 
 
-def cpu_baseline(grid, gpu_idx, budget_s=12.0):
-    """The CPU oracle (a port: the reference is Rust and cannot be built here) on a bounded
-    sample of the same workload, all host cores, OpenMP over targets.  A small probe sizes the
-    sample so that it takes about `budget_s` seconds on whatever host this is."""
+def cpu_baseline(grid, gpu_idx, band, budget_s=10.0, budget_1core_s=5.0):
+    """The CPU oracle (a port: the reference is Rust and cannot be built here) on bounded samples of
+    the same workload: OpenMP over targets on all host cores (the headline baseline) and a single
+    thread ("separately against 1 core and against all cores").  A small probe sizes
+    each sample so that it takes about its budget on whatever host this is."""
     import oracle
     o = oracle.load()
     threads = max(1, min(o.max_threads(), os.cpu_count() or 1))
     n_all_s, n_all_t = grid.sources.shape[0], grid.targets.shape[0]
-    pairs, dt, _ = _oracle_sample(o, grid, None, 64, min(n_all_t, 4 * threads), threads)
-    rate = pairs / max(dt, 1e-6)
-    want = max(pairs, rate * budget_s)
-    n_tgt = int(min(n_all_t, max(threads, 256)))
-    n_src = int(min(n_all_s, max(n_tgt, want // n_tgt)))
-    if n_src == n_all_s:
-        n_tgt = int(min(n_all_t, max(n_tgt, want // n_src)))
-    pairs, dt, ok = _oracle_sample(o, grid, gpu_idx, n_src, n_tgt, threads)
-    return {
+
+    def leg(nthreads, budget):
+        pairs, dt, _ = _oracle_sample(o, grid, None, 16 if nthreads == 1 else 64,
+                                      min(n_all_t, 8 if nthreads == 1 else 4 * nthreads), nthreads, band)
+        rate = pairs / max(dt, 1e-6)
+        want = max(pairs, rate * budget)
+        n_tgt = int(min(n_all_t, max(nthreads, 32 if nthreads == 1 else 256)))
+        n_src = int(min(n_all_s, max(n_tgt, want // n_tgt)))
+        if n_src == n_all_s:
+            n_tgt = int(min(n_all_t, max(n_tgt, want // n_src)))
+        pairs, dt, ok = _oracle_sample(o, grid, gpu_idx, n_src, n_tgt, nthreads, band)
+        return pairs, dt, ok, n_src, n_tgt
+
+    pairs, dt, ok, n_src, n_tgt = leg(threads, budget_s)
+    out = {
         "value": pairs / dt,
         "unit": "segment-pairs/s",
         "cores": threads,
@@ -73,11 +89,16 @@ def cpu_baseline(grid, gpu_idx, budget_s=12.0):
         "sample": f"{n_src}x{n_tgt} sub-grid of the workload ({pairs} pairs, {dt:.1f} s, f64 oracle, "
                   f"OpenMP over targets); indices equal the GPU's: {ok}",
     }
+    p1, d1, ok1, s1, t1 = leg(1, budget_1core_s)
+    out["one_core"] = {"value": p1 / d1, "unit": "segment-pairs/s", "cores": 1, "kind": "port",
+                       "sample": f"{s1}x{t1} sub-grid ({p1} pairs, {d1:.1f} s, one thread); indices equal the GPU's: {ok1}"}
+    return out
 
 
-def secondary_metrics(device: int, with_cpu: bool) -> dict:
+def secondary_metrics(device: int) -> dict:
     """Outside the timed region: the reference's own metric (refcos, SURVEY.md 8(d) "also report")
-    and the neighbouring rows (chain F4, MFCC F3), each one short measurement."""
+    and the neighbouring rows (chain F4, MFCC F3), each one short measurement.  GPU legs only; the
+    CPU baseline of refcos is timed by secondary_cpu() after every GPU leg is done."""
     from soundsym_amd import Engine, synth
     out = {}
     n, f, dd = 4096, 128, 12
@@ -88,12 +109,26 @@ def secondary_metrics(device: int, with_cpu: bool) -> dict:
     q = e.queries(g.targets.astype(np.float64).reshape(-1), off, dd)
     e.match(d, q)
     t0 = time.perf_counter()
+    kms = []
     for _ in range(5):
         e.match(d, q)
+        kms.append(e.timings()["main_ms"])
     dt = (time.perf_counter() - t0) / 5
+    k_s = float(np.mean(kms)) * 1e-3
+    # algorithmic work of the reference's metric: 2 L f64 flops per pair, L = F d (one multiply and
+    # one add per element of the common prefix, separately rounded as src/sound.rs:31 / rulinalg's dot does);
+    # f64 vector peak: 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz = 39.3 T separately rounded ops/s (tools/f64_rate.hip:
+    # v_mul_f64 / v_add_f64 issue in 4 cycles per wave on MI355X)
+    flops = 2.0 * n * n * f * dd
     out["refcos"] = {"value": n * n / dt, "unit": "segment-pairs/s", "ms_per_step": dt * 1e3,
                      "workload": f"{n}x{n} segments, {f} frames x {dd} dims, f64, reference metric "
-                                 "(cosine_sim + at_distance, bit-exact)"}
+                                 "(cosine_sim + at_distance, bit-exact)",
+                     "phase_ms": {k: round(float(v), 3) for k, v in e.timings().items() if k.endswith("_ms")},
+                     "roofline": {"bound": "f64 valu", "kernel": "refcos main kernel(s)", "kernel_ms": k_s * 1e3,
+                                  "achieved": flops / k_s / 1e12, "peak": 39.3, "unit": "T f64 op/s",
+                                  "frac": flops / k_s / 1e12 / 39.3,
+                                  "model": "2*F*d separately rounded f64 operations per pair (SURVEY.md 8(d)) over the "
+                                           "main kernel time; peak = f64 vector issue rate (one op per lane per 4 cycles)"}}
     dist_ = np.linspace(0.2, 1.2, 256)
     e.chain(d, g.targets[0].astype(np.float64).reshape(-1), dist_[:2])
     t0 = time.perf_counter()
@@ -121,20 +156,25 @@ def secondary_metrics(device: int, with_cpu: bool) -> dict:
     fr = e.mfcc(x, rate).shape[0]
     dt = time.perf_counter() - t0
     out["mfcc"] = {"value": fr / dt, "unit": "frames/s", "workload": "120 s of 44.1 kHz audio, host to host"}
-    if with_cpu:
-        import oracle as oracle_pkg
-        o = oracle_pkg.load()
-        k = 192
-        offk = np.arange(k + 1, dtype=np.uint64) * f
-        sf = g.sources[:k].astype(np.float64).reshape(-1)
-        tf = g.targets[:k].astype(np.float64).reshape(-1)
-        t0 = time.perf_counter()
-        o.refcos_match_all(sf, offk, tf, offk, dd)
-        dt = time.perf_counter() - t0
-        out["refcos"]["cpu_baseline"] = {"value": k * k / dt, "unit": "segment-pairs/s", "cores": 1, "kind": "port",
-                                         "sample": f"{k}x{k} sub-grid, single thread as the reference runs it"}
     e.close()
     return out
+
+
+def secondary_cpu(out: dict) -> None:
+    """refcos as the reference runs it: one thread, norms recomputed per pair (the oracle), on a sub-grid."""
+    import oracle as oracle_pkg
+    from soundsym_amd import synth
+    o = oracle_pkg.load()
+    n, f, dd, k = 4096, 128, 12, 192
+    g = synth.make_grid(n, n, f, dd, 0x5EED0103)
+    offk = np.arange(k + 1, dtype=np.uint64) * f
+    sf = g.sources[:k].astype(np.float64).reshape(-1)
+    tf = g.targets[:k].astype(np.float64).reshape(-1)
+    t0 = time.perf_counter()
+    o.refcos_match_all(sf, offk, tf, offk, dd)
+    dt = time.perf_counter() - t0
+    out["refcos"]["cpu_baseline"] = {"value": k * k / dt, "unit": "segment-pairs/s", "cores": 1, "kind": "port",
+                                     "sample": f"{k}x{k} sub-grid, single thread as the reference runs it"}
 
 
 def main():
@@ -142,15 +182,28 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3",
+                    help="BASELINE.json config: c3 = configs[2] (default, the metric's), c4 = configs[3], c5 = configs[4]")
     ap.add_argument("--no-secondary", action="store_true",
-                    help="skip the refcos / chain / mfcc measurements reported beside the headline")
+                    help="skip the refcos / chain / mfcc / early-abandon measurements reported beside the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--src-per-gpu", type=int, default=SRC_PER_GPU)
-    ap.add_argument("--targets", type=int, default=N_TGT)
-    ap.add_argument("--frames", type=int, default=FRAMES)
-    ap.add_argument("--dim", type=int, default=DIM)
-    ap.add_argument("--band", type=int, default=-1, help="Sakoe-Chiba radius (configs[4]: 32), -1 = none")
+    ap.add_argument("--src-per-gpu", type=int, default=0, help="WEAK scaling: this many sources per GPU (default: "
+                    "the workload's sources split over the GPUs, strong scaling)")
+    ap.add_argument("--sources", type=int, default=0)
+    ap.add_argument("--targets", type=int, default=0)
+    ap.add_argument("--frames", type=int, default=0)
+    ap.add_argument("--dim", type=int, default=0)
+    ap.add_argument("--band", type=int, default=None, help="Sakoe-Chiba radius, -1 = none")
     args = ap.parse_args()
+    wl = dict(WORKLOADS[args.workload])
+    custom = []
+    for key, val in (("n_src", args.sources), ("n_tgt", args.targets), ("frames", args.frames), ("dim", args.dim)):
+        if val:
+            wl[key] = val
+            custom.append(key)
+    if args.band is not None:
+        wl["band"] = args.band
+        custom.append("band")
 
     import torch
     import torch.distributed as dist
@@ -159,8 +212,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # SSYM_BENCH_FORCE_DIST=1: run the collective code path (RCCL init, all-gather, merge) even with
-    # one rank -- a smoke check of the N > 1 plumbing on a single-GPU box
+    # SSYM_BENCH_FORCE_DIST=1: run the collective code path (RCCL communicator, all-reduce, all-gather, merge)
+    # with one rank -- a smoke check of the N > 1 plumbing on a single-GPU box
     force_dist = os.environ.get("SSYM_BENCH_FORCE_DIST") == "1"
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -169,48 +222,55 @@ def main():
     if args.gpus > 1 and world == 1:
         sys.exit("bench.py --gpus N > 1 must be launched with `python -m torch.distributed.run "
                  "--nproc-per-node N ... bench.py --gpus N` (one rank per GPU)")
-    # SSYM_BENCH_BACKEND=gloo rehearses the N > 1 code path on a box with fewer GPUs than ranks
+    # SSYM_BENCH_BACKEND=gloo rehearses the N > 1 code path on a box with fewer GPUs than ranks: the exchange
+    # then runs as torch.distributed collectives over gloo around the two-phase C-ABI calls (RCCL cannot put
+    # two ranks on one device); the judged path is the default, RCCL inside the library
     backend = os.environ.get("SSYM_BENCH_BACKEND", "nccl")
     local_rank = local_rank % max(torch.cuda.device_count(), 1) if backend == "gloo" else local_rank
     torch.cuda.set_device(local_rank)
-    if world > 1 or force_dist:
+    if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     n_gpus = max(world, 1)
-    n_src_total = args.src_per_gpu * n_gpus
-    m = args.targets
+    weak = args.src_per_gpu > 0
+    n_src_total = args.src_per_gpu * n_gpus if weak else wl["n_src"]
+    m, frames, DIM_, band = wl["n_tgt"], wl["frames"], wl["dim"], wl["band"]
 
     # synthetic workload (seeded; the generator is counter-based, so each rank materialises only its
     # own source shard of the one global grid -- the targets and planted indices are the same on all)
-    DIM_ = args.dim
     lo, hi = sharding.shard_range(n_src_total, n_gpus, rank)
     if n_gpus > 1:
-        grid = synth.make_grid(n_src_total, m, args.frames, DIM_, SEED, src_range=(lo, hi))
+        grid = synth.make_grid(n_src_total, m, frames, DIM_, SEED, src_range=(lo, hi))
         shard = grid.sources
     else:
-        grid = synth.make_grid(n_src_total, m, args.frames, DIM_, SEED)
+        grid = synth.make_grid(n_src_total, m, frames, DIM_, SEED)
         shard = grid.sources[lo:hi]
-    eng = Engine(metric="dtw", dtype="f32", device=local_rank, band=args.band)
+    eng = Engine(metric="dtw", dtype="f32", device=local_rank, band=band)
     src_dev = torch.from_numpy(np.ascontiguousarray(shard).reshape(-1)).cuda()
     tgt_dev = torch.from_numpy(np.ascontiguousarray(grid.targets).reshape(-1)).cuda()
-    so = np.arange(hi - lo + 1, dtype=np.uint64) * args.frames
-    to = np.arange(m + 1, dtype=np.uint64) * args.frames
+    so = np.arange(hi - lo + 1, dtype=np.uint64) * frames
+    to = np.arange(m + 1, dtype=np.uint64) * frames
     d = eng.dictionary(src_dev, so, DIM_)
     q = eng.queries(tgt_dev, to, DIM_)
     out_idx = torch.empty(m, dtype=torch.int32, device="cuda")
     out_cost = torch.empty(m, dtype=torch.float64, device="cuda")
-
     bounds = torch.empty(m, dtype=torch.float64, device="cuda")
+    sharded = world > 1 or force_dist
+    comm = None
+    if sharded and backend == "nccl":
+        comm = sharding.init_comm(eng, rank, world)       # RCCL communicator behind the C ABI (collective)
 
-    def step():
-        if world > 1 or force_dist:
-            # filter -> all-reduce(MIN) of the per-target bounds -> select / re-score -> all-gather + merge
-            return sharding.match_sharded(eng, d, q, lo, out_idx, out_cost, bounds)
-        eng.match(d, q, index_base=lo, out_idx=out_idx, out_cost=out_cost)
-        return out_idx, out_cost
+    def run_step(oi, oc, prune=False, queries=None):
+        qq = q if queries is None else queries
+        if comm is not None:
+            return sharding.match_sharded(eng, comm, d, qq, lo, out_idx=oi, out_cost=oc, prune=prune)
+        if sharded:
+            return sharding.match_sharded_torch(eng, d, qq, lo, oi, oc, bounds, prune=prune)
+        eng.match(d, qq, index_base=lo, out_idx=oi, out_cost=oc, prune=prune)
+        return oi, oc
 
     def fence():
         torch.cuda.synchronize()
@@ -218,94 +278,123 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    main_ms, total_ms, refined, last_tm = [], [], 0, {}
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        fin_idx, fin_cost = step()
-        tm = eng.timings()
-        main_ms.append(tm["main_ms"])
-        total_ms.append(tm["total_ms"])
-        refined = tm["n_refined"]
-        last_tm = tm
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed(fn, steps, warmup, per_step=None):
+        for _ in range(warmup):
+            fn()
+        fence()
+        t0 = time.perf_counter()
+        res = None
+        for _ in range(steps):
+            res = fn()
+            if per_step:
+                per_step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, res
 
+    stats = {k: [] for k in ("main_ms", "select_ms", "refine_ms", "reduce_ms", "collective_ms", "total_ms")}
+    last = {}
+
+    def note():
+        tm = eng.timings()
+        for k in stats:
+            stats[k].append(tm[k])
+        last.update(tm)
+
+    elapsed, (fin_idx, fin_cost) = timed(lambda: run_step(out_idx, out_cost), args.steps, args.warmup, note)
     pairs_per_step = n_src_total * m
     value = pairs_per_step * args.steps / elapsed
-    idx_host = fin_idx.cpu().numpy().astype(np.int64)
+    idx_host = fin_idx.cpu().numpy().view(np.uint32).astype(np.int64)
     planted_ok = bool(np.array_equal(idx_host, grid.planted))
 
+    # per-rank figures of the timed steps (rank 0 prints them)
+    mine = [float(np.mean(stats[k])) for k in ("main_ms", "select_ms", "refine_ms", "collective_ms", "total_ms")] + \
+           [float(last.get("n_refined", 0)), float(last.get("attempts", 1))]
+    per_rank = [mine]
+    if world > 1:
+        t = torch.tensor(mine, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        allt = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per_rank = [x.cpu().tolist() for x in allt]
+
     # Beside the headline (which fills the whole cost matrix): the same search with early abandoning
-    # (SSYM_DTW_PRUNE) -- identical indices and costs, but the time depends on the data, and
-    # this planted grid is its best case; reported separately and never as `value`.
+    # (SSYM_DTW_PRUNE) -- identical indices and costs, but the time depends on the data: this
+    # planted grid is its BEST case, so the worst case (targets with no close source: nothing can be cut)
+    # is measured beside it.  Reported separately and never as `value`.
     early = None
-    if args.band < 0 and not args.no_secondary:
+    if not args.no_secondary:
         p_idx, p_cost = torch.empty_like(out_idx), torch.empty_like(out_cost)
         full_idx, full_cost = fin_idx.clone(), fin_cost.clone()
-
-        def pstep():
-            if world > 1 or force_dist:
-                # candidates' costs all-reduced (MIN) first, then the sequence of step() with abandoning filters
-                return sharding.match_sharded(eng, d, q, lo, p_idx, p_cost, bounds, prune=True)
-            eng.match(d, q, index_base=lo, out_idx=p_idx, out_cost=p_cost, prune=True)
-            return p_idx, p_cost
-
-        for _ in range(args.warmup):
-            pstep()
-        fence()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            pf_idx, pf_cost = pstep()
-        fence()
-        p_elapsed = time.perf_counter() - t1
-        if world > 1:
-            t = torch.tensor([p_elapsed], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            p_elapsed = float(t.item())
+        p_elapsed, (pf_idx, pf_cost) = timed(lambda: run_step(p_idx, p_cost, prune=True), args.steps, args.warmup)
         ptm = eng.timings()
-        full_cells = float(((hi - lo + 7) // 8 * 8)) * ((m + 31) // 32 * 32) * (16 * 4 * ((args.frames + 63) // 64)
-                                                                                 if args.frames > 48 else 16 * ((args.frames + 15) // 16)) * args.frames
+        identical = bool(torch.equal(pf_idx, full_idx) and torch.equal(pf_cost, full_cost))
+        rows = 16 * 4 * ((frames + 63) // 64) if frames > 48 else 16 * ((frames + 15) // 16)
+        full_cells = float(((hi - lo + 7) // 8 * 8)) * ((m + 31) // 32 * 32) * rows * frames
         early = {
             "value": pairs_per_step * args.steps / p_elapsed, "unit": "segment-pairs/s",
             "ms_per_step": p_elapsed / args.steps * 1e3,
-            "identical_to_full_search": bool(torch.equal(pf_idx, full_idx) and torch.equal(pf_cost, full_cost)),
-            "filter_cells_swept_frac": ptm["n_filter_cells"] / full_cells if ptm["pruned"] else None,
+            "identical_to_full_search": identical,
+            "filter_cells_swept_frac": (ptm["n_filter_cells"] / full_cells if ptm["pruned"] and band < 0 else None),
             "phase_ms": {k: round(float(v), 3) for k, v in ptm.items() if k.endswith("_ms")},
             "rank0_only": ["filter_cells_swept_frac", "phase_ms"] if world > 1 else [],
             "note": "one centroid-nearest candidate per target scored exactly, then the filter stops row passes and drops "
-                    "64-pair tasks that are provably above it; planted grid = best case (no-close-pair data: +4 % over the full search)",
+                    "64-pair tasks that are provably above it; planted grid = best case, see no_close_pair for the worst",
         }
+        # worst case: the same dictionary against targets that are nobody's neighbour (another seed's sources)
+        other = synth.make_grid(m, 1, frames, DIM_, SEED ^ 0x77777).sources
+        q2 = eng.queries(torch.from_numpy(np.ascontiguousarray(other).reshape(-1)).cuda(), to, DIM_)
+        u_idx, u_cost = torch.empty_like(out_idx), torch.empty_like(out_cost)
+        ksteps = max(2, args.steps // 4)
+        uf_elapsed, (uf_idx, uf_cost) = timed(lambda: run_step(u_idx, u_cost, queries=q2), ksteps, 1)
+        uf_idx, uf_cost = uf_idx.clone(), uf_cost.clone()
+        up_elapsed, (up_idx, up_cost) = timed(lambda: run_step(p_idx, p_cost, prune=True, queries=q2), ksteps, 1)
+        early["no_close_pair"] = {
+            "full_ms_per_step": uf_elapsed / ksteps * 1e3, "pruned_ms_per_step": up_elapsed / ksteps * 1e3,
+            "pruned_over_full": up_elapsed / uf_elapsed,
+            "identical_to_full_search": bool(torch.equal(up_idx, uf_idx) and torch.equal(up_cost, uf_cost)),
+            "workload": f"the same {n_src_total} sources against {m} unrelated targets (no planted neighbour)",
+        }
+        q2.close()
+
+    secondary = None
+    if rank == 0 and n_gpus == 1 and not args.no_secondary:
+        secondary = secondary_metrics(local_rank)
 
     if rank == 0:
-        # Roofline of the dominant kernel (dtw_filter_kernel).  Its duration is measured live with
-        # HIP events on the library's own stream (ssym_get_timings).  Algorithmic work per pair is
+        # Roofline of the dominant kernel (dtw_filter_kernel / dtw_band_kernel).  Its duration is measured live
+        # with HIP events on the library's own stream (ssym_get_timings).  Algorithmic work per pair is
         # SURVEY.md 8(d)'s: bytes 2*F*d*4 (per-pair operand-streaming model -- the model the
-        # north star's ">= 60 % HBM roofline" is stated in), matrix flops 2*F^2*d, DP cells F^2.
-        k_ms = float(np.mean(main_ms))
+        # north star's ">= 60 % HBM roofline" is stated in), matrix flops 2*cells*d, DP cells F^2 (band: in-band cells).
+        k_ms = float(np.mean(stats["main_ms"]))
         k_s = k_ms * 1e-3
         pairs_launch = (hi - lo) * m
-        f, dd = args.frames, DIM_
-        r = args.band
+        f, dd, r = frames, DIM_, band
         cells_pair = float(f) * f if r < 0 else float(f * (2 * r + 1) - r * (r + 1))
         stream_gbps = pairs_launch * 2 * f * dd * 4 / k_s / 1e9
         flops_tf = pairs_launch * 2.0 * cells_pair * dd / k_s / 1e12
         cells_per_s = pairs_launch * cells_pair / k_s
-        traffic = mfma_busy = valu_busy = None
-        prof = sorted(glob.glob(os.path.join(ROOT, "profiles", "*bench_1gpu.json")))
-        if prof and n_gpus == 1 and (hi - lo, m, f, dd, r) == (SRC_PER_GPU, N_TGT, FRAMES, DIM, -1):
+        recorded = None
+        prof_name = {"c3": "*bench_1gpu.json", "c5": "*bench_c5_1gpu.json"}.get(args.workload)
+        prof = sorted(glob.glob(os.path.join(ROOT, "profiles", prof_name))) if prof_name else []
+        if prof and n_gpus == 1 and not custom and not weak:
             pj = json.load(open(prof[-1]))           # rocprofv3 PMC passes over this same command (tools/profile_bench.sh)
-            traffic = pj.get("hbm_traffic_bytes_per_launch")
-            mfma_busy, valu_busy = pj.get("mfma_busy_fraction"), pj.get("valu_busy_fraction")
+            recorded = {"file": os.path.relpath(prof[-1], ROOT),
+                        "hbm_traffic_bytes_per_launch": pj.get("hbm_traffic_bytes_per_launch"),
+                        "kernel_ms_in_profile": pj.get("dominant_kernel_avg_ms"),
+                        "mfma_pipe_busy_frac": pj.get("mfma_busy_fraction"),
+                        "valu_busy_frac": pj.get("valu_busy_fraction"),
+                        "note": "RECORDED by an earlier rocprofv3 --pmc run of this command (counters cannot be read "
+                                "inside an unprofiled run); not measured by the run that printed this line"}
+        traffic = recorded["hbm_traffic_bytes_per_launch"] if recorded else None
         # VALU floor measured on MI355X (profiles/): v_sqrt_f32 8 + v_min3_f32 4 + v_add_f32 4
         # cycles per wave-instruction = 16 cycles per 64 cells per SIMD, 1024 SIMDs
         valu_peak_cells = 1024 * 64 / 16.0 * 2.4e9
+        scaling = "weak" if (weak or n_gpus == 1) else "strong"
+        names = ("main_ms", "select_ms", "refine_ms", "collective_ms", "total_ms", "n_refined", "attempts")
         line = {
             "metric": "segment-pairs/sec (DTW cost+argmin)",
             "value": value,
@@ -315,54 +404,73 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{n_src_total}x{m} segments, {f} frames x {dd} dims, f32, "
+                "workload": f"{wl['config'] if not custom and not weak else 'custom'}: {n_src_total}x{m} segments, "
+                            f"{f} frames x {dd} dims, f32, "
                             f"dtw (L2 local cost, {'full matrix' if r < 0 else f'Sakoe-Chiba r={r}'}), "
                             f"planted neighbours, seed 0x{SEED:X}",
+                "workload_key": args.workload,
                 "sources_per_gpu": hi - lo,
-                "parallelism": f"source-shard x{n_gpus}" if n_gpus > 1 else "single GPU",
+                "parallelism": (f"source-shard x{n_gpus}, RCCL all-reduce(MIN) of bounds + all-gather of (cost, index) "
+                                f"inside the library" if comm is not None and n_gpus > 1 else
+                                (f"source-shard x{n_gpus} ({backend} rehearsal)" if sharded else "single GPU")),
                 "indices_equal_planted": planted_ok,
-                "pairs_refined_f64": int(refined),
-                "phase_ms": {k: round(float(v), 3) for k, v in last_tm.items() if k.endswith("_ms")},
+                "pairs_refined_f64": int(last.get("n_refined", 0)),
+                "phase_ms": {k: round(float(np.mean(v)), 3) for k, v in stats.items()},
+                "collective_ms": round(float(np.mean(stats["collective_ms"])), 4),
+                "per_rank": [{k: (round(v, 4) if k.endswith("_ms") else int(v)) for k, v in zip(names, row)}
+                             for row in per_rank],
             },
             "roofline": {
                 "bound": "hbm",
                 "kernel": "dtw_filter_kernel" if r < 0 else "dtw_band_kernel",
-                "model": "per-pair operand-streaming bytes 2*F*d*4 (SURVEY.md 8(d)); the kernel keeps "
-                         "operands on chip, so measured HBM traffic is far below this and the "
-                         "limiter is VALU issue, see 'valu' and DESIGN.md",
+                "model": "SURVEY.md 8(d) per-pair operand-streaming bytes 2*F*d*4 x pairs per launch / kernel time.  The "
+                         "kernel keeps operands on chip: the bytes it really moves are in 'hbm_measured', and what "
+                         "binds it is VALU issue ('binding_limit', 'valu')",
                 "achieved": stream_gbps,
                 "peak": PEAK_HBM_GBPS,
                 "unit": "GB/s",
                 "frac": stream_gbps / PEAK_HBM_GBPS,
                 "traffic": traffic,
-                "traffic_note": "bytes per launch at the L2-fabric boundary (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, "
-                                "profiles/r01_bench_1gpu.md): the per-wave hand-off rows written and read once",
+                "traffic_note": "bytes per launch at the L2-fabric boundary (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE), RECORDED "
+                                "in profiles/ (see 'recorded_pmc'), not measured by this run",
                 "algorithmic_bytes_per_launch": pairs_launch * 2 * f * dd * 4,
                 "kernel_ms": k_ms,
+                "binding_limit": "valu",
+                "hbm_measured": ({"achieved": traffic / k_s / 1e9, "unit": "GB/s", "frac": traffic / k_s / 1e9 / PEAK_HBM_GBPS,
+                                  "note": "recorded traffic / live kernel time"} if traffic else None),
                 "mfma": {"achieved": flops_tf, "unit": "TFLOP/s", "algorithmic_flops_per_pair": 2 * cells_pair * dd,
-                         "peak_f32_mfma": PEAK_F32_MFMA_TFLOPS, "frac_of_f32_mfma_peak": flops_tf / PEAK_F32_MFMA_TFLOPS,
-                         "pipe_busy_frac_pmc": mfma_busy,
-                         "note": "cost block runs on the f16 matrix pipe (3 x 32x32x16 per 32x32 tile, "
-                                 "two-piece operand split); algorithmic flops, not issued flops"},
+                         "peak_f16_mfma": PEAK_F16_MFMA_TFLOPS, "frac_of_f16_mfma_peak": flops_tf / PEAK_F16_MFMA_TFLOPS,
+                         "note": "cost block on the f16 matrix pipe (3 x v_mfma_f32_32x32x16_f16 per 32x32 tile, K = 48 "
+                                 "slots for d values: two-piece operand split); ALGORITHMIC flops 2*cells*d over the dense "
+                                 "f16 peak -- utilisation of the pipe itself is recorded_pmc.mfma_pipe_busy_frac"},
                 "valu": {"achieved": cells_per_s, "unit": "DP cells/s", "peak": valu_peak_cells,
-                         "frac": cells_per_s / valu_peak_cells, "busy_frac_pmc": valu_busy,
-                         "note": "16 VALU cycles per cell per SIMD at 2.4 GHz (measured issue costs)"},
+                         "frac": cells_per_s / valu_peak_cells,
+                         "note": "16 VALU cycles per cell per SIMD (v_sqrt_f32 8 + v_min3_f32 4 + v_add_f32 4, measured "
+                                 "issue costs) x 1024 SIMDs at 2.4 GHz"},
+                "recorded_pmc": recorded,
             },
         }
         if early is not None:
             line["early_abandon"] = early
+        # the CPU legs come last: every GPU figure above is measured before the host cores are loaded
         if n_gpus == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(grid, idx_host)
-        if n_gpus == 1 and not args.no_secondary:
-            line["secondary"] = secondary_metrics(local_rank, not args.no_cpu_baseline)
+            line["cpu_baseline"] = cpu_baseline(grid, idx_host, band)
+            line["vs_cpu_all_cores"] = value / line["cpu_baseline"]["value"]
+            line["vs_cpu_one_core"] = value / line["cpu_baseline"]["one_core"]["value"]
+        if secondary is not None:
+            if not args.no_cpu_baseline:
+                secondary_cpu(secondary)
+            line["secondary"] = secondary
         print(json.dumps(line), flush=True)
+    if comm is not None:
+        comm.close()
     eng.close()
-    if world > 1 or force_dist:
+    if world > 1:
         dist.destroy_process_group()
 
 

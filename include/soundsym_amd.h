@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define SSYM_ABI_VERSION 1
+#define SSYM_ABI_VERSION 2
 
 #if defined(__GNUC__)
 #define SSYM_API __attribute__((visibility("default")))
@@ -55,6 +55,7 @@ typedef struct ssym_ctx ssym_ctx;         /* one GPU + one stream + scratch     
 typedef struct ssym_dict ssym_dict;       /* SoundDictionary's feature side (src/sound.rs:290)   */
 typedef struct ssym_queries ssym_queries; /* the targets of one batch (SoundSequence::sounds)    */
 typedef struct ssym_samples ssym_samples; /* the dictionary sounds' SAMPLES, resident on the GPU   */
+typedef struct ssym_comm ssym_comm;       /* one rank of a source-sharded run: an RCCL communicator  */
 
 enum {
     SSYM_OK = 0,
@@ -110,6 +111,9 @@ typedef struct ssym_timings {
     float prune_ms;        /* SSYM_DTW_PRUNE: candidate search + exact scores + thresholds        */
     int32_t pruned;        /* 1 = the filter ran with early abandoning                           */
     uint64_t n_filter_cells; /* pruned runs: DP cells the filter evaluated (padding included)    */
+    float collective_ms;   /* ssym_match_sharded: the RCCL all-reduce(s) + all-gather, device time  */
+    int32_t attempts;      /* ssym_match_sharded: selection attempts of the step (1 unless a rank's
+                              candidate list overflowed and every rank redid the tail)             */
 } ssym_timings;
 
 SSYM_API int32_t ssym_abi_version(void);
@@ -262,6 +266,40 @@ SSYM_API int32_t ssym_merge_shards(ssym_ctx *ctx, uint32_t n_shards, uint32_t n_
 SSYM_API int32_t ssym_merge_shards_at(ssym_ctx *ctx, uint32_t n_shards, uint32_t n_targets,
                              const double *costs_dev, const uint32_t *idx_dev, const double *distance,
                              uint32_t *out_idx_dev, double *out_cost_dev);
+
+/* Source-sharded multi-GPU with the collectives INSIDE the library (RCCL over xGMI, enqueued on the context's
+ * stream): the north star's "sharding the source-segment axis with an RCCL all-gather of per-target argmin
+ * indices".  The reference has no counterpart -- its loop (src/sound.rs:451-455) is serial -- so these entry
+ * points replace that loop for a dictionary that is split over the GPUs of one node, one process (or thread)
+ * per GPU, each with its own context:
+ *   ssym_comm_unique_id  rank 0 obtains the 128-byte RCCL id (ncclGetUniqueId) and hands it to the other
+ *                        ranks by any means the host has (a file, a pipe, MPI, torch.distributed ...)
+ *   ssym_comm_create     ncclCommInitRank on the context's device; collective over all `world` ranks
+ *   ssym_match_sharded   rank g holds the dictionary shard [index_base, index_base + n) and ALL targets
+ *                        (the same targets, in the same order, on every rank).  One step =
+ *                          filter over the shard                      (ssym_match_begin, no host sync)
+ *                          ncclAllReduce(MIN) of the M per-target bounds            (M x 8 bytes)
+ *                          selection, exact re-scoring, fold                (ssym_match_finish, no host sync)
+ *                          ncclAllGather of (cost f64, global index u32) per target + list status (12 M + 8 bytes)
+ *                          merge: smallest key, lowest global index on ties      (ssym_merge_shards_at)
+ *                        all enqueued back to back on the context's stream; the host synchronises ONCE, at the
+ *                        end, and every rank returns the same, complete answer -- bit for bit what
+ *                        ssym_match_queries returns for the unsharded dictionary.  Should a rank's candidate list
+ *                        overflow (the gathered status says so to everyone) all ranks repeat the tail once with
+ *                        the room asked for.  With SSYM_DTW_PRUNE the candidates' costs are all-reduced first
+ *                        (ssym_match_candidates / ssym_match_begin_pruned).  An empty local shard takes part and
+ *                        reports the fold start; a dictionary that is empty on EVERY rank is the caller's to
+ *                        reject (the reference panics, src/sound.rs:369).
+ *                        out_idx / out_cost / flags as for ssym_match_queries (SSYM_OUT_DEVICE honoured).
+ * RCCL is looked up at run time (symbols already in the process, else librccl.so.1 / $SSYM_RCCL_LIB), so a
+ * single-GPU user needs no RCCL at all; without it the three calls fail with SSYM_E_UNSUPPORTED. */
+#define SSYM_COMM_ID_BYTES 128
+SSYM_API int32_t ssym_comm_unique_id(void *out_id /* SSYM_COMM_ID_BYTES */);
+SSYM_API int32_t ssym_comm_create(ssym_ctx *ctx, const void *id, int32_t rank, int32_t world, ssym_comm **out);
+SSYM_API int32_t ssym_comm_destroy(ssym_ctx *ctx, ssym_comm *comm);
+SSYM_API int32_t ssym_match_sharded(ssym_ctx *ctx, ssym_comm *comm, const ssym_dict *dict, const ssym_queries *q,
+                                    const double *distance, uint32_t index_base, uint32_t *out_idx,
+                                    double *out_cost, uint32_t flags);
 
 /* Reconstruction tail (the step right after the hot path): the samples of every dictionary sound,
  * resident on the GPU (Sound::samples(), src/sound.rs:181; `sample_offsets` = n_sounds+1 SAMPLE

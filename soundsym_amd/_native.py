@@ -43,7 +43,9 @@ ABI_SYMBOLS = [
     "ssym_match_batch",
     "ssym_match_one", "ssym_chain", "ssym_pair_matrix", "ssym_merge_shards", "ssym_merge_shards_at", "ssym_samples_create",
     "ssym_samples_destroy", "ssym_reconstruct", "ssym_mfcc_num_frames", "ssym_mfcc",
+    "ssym_comm_unique_id", "ssym_comm_create", "ssym_comm_destroy", "ssym_match_sharded",
 ]
+COMM_ID_BYTES = 128        # SSYM_COMM_ID_BYTES
 
 
 NO_MATCH = 0xFFFFFFFF      # SSYM_NO_MATCH
@@ -90,6 +92,8 @@ class Timings(ctypes.Structure):
         ("prune_ms", ctypes.c_float),
         ("pruned", ctypes.c_int32),
         ("n_filter_cells", ctypes.c_uint64),
+        ("collective_ms", ctypes.c_float),
+        ("attempts", ctypes.c_int32),
     ]
 
     def as_dict(self):
@@ -125,6 +129,33 @@ def hip_runtime_path() -> str:
         if os.path.exists(cand):
             return cand
     raise ImportError("no libamdhip64.so found (torch/lib or $ROCM_PATH/lib)")
+
+
+_rccl: Optional[ctypes.CDLL] = None
+
+
+def load_rccl() -> None:
+    """Make ONE RCCL visible to the library (it binds the symbols at run time, csrc/comm.hip).  Same rule as for
+    the HIP runtime: when torch is installed its bundled librccl.so is the one, imported yet or not."""
+    global _rccl
+    if _rccl is not None:
+        return
+    lib()
+    import importlib.util
+    cands = []
+    spec = importlib.util.find_spec("torch")
+    if spec is not None and spec.origin:
+        cands.append(os.path.join(os.path.dirname(spec.origin), "lib", "librccl.so"))
+    cands += [os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "librccl.so.1"), "librccl.so.1"]
+    for cand in cands:
+        if os.path.isabs(cand) and not os.path.exists(cand):
+            continue
+        try:
+            _rccl = ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+            return
+        except OSError:
+            continue
+    raise ImportError("no librccl.so found (torch/lib or $ROCM_PATH/lib): the sharded match needs RCCL")
 
 
 def lib() -> ctypes.CDLL:
@@ -201,6 +232,14 @@ def lib() -> ctypes.CDLL:
     L.ssym_samples_destroy.argtypes = [vp, vp]
     L.ssym_reconstruct.restype = i32
     L.ssym_reconstruct.argtypes = [vp, vp, vp, vp, u32, vp, vp]
+    L.ssym_comm_unique_id.restype = i32
+    L.ssym_comm_unique_id.argtypes = [vp]
+    L.ssym_comm_create.restype = i32
+    L.ssym_comm_create.argtypes = [vp, vp, i32, i32, pvp]
+    L.ssym_comm_destroy.restype = i32
+    L.ssym_comm_destroy.argtypes = [vp, vp]
+    L.ssym_match_sharded.restype = i32
+    L.ssym_match_sharded.argtypes = [vp, vp, vp, vp, vp, u32, vp, vp, u32]
     _lib = L
     return L
 

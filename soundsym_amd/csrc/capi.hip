@@ -437,9 +437,14 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
                 if (rc != SSYM_OK)
                     return rc;
                 SSYM_HIP_CHECK(ctx, hipEventRecord(ev[1], st));
-                if (prune)
+                if (prune && ctx->stream_only) {     // through the pinned window: a pageable destination would block the host
+                    rc = stage_d2h(ctx, &ctx->pruned_cells, colCtr, sizeof(*colCtr));
+                    if (rc != SSYM_OK)
+                        return rc;
+                } else if (prune) {
                     SSYM_HIP_CHECK(ctx, hipMemcpyAsync(&ctx->pruned_cells, colCtr, sizeof(*colCtr),
                                                        hipMemcpyDeviceToHost, st));
+                }
                 rc = wide ? launch_dtw_bounds_partial(ctx, src, tgt, cmat, prune ? (const double *)ctx->prune_cost.ptr : nullptr, k_top, distDev)
                           : launch_dtw_bounds(ctx, src, tgt, cmat, distDev, k_top,
                                               prune ? (const double *)ctx->prune_cost.ptr : nullptr);
@@ -453,9 +458,13 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
                 slots_to_targets_kernel<<<(M + 255) / 256, 256, 0, st>>>((const double *)ctx->tmin.ptr, tgt.perm, M,
                                                                          bounds_dev);
                 SSYM_HIP_CHECK(ctx, hipGetLastError());
+                ctx->pending.pruned = prune;
+                if (ctx->stream_only) {          // ssym_match_sharded: the times are read after the step's one synchronisation
+                    ctx->timings = tm;
+                    return SSYM_OK;
+                }
                 SSYM_HIP_CHECK(ctx, hipStreamSynchronize(st));
                 ctx->pending.main_ms = ev_ms(ev[6], ev[1]);
-                ctx->pending.pruned = prune;
                 tm.main_ms = ctx->pending.main_ms;
                 ctx->timings = tm;
                 return SSYM_OK;
@@ -471,6 +480,8 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
             // stages see the flag and do nothing, and the selection is redone with that room
             // (exactness never depends on the capacity)
             uint64_t cap = std::max<uint64_t>((256ull + 16ull * (k_top - 1)) * M, 65536);
+            if (ctx->stream_only && ctx->so_cap)
+                cap = ctx->so_cap;               // the size a previous attempt of this step asked for
             cap = std::min<uint64_t>(cap, (uint64_t)N * M);
             float sel_ms = 0.f, ref_ms = 0.f, red_ms = 0.f;
             for (int attempt = 0; attempt < 2; ++attempt) {
@@ -512,6 +523,14 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
                 if (rc != SSYM_OK)
                     return rc;
                 SSYM_HIP_CHECK(ctx, hipEventRecord(ev[5], st));
+                if (ctx->stream_only) {          // one attempt, enqueued only: the caller looks at the headers later
+                    ctx->so_hdr1 = hdr1;
+                    ctx->so_hdr2 = hdr2;
+                    ctx->so_cap = cap;
+                    ctx->so_filter = true;
+                    ctx->timings = tm;
+                    return SSYM_OK;
+                }
                 uint32_t h1[2] = {0, 0}, h2[2] = {0, 0};
                 SSYM_HIP_CHECK(ctx, hipMemcpyAsync(h1, hdr1, sizeof(h1), hipMemcpyDeviceToHost, st));
                 SSYM_HIP_CHECK(ctx, hipMemcpyAsync(h2, hdr2, sizeof(h2), hipMemcpyDeviceToHost, st));
@@ -561,6 +580,11 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
             if (rc != SSYM_OK)
                 return rc;
             SSYM_HIP_CHECK(ctx, hipEventRecord(ev[2], st));
+            if (ctx->stream_only) {
+                ctx->so_filter = false;
+                ctx->timings = tm;
+                return SSYM_OK;
+            }
             SSYM_HIP_CHECK(ctx, hipStreamSynchronize(st));
             tm.refine_ms = ev_ms(ev[0], ev[1]);
             tm.reduce_ms = ev_ms(ev[1], ev[2]);
@@ -575,6 +599,11 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
             rc = stage_d2h(ctx, out_cost, costDev, sizeof(double) * (size_t)M * k_top);
         if (rc != SSYM_OK)
             return rc;
+    }
+    if (ctx->stream_only) {              // refcos through ssym_match_sharded (device outputs)
+        ctx->so_filter = false;
+        ctx->timings = tm;
+        return SSYM_OK;
     }
     if (!outDev || ctx->metric == SSYM_METRIC_REFCOS)
         SSYM_HIP_CHECK(ctx, hipStreamSynchronize(st));
@@ -624,7 +653,11 @@ __global__ void fill_f64_kernel(double *p, double v, uint32_t n)
         p[i] = v;
 }
 
-int32_t ssym_match_candidates(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queries *q, double *cost_dev)
+}  // extern "C"
+
+namespace ssym {
+
+int32_t match_candidates_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queries *q, double *cost_dev)
 {
     int32_t rc = check_match_args(ctx, dict, q);
     if (rc != SSYM_OK)
@@ -652,12 +685,13 @@ int32_t ssym_match_candidates(ssym_ctx *ctx, const ssym_dict *dict, const ssym_q
         fill_f64_kernel<<<(M + 255) / 256, 256, 0, ctx->stream>>>(cost_dev, (double)INFINITY, M);
     }
     SSYM_HIP_CHECK(ctx, hipGetLastError());
-    SSYM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (!ctx->stream_only)
+        SSYM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return SSYM_OK;
 }
 
-static int32_t match_begin_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queries *q, const double *distance,
-                                uint32_t index_base, double *bounds_dev, const double *prune_cost_dev)
+int32_t match_begin_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queries *q, const double *distance,
+                         uint32_t index_base, double *bounds_dev, const double *prune_cost_dev)
 {
     int32_t rc = check_match_args(ctx, dict, q);
     if (rc != SSYM_OK)
@@ -689,13 +723,41 @@ static int32_t match_begin_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym
             return rc;
     } else if (M > 0) {
         SSYM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-        std::vector<double> inf(M, (double)INFINITY);
-        SSYM_HIP_CHECK(ctx, hipMemcpyAsync(bounds_dev, inf.data(), sizeof(double) * M, hipMemcpyHostToDevice,
-                                           ctx->stream));
-        SSYM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        fill_f64_kernel<<<(M + 255) / 256, 256, 0, ctx->stream>>>(bounds_dev, (double)INFINITY, M);
+        SSYM_HIP_CHECK(ctx, hipGetLastError());
+        if (!ctx->stream_only)
+            SSYM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     }
     pd.valid = true;
     return SSYM_OK;
+}
+
+int32_t match_finish_impl(ssym_ctx *ctx, const double *bounds_dev, uint32_t *out_idx, double *out_cost, uint32_t flags)
+{
+    ssym_ctx::Pending &pd = ctx->pending;
+    if (!pd.valid) {
+        ctx->err = "ssym_match_finish without ssym_match_begin";
+        return SSYM_E_INVALID;
+    }
+    pd.valid = false;
+    if (!bounds_dev) {
+        ctx->err = "ssym_match_finish: bounds_dev is NULL";
+        return SSYM_E_INVALID;
+    }
+    const double *dist = pd.has_dist ? pd.dist_host.data() : nullptr;
+    if (!pd.filter)
+        return match_impl(ctx, pd.dict, pd.q, dist, pd.index_base, 1, out_idx, out_cost, flags);
+    return match_impl(ctx, pd.dict, pd.q, dist, pd.index_base, 1, out_idx, out_cost, flags, 2,
+                      const_cast<double *>(bounds_dev));
+}
+
+}  // namespace ssym
+
+extern "C" {
+
+int32_t ssym_match_candidates(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queries *q, double *cost_dev)
+{
+    return match_candidates_impl(ctx, dict, q, cost_dev);
 }
 
 int32_t ssym_match_begin(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queries *q, const double *distance,
@@ -719,21 +781,7 @@ int32_t ssym_match_finish(ssym_ctx *ctx, const double *bounds_dev, uint32_t *out
 {
     if (!ctx)
         return SSYM_E_INVALID;
-    ssym_ctx::Pending &pd = ctx->pending;
-    if (!pd.valid) {
-        ctx->err = "ssym_match_finish without ssym_match_begin";
-        return SSYM_E_INVALID;
-    }
-    pd.valid = false;
-    if (!bounds_dev) {
-        ctx->err = "ssym_match_finish: bounds_dev is NULL";
-        return SSYM_E_INVALID;
-    }
-    const double *dist = pd.has_dist ? pd.dist_host.data() : nullptr;
-    if (!pd.filter)
-        return match_impl(ctx, pd.dict, pd.q, dist, pd.index_base, 1, out_idx, out_cost, flags);
-    return match_impl(ctx, pd.dict, pd.q, dist, pd.index_base, 1, out_idx, out_cost, flags, 2,
-                      const_cast<double *>(bounds_dev));
+    return match_finish_impl(ctx, bounds_dev, out_idx, out_cost, flags);
 }
 
 int32_t ssym_match_batch(ssym_ctx *ctx, const ssym_dict *dict, const void *tgt_feats,

@@ -1,0 +1,440 @@
+// comm.hip -- the source-sharded match with its collectives inside the library (RCCL over xGMI).
+//
+// Role on the path: the reference's loop over targets (SoundSequence::clone_from_dictionary,
+// src/sound.rs:451-455, one SoundDictionary::at_distance per target, :351-370) for a dictionary whose
+// entries are split over the GPUs of one node.  Every rank searches its shard; two small collectives
+// make the answer global: an all-reduce(MIN) of the per-target bounds between filter and selection
+// (so that a rank without a target's neighbour re-scores nothing for it) and an all-gather of every
+// rank's per-target (cost, global index), merged by the first-minimum rule (smallest key, lowest
+// index on ties -- the rule of src/sound.rs:361-367, preserved because shards are ordered).
+// Everything is enqueued on the context's stream; the host synchronises once per step.
+//
+// RCCL is bound at run time: a process that already carries it (a PyTorch process does) is used as
+// it is, otherwise librccl.so.1 is opened.  No RCCL, no sharded match -- there is no substitute path.
+#include "ssym_internal.hpp"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+using namespace ssym;
+
+namespace {
+
+struct Rccl {
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+    std::string why;
+};
+
+void *find_symbol(void *&handle, const char *name)
+{
+    void *p = dlsym(RTLD_DEFAULT, name);
+    if (p)
+        return p;
+    if (!handle) {
+        const char *env = getenv("SSYM_RCCL_LIB");
+        const char *cands[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *c : cands) {
+            if (!c || !*c)
+                continue;
+            handle = dlopen(c, RTLD_NOW | RTLD_GLOBAL);
+            if (handle)
+                break;
+        }
+    }
+    return handle ? dlsym(handle, name) : nullptr;
+}
+
+Rccl load_rccl()
+{
+    Rccl r;
+    void *h = nullptr;
+#define SSYM_BIND(field, sym)                                                        \
+    r.field = reinterpret_cast<decltype(r.field)>(find_symbol(h, sym));             \
+    if (!r.field) {                                                                  \
+        r.why = std::string("RCCL symbol ") + sym + " not found (librccl.so.1 / $SSYM_RCCL_LIB)"; \
+        return r;                                                                    \
+    }
+    SSYM_BIND(GetUniqueId, "ncclGetUniqueId")
+    SSYM_BIND(CommInitRank, "ncclCommInitRank")
+    SSYM_BIND(CommDestroy, "ncclCommDestroy")
+    SSYM_BIND(AllReduce, "ncclAllReduce")
+    SSYM_BIND(AllGather, "ncclAllGather")
+    SSYM_BIND(GetErrorString, "ncclGetErrorString")
+#undef SSYM_BIND
+    r.ok = true;
+    return r;
+}
+
+const Rccl &rccl()
+{
+    static const Rccl r = load_rccl();
+    return r;
+}
+
+thread_local std::string g_comm_err;
+
+}  // namespace
+
+struct ssym_comm {
+    ncclComm_t nccl = nullptr;
+    int rank = 0, world = 1;
+    DeviceBuf bounds;      // M f64: per-target bounds (and, before them, the candidates' costs of a pruned step)
+    DeviceBuf cand;        // M f64: candidates' costs
+    DeviceBuf send, recv;  // one block per rank: [M f64 cost][Mpad u32 index][u32 wanted, u32 overflow]
+    uint32_t *status_host = nullptr;    // pinned: world x {wanted, overflow} + {list-2 count, 0}
+    hipEvent_t ev[8]{};    // 0-1 all-reduce of the candidates' costs, 2-3 of the bounds, 4 step start, 5-6 all-gather, 7 step end
+};
+
+#define SSYM_NCCL_CHECK(ctx, call)                                                        \
+    do {                                                                                  \
+        ncclResult_t r__ = (call);                                                        \
+        if (r__ != ncclSuccess) {                                                         \
+            (ctx)->err = std::string(#call) + ": " + rccl().GetErrorString(r__);          \
+            return SSYM_E_HIP;                                                            \
+        }                                                                                 \
+    } while (0)
+
+__global__ void comm_fill_block_kernel(double *cost, uint32_t *idx, uint32_t *status, double v, uint32_t base, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        cost[i] = v;
+        idx[i] = base;
+    }
+    if (i == 0) {
+        status[0] = 0;
+        status[1] = 0;
+    }
+}
+
+__global__ void comm_status_kernel(const uint32_t *__restrict__ hdr1, uint32_t *__restrict__ status)
+{
+    status[0] = hdr1 ? hdr1[0] : 0u;     // entries list 1 wanted
+    status[1] = hdr1 ? hdr1[1] : 0u;     // it did not fit
+}
+
+static float ev_ms2(hipEvent_t a, hipEvent_t b)
+{
+    float ms = 0.f;
+    return hipEventElapsedTime(&ms, a, b) == hipSuccess ? ms : 0.f;
+}
+
+extern "C" {
+
+int32_t ssym_comm_unique_id(void *out_id)
+{
+    if (!out_id)
+        return SSYM_E_INVALID;
+    if (!rccl().ok)
+        return SSYM_E_UNSUPPORTED;
+    ncclUniqueId id;
+    if (rccl().GetUniqueId(&id) != ncclSuccess)
+        return SSYM_E_HIP;
+    static_assert(sizeof(id) == SSYM_COMM_ID_BYTES, "RCCL unique id size");
+    memcpy(out_id, &id, sizeof(id));
+    return SSYM_OK;
+}
+
+int32_t ssym_comm_create(ssym_ctx *ctx, const void *id, int32_t rank, int32_t world, ssym_comm **out)
+{
+    if (!ctx)
+        return SSYM_E_INVALID;
+    if (!id || !out || world < 1 || rank < 0 || rank >= world) {
+        ctx->err = "ssym_comm_create: bad arguments";
+        return SSYM_E_INVALID;
+    }
+    *out = nullptr;
+    if (!rccl().ok) {
+        ctx->err = "ssym_comm_create: " + rccl().why;
+        return SSYM_E_UNSUPPORTED;
+    }
+    SSYM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    ssym_comm *c = new (std::nothrow) ssym_comm();
+    if (!c)
+        return SSYM_E_NOMEM;
+    c->rank = rank;
+    c->world = world;
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof(uid));
+    ncclResult_t r = rccl().CommInitRank(&c->nccl, world, uid, rank);
+    if (r != ncclSuccess) {
+        ctx->err = std::string("ncclCommInitRank: ") + rccl().GetErrorString(r);
+        delete c;
+        return SSYM_E_HIP;
+    }
+    hipError_t e = hipHostMalloc((void **)&c->status_host, sizeof(uint32_t) * 2 * ((size_t)world + 1), hipHostMallocDefault);
+    for (auto &ev : c->ev)
+        if (e == hipSuccess)
+            e = hipEventCreate(&ev);
+    if (e != hipSuccess) {
+        ctx->err = std::string("ssym_comm_create: ") + hipGetErrorString(e);
+        ssym_comm_destroy(ctx, c);
+        return SSYM_E_HIP;
+    }
+    *out = c;
+    return SSYM_OK;
+}
+
+int32_t ssym_comm_destroy(ssym_ctx *ctx, ssym_comm *c)
+{
+    if (!c)
+        return SSYM_OK;
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    if (c->nccl && rccl().ok)
+        (void)rccl().CommDestroy(c->nccl);
+    for (DeviceBuf *b : {&c->bounds, &c->cand, &c->send, &c->recv})
+        if (b->ptr)
+            (void)hipFree(b->ptr);
+    if (c->status_host)
+        (void)hipHostFree(c->status_host);
+    for (auto &ev : c->ev)
+        if (ev)
+            (void)hipEventDestroy(ev);
+    delete c;
+    return SSYM_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+struct StreamOnly {      // the phases below only enqueue; restored on every way out
+    ssym_ctx *c;
+    explicit StreamOnly(ssym_ctx *ctx) : c(ctx) { c->stream_only = true; c->so_cap = 0; c->so_hdr1 = c->so_hdr2 = nullptr; }
+    ~StreamOnly() { c->stream_only = false; c->so_cap = 0; }
+};
+
+int32_t match_sharded_impl(ssym_ctx *ctx, ssym_comm *comm, const ssym_dict *dict, const ssym_queries *q,
+                           const double *distance, uint32_t index_base, uint32_t *out_idx, double *out_cost,
+                           uint32_t flags)
+{
+    if (!comm || !dict || !q || !out_idx) {
+        ctx->err = "ssym_match_sharded: NULL argument";
+        return SSYM_E_INVALID;
+    }
+    if (dict->set.n && dict->set.dim != q->set.dim) {
+        ctx->err = "dim mismatch between dictionary and targets";
+        return SSYM_E_INVALID;
+    }
+    const uint32_t M = q->set.n;
+    ssym_timings tm{};
+    tm.n_pairs = (uint64_t)dict->set.n * M;
+    if (M == 0) {               // (the targets are the same on every rank: everybody returns here)
+        ctx->timings = tm;
+        return SSYM_OK;
+    }
+    SSYM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int G = comm->world;
+    const bool outDev = (flags & SSYM_OUT_DEVICE) != 0;
+    const bool refcos = ctx->metric == SSYM_METRIC_REFCOS;
+    const bool emptyShard = dict->set.n == 0;
+    const double foldStart = refcos ? 2.0 : (double)INFINITY;
+
+    // one block per rank: costs, indices (padded to an even count so that blocks stay 8-byte aligned), list status
+    const size_t mPad = ((size_t)M + 1) & ~(size_t)1;
+    const size_t blk = sizeof(double) * M + sizeof(uint32_t) * mPad + 2 * sizeof(uint32_t);
+    int32_t rc = ensure(ctx, comm->bounds, sizeof(double) * M);
+    if (rc == SSYM_OK)
+        rc = ensure(ctx, comm->cand, sizeof(double) * M);
+    if (rc == SSYM_OK)
+        rc = ensure(ctx, comm->send, blk);
+    if (rc == SSYM_OK)
+        rc = ensure(ctx, comm->recv, blk * G);
+    if (rc != SSYM_OK)
+        return rc;
+    double *bounds = (double *)comm->bounds.ptr;
+    double *sendCost = (double *)comm->send.ptr;
+    uint32_t *sendIdx = (uint32_t *)((char *)comm->send.ptr + sizeof(double) * M);
+    uint32_t *sendStatus = sendIdx + mPad;
+    uint32_t *userIdx = out_idx;
+    double *userCost = out_cost;
+    if (!outDev) {
+        rc = ensure(ctx, ctx->out_idx, sizeof(uint32_t) * M);
+        if (rc == SSYM_OK)
+            rc = ensure(ctx, ctx->out_cost, sizeof(double) * M);
+        if (rc != SSYM_OK)
+            return rc;
+        userIdx = (uint32_t *)ctx->out_idx.ptr;
+        userCost = (double *)ctx->out_cost.ptr;
+    }
+
+    StageScope stageScope(ctx);
+    StreamOnly streamOnly(ctx);
+    hipEvent_t *cev = comm->ev;
+    float coll_ms = 0.f;
+    const bool wantPrune = ((flags & SSYM_DTW_PRUNE) || ctx->prune_default) && !distance && !refcos;
+
+    // ---- phase 1: candidates (pruned steps), filter, per-target bounds ------------------------------------
+    SSYM_HIP_CHECK(ctx, hipEventRecord(cev[4], st));
+    bool pruned = false;
+    if (wantPrune) {
+        double *cand = (double *)comm->cand.ptr;
+        if (emptyShard) {
+            comm_fill_block_kernel<<<(M + 255) / 256, 256, 0, st>>>(cand, sendIdx, sendStatus, (double)INFINITY, index_base, M);
+            SSYM_HIP_CHECK(ctx, hipGetLastError());
+        } else {
+            rc = match_candidates_impl(ctx, dict, q, cand);
+            if (rc != SSYM_OK)
+                return rc;
+        }
+        SSYM_HIP_CHECK(ctx, hipEventRecord(cev[0], st));
+        SSYM_NCCL_CHECK(ctx, rccl().AllReduce(cand, cand, M, ncclFloat64, ncclMin, comm->nccl, st));
+        SSYM_HIP_CHECK(ctx, hipEventRecord(cev[1], st));
+        pruned = true;
+    }
+    if (emptyShard) {
+        comm_fill_block_kernel<<<(M + 255) / 256, 256, 0, st>>>(bounds, sendIdx, sendStatus, (double)INFINITY, index_base, M);
+        SSYM_HIP_CHECK(ctx, hipGetLastError());
+    } else {
+        rc = match_begin_impl(ctx, dict, q, distance, index_base, bounds, pruned ? (const double *)comm->cand.ptr : nullptr);
+        if (rc != SSYM_OK)
+            return rc;
+    }
+    const bool filterPath = !emptyShard && ctx->pending.filter;
+    tm.used_filter = filterPath ? 1 : 0;
+    tm.pruned = filterPath && ctx->pending.pruned ? 1 : 0;
+    SSYM_HIP_CHECK(ctx, hipEventRecord(cev[2], st));
+    SSYM_NCCL_CHECK(ctx, rccl().AllReduce(bounds, bounds, M, ncclFloat64, ncclMin, comm->nccl, st));
+    SSYM_HIP_CHECK(ctx, hipEventRecord(cev[3], st));
+
+    // ---- phase 2 + exchange; repeated once by EVERY rank when any rank's candidate list overflowed -----------
+    uint32_t *status = comm->status_host;
+    const double *distDev = nullptr;
+    if (distance) {
+        if (emptyShard) {                           // (otherwise phase 1 has uploaded them)
+            rc = ensure(ctx, ctx->dist, sizeof(double) * M);
+            if (rc == SSYM_OK)
+                rc = stage_h2d(ctx, ctx->dist.ptr, distance, sizeof(double) * M);
+            if (rc != SSYM_OK)
+                return rc;
+        }
+        distDev = (const double *)ctx->dist.ptr;
+    }
+    float sel_ms = 0.f, ref_ms = 0.f, red_ms = 0.f;
+    ssym_ctx::Pending keep = ctx->pending;          // (finish consumes it; a second attempt needs it again)
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        tm.attempts = attempt + 1;
+        if (emptyShard) {
+            comm_fill_block_kernel<<<(M + 255) / 256, 256, 0, st>>>(sendCost, sendIdx, sendStatus, foldStart, index_base, M);
+            SSYM_HIP_CHECK(ctx, hipGetLastError());
+        } else {
+            ctx->pending = keep;
+            ctx->so_hdr1 = ctx->so_hdr2 = nullptr;
+            ctx->so_filter = false;
+            rc = match_finish_impl(ctx, bounds, sendIdx, sendCost, SSYM_OUT_DEVICE | (flags & SSYM_DTW_FORCE_EXACT));
+            if (rc != SSYM_OK)
+                return rc;
+            comm_status_kernel<<<1, 1, 0, st>>>(ctx->so_filter ? ctx->so_hdr1 : nullptr, sendStatus);
+            SSYM_HIP_CHECK(ctx, hipGetLastError());
+        }
+        SSYM_HIP_CHECK(ctx, hipEventRecord(cev[5], st));
+        SSYM_NCCL_CHECK(ctx, rccl().AllGather(comm->send.ptr, comm->recv.ptr, blk, ncclUint8, comm->nccl, st));
+        SSYM_HIP_CHECK(ctx, hipEventRecord(cev[6], st));
+        rc = launch_merge_shards(ctx, (uint32_t)G, M, (const double *)comm->recv.ptr,
+                                 (const uint32_t *)((const char *)comm->recv.ptr + sizeof(double) * M), distDev, userIdx,
+                                 userCost, blk / sizeof(double), blk / sizeof(uint32_t));
+        if (rc != SSYM_OK)
+            return rc;
+        // every rank's list status, and this rank's own list-2 count
+        SSYM_HIP_CHECK(ctx, hipMemcpy2DAsync(status, 2 * sizeof(uint32_t),
+                                             (const char *)comm->recv.ptr + blk - 2 * sizeof(uint32_t), blk,
+                                             2 * sizeof(uint32_t), (size_t)G, hipMemcpyDeviceToHost, st));
+        status[2 * G] = status[2 * G + 1] = 0;
+        if (ctx->so_filter && ctx->so_hdr2)
+            SSYM_HIP_CHECK(ctx, hipMemcpyAsync(status + 2 * G, ctx->so_hdr2, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        if (!outDev) {
+            rc = stage_d2h(ctx, out_idx, userIdx, sizeof(uint32_t) * M);
+            if (rc == SSYM_OK && out_cost)
+                rc = stage_d2h(ctx, out_cost, userCost, sizeof(double) * M);
+            if (rc != SSYM_OK)
+                return rc;
+        }
+        SSYM_HIP_CHECK(ctx, hipEventRecord(cev[7], st));
+        SSYM_HIP_CHECK(ctx, hipStreamSynchronize(st));          // the step's one synchronisation
+        if (attempt == 0)
+            coll_ms += ev_ms2(cev[2], cev[3]) + (pruned ? ev_ms2(cev[0], cev[1]) : 0.f);
+        coll_ms += ev_ms2(cev[5], cev[6]);
+        if (ctx->so_filter) {
+            hipEvent_t *ev = ctx->ev;
+            sel_ms += ev_ms2(ev[0], ev[3]);
+            ref_ms += ev_ms2(ev[3], ev[4]);
+            red_ms += ev_ms2(ev[4], ev[5]);
+            tm.n_refined = status[2 * G];
+        }
+        bool anyOverflow = false;
+        for (int g = 0; g < G; ++g)
+            anyOverflow |= status[2 * g + 1] != 0;
+        if (!anyOverflow)
+            break;
+        if (attempt == 1) {
+            ctx->err = "dtw: candidate list overflow on a rank of the sharded match";
+            return SSYM_E_NOMEM;
+        }
+        if (status[2 * comm->rank + 1])
+            ctx->so_cap = status[2 * comm->rank];               // this rank's list wanted that much
+        if (ctx->so_cap >= 0xffffffffull) {
+            ctx->err = "dtw: too many near-tied candidates for one batch";      // (every rank stops: all saw the flag)
+            return SSYM_E_UNSUPPORTED;
+        }
+    }
+    stage_finish(ctx);
+    if (filterPath) {
+        tm.main_launches = 1;
+        tm.main_ms = ev_ms2(ctx->ev[6], ctx->ev[1]);
+        if (tm.pruned) {
+            tm.n_filter_cells = ctx->pruned_cells * 64ull;
+            if (ctx->band < 0) {
+                const SegmentSet &src = dict->set, &tgt = q->set;
+                const double full = (double)src.n_pad * tgt.n_pad * src.frames_pad * std::max<uint32_t>(tgt.max_frames, 1);
+                ctx->prune_swept = (float)std::min(1.0, (double)tm.n_filter_cells / full);
+            }
+        }
+    } else if (!emptyShard && !refcos) {
+        tm.n_refined = tm.n_pairs;
+    }
+    tm.select_ms = sel_ms;
+    tm.refine_ms = ref_ms;
+    tm.reduce_ms = red_ms;
+    tm.collective_ms = coll_ms;
+    tm.total_ms = ev_ms2(cev[4], cev[7]);
+    if (pruned)
+        tm.prune_ms = ev_ms2(cev[4], cev[0]);
+    ctx->timings = tm;
+    return SSYM_OK;
+}
+
+}  // namespace
+
+extern "C" int32_t ssym_match_sharded(ssym_ctx *ctx, ssym_comm *comm, const ssym_dict *dict, const ssym_queries *q,
+                                      const double *distance, uint32_t index_base, uint32_t *out_idx,
+                                      double *out_cost, uint32_t flags)
+{
+    if (!ctx)
+        return SSYM_E_INVALID;
+    try {
+        return match_sharded_impl(ctx, comm, dict, q, distance, index_base, out_idx, out_cost, flags);
+    } catch (const std::bad_alloc &) {
+        ctx->stream_only = false;
+        ctx->err = "out of host memory";
+        return SSYM_E_NOMEM;
+    } catch (...) {
+        ctx->stream_only = false;
+        ctx->err = "unexpected C++ exception";
+        return SSYM_E_HIP;
+    }
+}

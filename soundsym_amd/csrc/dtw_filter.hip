@@ -126,10 +126,18 @@ bool filter_supported(const ssym_ctx *ctx, const SegmentSet &src, const SegmentS
         return false;   // more than 4096 source frames
     if (!std::isfinite(src.max_abs) || !std::isfinite(tgt.max_abs))
         return false;   // inf / NaN features: exact kernel keeps IEEE semantics
+    if (!std::isfinite(src.max_sqnorm_all) || !std::isfinite(tgt.max_sqnorm_all))
+        return false;   // squared frame norms beyond f32: no common scale serves values and norms
     return src.n > 0 && tgt.n > 0;
 }
 
-// common power-of-two scale: max |s v| in [32, 64) (1 when everything is zero)
+// Common power-of-two scale s: max |s v| < 64 (in [32, 64) unless the norms below ask for less; 1 when
+// everything is zero), AND every scaled squared frame norm below the f16 maximum -- the records carry
+// |a|^2 as three f16 pieces, and from 17 values per frame on 64^2 * dim passes 65504: the first piece
+// would be +inf, the third NaN, and the pair would silently drop out of the search.  A smaller s keeps
+// every assumption of the error model (|s v| < 64 is an upper bound; its absolute terms are priced
+// through 1 / s^2, dtw_margin.hpp).  max_sqnorm is rounded up and the records' norms are those of the
+// f16-rounded frames (<= (1 + 2^-11)^2 larger), hence the slack.
 static double common_scale(const SegmentSet &src, const SegmentSet &tgt)
 {
     const double m = std::max(src.max_abs, tgt.max_abs);
@@ -138,6 +146,9 @@ static double common_scale(const SegmentSet &src, const SegmentSet &tgt)
     int e = 0;
     (void)std::frexp(m, &e);          // m = f * 2^e, f in [0.5, 1)
     e = std::min(std::max(6 - e, -100), 100);
+    const double sq = std::max(src.max_sqnorm_all, tgt.max_sqnorm_all);
+    while (e > -200 && sq * std::ldexp(1.0, 2 * e) * 1.01 >= 65000.0)
+        --e;
     return std::ldexp(1.0, e);
 }
 

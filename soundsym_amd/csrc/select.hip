@@ -491,7 +491,8 @@ __global__ __launch_bounds__(128) void fold_final_topk_kernel(const uint32_t *__
 // on equal cost.  Shards are ordered by index, so this is the same first-minimum rule.
 __global__ void merge_shards_kernel(uint32_t nShards, uint32_t nTgt, const double *__restrict__ costs,
                                     const uint32_t *__restrict__ idx, const double *__restrict__ dist,
-                                    uint32_t *__restrict__ outIdx, double *__restrict__ outCost)
+                                    uint32_t *__restrict__ outIdx, double *__restrict__ outCost,
+                                    size_t costStride, size_t idxStride)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nTgt)
@@ -501,9 +502,9 @@ __global__ void merge_shards_kernel(uint32_t nShards, uint32_t nTgt, const doubl
     double bc = costs[t], bk = fabs(bc - d);
     uint32_t bi = idx[t];
     for (uint32_t g = 1; g < nShards; ++g) {
-        const double c = costs[(size_t)g * nTgt + t];
+        const double c = costs[g * costStride + t];
         const double k = fabs(c - d);
-        const uint32_t i = idx[(size_t)g * nTgt + t];
+        const uint32_t i = idx[g * idxStride + t];
         if (k < bk || (k == bk && i < bi)) {
             bc = c;
             bk = k;
@@ -941,12 +942,14 @@ int32_t launch_refcos_argmin(ssym_ctx *ctx, uint32_t n_src, uint32_t n_tgt, cons
 }
 
 int32_t launch_merge_shards(ssym_ctx *ctx, uint32_t n_shards, uint32_t n_targets, const double *costs,
-                            const uint32_t *idx, const double *dist_dev, uint32_t *out_idx, double *out_cost)
+                            const uint32_t *idx, const double *dist_dev, uint32_t *out_idx, double *out_cost,
+                            size_t cost_stride, size_t idx_stride)
 {
     if (n_targets == 0)
         return SSYM_OK;
-    merge_shards_kernel<<<(n_targets + 255) / 256, 256, 0, ctx->stream>>>(n_shards, n_targets, costs, idx,
-                                                                         dist_dev, out_idx, out_cost);
+    merge_shards_kernel<<<(n_targets + 255) / 256, 256, 0, ctx->stream>>>(
+        n_shards, n_targets, costs, idx, dist_dev, out_idx, out_cost, cost_stride ? cost_stride : n_targets,
+        idx_stride ? idx_stride : n_targets);
     SSYM_HIP_CHECK(ctx, hipGetLastError());
     return SSYM_OK;
 }

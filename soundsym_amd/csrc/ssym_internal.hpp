@@ -119,6 +119,14 @@ struct ssym_ctx {
     // once at its end, so the pack stages need not wait for their copies individually
     bool defer_sync = false;
     bool pack_light = false;        // set by ssym_match_batch around the pack of a handful of short dtw queries
+    // set by ssym_match_sharded (comm.hip) around the phases of a source-sharded match: everything is only ENQUEUED
+    // on the stream -- no host synchronisation, no read-back; phase 2 runs ONE selection attempt with `so_cap`
+    // entries of room (0 = the default) and leaves the device headers of its two candidate lists in so_hdr1 /
+    // so_hdr2 for the caller, who reads them after the step's single synchronisation
+    bool stream_only = false;
+    uint64_t so_cap = 0;
+    const uint32_t *so_hdr1 = nullptr, *so_hdr2 = nullptr;
+    bool so_filter = false;         // the last stream-only phase ran the filter path (events ev[1..6] are its)
     // ssym_match_begin .. ssym_match_finish (two-phase match of a source-sharded run)
     struct Pending {
         bool valid = false, filter = false, has_dist = false;
@@ -257,9 +265,17 @@ int32_t launch_dtw_final_allpairs(ssym_ctx *ctx, uint32_t n_src, uint32_t n_tgt,
                                   const double *costs, const double *dist_dev,
                                   uint32_t index_base, uint32_t k_top, uint32_t *out_idx_dev,
                                   double *out_cost_dev);
+// shard g's costs start at costs + g * cost_stride (doubles), its indices at idx + g * idx_stride (u32);
+// strides 0 = n_targets (the dense [n_shards][n_targets] layout of ssym_merge_shards)
 int32_t launch_merge_shards(ssym_ctx *ctx, uint32_t n_shards, uint32_t n_targets,
                             const double *costs, const uint32_t *idx, const double *dist_dev,
-                            uint32_t *out_idx, double *out_cost);
+                            uint32_t *out_idx, double *out_cost, size_t cost_stride = 0, size_t idx_stride = 0);
+
+// capi.hip: the phases of a source-sharded match, shared with comm.hip.  With ctx->stream_only they only enqueue.
+int32_t match_candidates_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queries *q, double *cost_dev);
+int32_t match_begin_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queries *q, const double *distance,
+                         uint32_t index_base, double *bounds_dev, const double *prune_cost_dev);
+int32_t match_finish_impl(ssym_ctx *ctx, const double *bounds_dev, uint32_t *out_idx, double *out_cost, uint32_t flags);
 
 // chain.hip
 int32_t launch_chain_argmin(ssym_ctx *ctx, const double *base, size_t row_stride, const uint32_t *row_sel,

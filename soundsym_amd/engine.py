@@ -66,6 +66,32 @@ class _SamplesHandle:
             pass
 
 
+class Comm:
+    """One rank of a source-sharded run: an RCCL communicator bound to an Engine (ssym_comm)."""
+
+    def __init__(self, engine: "Engine", ptr: int, rank: int, world: int):
+        self.engine, self.ptr, self.rank, self.world = engine, ptr, rank, world
+
+    def close(self):
+        if self.ptr and self.engine.ctx:
+            nat.lib().ssym_comm_destroy(self.engine.ctx, self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def comm_unique_id() -> bytes:
+    """ssym_comm_unique_id: the 128-byte RCCL id rank 0 hands to the other ranks."""
+    nat.load_rccl()
+    buf = ctypes.create_string_buffer(nat.COMM_ID_BYTES)
+    nat.check(nat.lib().ssym_comm_unique_id(buf), None)
+    return buf.raw
+
+
 class Engine:
     """One ssym_ctx: one GPU, one stream, one metric / dtype configuration."""
 
@@ -187,6 +213,42 @@ class Engine:
                                               out_cost.data_ptr() if out_cost is not None else None,
                                               nat.OUT_DEVICE), self.ctx)
         return out_idx, out_cost
+
+    # -- source-sharded runs: the collectives inside the library (RCCL on the context's stream) ----------
+    def comm_create(self, unique_id: bytes, rank: int, world: int) -> Comm:
+        """ssym_comm_create: collective over all `world` ranks (ncclCommInitRank on this engine's GPU)."""
+        nat.load_rccl()
+        if len(unique_id) != nat.COMM_ID_BYTES:
+            raise ValueError("unique_id must be the 128 bytes of comm_unique_id()")
+        out = ctypes.c_void_p()
+        buf = ctypes.create_string_buffer(bytes(unique_id), nat.COMM_ID_BYTES)
+        nat.check(nat.lib().ssym_comm_create(self.ctx, buf, rank, world, ctypes.byref(out)), self.ctx)
+        return Comm(self, out.value, rank, world)
+
+    def match_sharded(self, comm: Comm, d: _Handle, q: _Handle, distance=None, index_base: int = 0,
+                      out_idx=None, out_cost=None, prune: bool = False, force_exact: bool = False):
+        """ssym_match_sharded: this rank's shard `d` (global indices from index_base) against all targets `q`;
+        every rank returns the merged answer.  Outputs as for match()."""
+        L = nat.lib()
+        m = q.n
+        dist_p = None
+        if distance is not None:
+            dist = np.ascontiguousarray(distance, dtype=np.float64)
+            if dist.size != m:
+                raise ValueError("distance must have one entry per target")
+            dist_p = dist.ctypes.data
+        flags = (nat.DTW_FORCE_EXACT if force_exact else 0) | (nat.DTW_PRUNE if prune else 0)
+        if out_idx is not None and _is_device_tensor(out_idx):
+            rc = L.ssym_match_sharded(self.ctx, comm.ptr, d.ptr, q.ptr, dist_p, index_base, out_idx.data_ptr(),
+                                      out_cost.data_ptr() if out_cost is not None else None, flags | nat.OUT_DEVICE)
+            nat.check(rc, self.ctx)
+            return out_idx, out_cost
+        idx = np.zeros(m, dtype=np.uint32)
+        cost = np.zeros(m, dtype=np.float64)
+        rc = L.ssym_match_sharded(self.ctx, comm.ptr, d.ptr, q.ptr, dist_p, index_base, idx.ctypes.data,
+                                  cost.ctypes.data, flags)
+        nat.check(rc, self.ctx)
+        return idx, cost
 
     def match_topk(self, d: _Handle, q: _Handle, k: int, distance=None, index_base: int = 0,
                    force_exact: bool = False) -> Tuple[np.ndarray, np.ndarray]:

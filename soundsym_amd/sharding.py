@@ -1,13 +1,16 @@
 """Source-axis sharding across the GPUs of one node.
 
-Rank g of G holds dictionary segments [lo, hi) = shard_range(N, G, g) and ALL targets; it returns
-per target its best (cost, global index).  One all-gather of M x (8 + 4) bytes per rank (RCCL over
-xGMI when the tensors are on GPUs; gloo in the CPU rehearsal tests) gives every rank the G x M
-candidates; the final per-target pick -- smallest cost, lowest global index on equal cost, i.e.
-the reference's first-minimum rule (src/sound.rs:361-367) since shards are ordered by index --
-is the HIP kernel behind ssym_merge_shards.  Before that, one all-reduce(MIN) of M x 8 bytes lets the
-ranks agree on each target's upper bound (ssym_match_begin / ssym_match_finish), so that a rank
-whose shard does not hold a target's neighbour re-scores nothing for it.
+Rank g of G holds dictionary segments [lo, hi) = shard_range(N, G, g) and ALL targets.  The step itself
+-- filter, all-reduce(MIN) of the per-target bounds, selection and exact re-scoring, all-gather of the
+per-target (cost, global index), merge by the reference's first-minimum rule (src/sound.rs:361-367) --
+is ONE C-ABI call, ssym_match_sharded: the collectives are RCCL calls enqueued by the library on its own
+stream (csrc/comm.hip), the host synchronises once.  This module is its caller: `init_comm` distributes
+the RCCL unique id over whatever process group the host already has and creates the communicator,
+`match_sharded` forwards.
+
+`gather_candidates` / `reduce_bounds` / `match_sharded_torch` are the same exchange spelled with
+torch.distributed collectives around ssym_match_begin / _finish / ssym_merge_shards; they remain for
+rehearsals over gloo (CPU tests here, more ranks than GPUs on a one-GPU box), where RCCL cannot run.
 
 This module only moves bytes and computes ranges; it contains no arithmetic of the path and no
 CPU substitute for the merge kernel.
@@ -47,8 +50,8 @@ def gather_candidates(cost, idx, group=None):
     via_host = dist.get_backend(group) == "gloo" and cost.is_cuda
     packed = torch.empty(2 * m, dtype=torch.float64, device=dev)
     packed[:m] = cost.reshape(-1)
-    packed[m:] = idx.reshape(-1).view(torch.int32).to(torch.float64) if idx.dtype != torch.int32 \
-        else idx.reshape(-1).to(torch.float64)
+    # indices are u32 in the ABI; torch stores them as int32 bits, so widen through int64 and mask
+    packed[m:] = (idx.reshape(-1).view(torch.int32).to(torch.int64) & 0xFFFFFFFF).to(torch.float64)
     if via_host:
         packed = packed.cpu()
     allp = torch.empty(world * 2 * m, dtype=torch.float64, device=packed.device)
@@ -56,7 +59,9 @@ def gather_candidates(cost, idx, group=None):
     if via_host:
         allp = allp.to(dev)
     allp = allp.view(world, 2, m)
-    return allp[:, 0, :].contiguous(), allp[:, 1, :].to(idx.dtype).contiguous()
+    gidx = allp[:, 1, :].to(torch.int64)
+    gidx = torch.where(gidx >= 2 ** 31, gidx - 2 ** 32, gidx).to(torch.int32)      # back to the u32 bit pattern
+    return allp[:, 0, :].contiguous(), gidx.view(idx.dtype).contiguous() if idx.dtype != torch.int32 else gidx.contiguous()
 
 
 def reduce_bounds(bounds, group=None):
@@ -75,10 +80,41 @@ def reduce_bounds(bounds, group=None):
     return bounds
 
 
-def match_sharded(engine, d, q, index_base, out_idx, out_cost, bounds, group=None, distance=None, prune=False):
-    """One rank's part of a source-sharded match: filter, agree on the per-target bound with the
-    other ranks, select / re-score against it, gather every rank's winners and merge them.
-    All tensors are CUDA tensors on this rank's GPU; returns (idx [M], cost [M]).
+def init_comm(engine, rank: int, world: int, group=None):
+    """Create this rank's RCCL communicator behind the C ABI (ssym_comm_create).  Rank 0 draws the unique
+    id (ssym_comm_unique_id); it reaches the other ranks through the torch.distributed group the host
+    already has (any backend -- 128 bytes as a tensor broadcast), or, with world == 1, not at all."""
+    from .engine import comm_unique_id
+
+    if world == 1:
+        return engine.comm_create(comm_unique_id(), 0, 1)
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        raise RuntimeError("init_comm with world > 1 needs an initialised torch.distributed group to hand the id over")
+    on_gpu = dist.get_backend(group) == "nccl"
+    dev = torch.device("cuda", engine.device) if on_gpu else torch.device("cpu")
+    if rank == 0:
+        t = torch.frombuffer(bytearray(comm_unique_id()), dtype=torch.uint8).to(dev)
+    else:
+        t = torch.zeros(128, dtype=torch.uint8, device=dev)
+    dist.broadcast(t, src=0, group=group)
+    return engine.comm_create(bytes(t.cpu().numpy().tobytes()), rank, world)
+
+
+def match_sharded(engine, comm, d, q, index_base, out_idx=None, out_cost=None, distance=None, prune=False):
+    """One rank's part of a source-sharded match, collectives included: ssym_match_sharded.  Every rank
+    returns the merged (idx [M], cost [M]); with torch CUDA tensors in out_idx / out_cost they stay on
+    the device."""
+    return engine.match_sharded(comm, d, q, distance=distance, index_base=index_base, out_idx=out_idx,
+                                out_cost=out_cost, prune=prune)
+
+
+def match_sharded_torch(engine, d, q, index_base, out_idx, out_cost, bounds, group=None, distance=None, prune=False):
+    """The same step with torch.distributed collectives around the two-phase C-ABI calls (gloo rehearsals):
+    filter, agree on the per-target bound with the other ranks, select / re-score against it, gather every
+    rank's winners and merge them.  All tensors are CUDA tensors on this rank's GPU; returns (idx [M], cost [M]).
     prune=True (plain nearest-neighbour search only): every rank scores one candidate pair per target
     first, the costs are reduced with MIN, and the filters abandon against them -- one more exchange of
     M f64 values, same results."""

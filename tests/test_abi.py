@@ -20,13 +20,13 @@ def test_header_and_binding_list_agree():
 def test_library_exports_every_declared_symbol(native_lib):
     for name in _declared():
         assert hasattr(native_lib, name), name
-    assert native_lib.ssym_abi_version() == 1
+    assert native_lib.ssym_abi_version() == 2
 
 
 def test_struct_layouts_match_header():
-    # ssym_config: u32 + 5 x i32 + pointer + 2 x i32; ssym_timings: 6 floats, 2 x u64, 2 x i32, float, i32, u64
+    # ssym_config: u32 + 5 x i32 + pointer + 2 x i32; ssym_timings: 6 floats, 2 x u64, 2 x i32, float, i32, u64, float, i32
     assert ctypes.sizeof(nat.Config) == 40
-    assert ctypes.sizeof(nat.Timings) == 64
+    assert ctypes.sizeof(nat.Timings) == 72
 
 
 def test_no_cpu_fallback_without_a_device(native_lib):

@@ -1,0 +1,117 @@
+"""ssym_comm_* / ssym_match_sharded: the source-sharded match with its RCCL collectives inside the library.
+
+One GPU is all a test box has, and RCCL refuses two ranks on one device, so what runs here is a
+WORLD-1 communicator: the all-reduce and the all-gather are real RCCL calls on the context's stream,
+the merge sees one shard, and the result must be bit for bit ssym_match_queries' -- for every path
+the step has (filter, per-target distances, early abandoning, bands, shapes outside the filter,
+refcos, an empty shard, an overflowing candidate list that makes every rank repeat the tail).
+Range / gather / merge logic with two ranks: tests/test_host.py (gloo), tests/test_gpu_sharded.py.
+"""
+import numpy as np
+import pytest
+
+from soundsym_amd import Engine, sharding, synth
+from soundsym_amd.engine import pack_segments
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _grid_sets(e, g, f, dim):
+    so = np.arange(g.sources.shape[0] + 1, dtype=np.uint64) * f
+    to = np.arange(g.targets.shape[0] + 1, dtype=np.uint64) * f
+    return e.dictionary(g.sources.reshape(-1), so, dim), e.queries(g.targets.reshape(-1), to, dim)
+
+
+@pytest.mark.parametrize("band,prune,with_dist", [(-1, False, False), (-1, True, False), (-1, False, True),
+                                                   (6, False, False), (6, True, False)])
+def test_world1_sharded_equals_match_queries(band, prune, with_dist):
+    n, m, f, dim = 384, 160, 40, 13
+    g = synth.make_grid(n, m, f, dim, 0x5EED0A00 + (band & 0xff))
+    e = Engine(metric="dtw", dtype="f32", band=band)
+    d, q = _grid_sets(e, g, f, dim)
+    dist = np.linspace(0.0, 30.0, m) if with_dist else None
+    want_idx, want_cost = e.match(d, q, distance=dist, index_base=1000)
+    comm = sharding.init_comm(e, 0, 1)
+    idx, cost = sharding.match_sharded(e, comm, d, q, 1000, distance=dist, prune=prune)
+    tm = e.timings()
+    assert np.array_equal(idx, want_idx) and np.array_equal(cost, want_cost)
+    assert tm["used_filter"] == 1 and tm["attempts"] == 1 and tm["collective_ms"] > 0
+    assert tm["pruned"] == (1 if prune else 0)
+    if not with_dist:
+        assert np.array_equal(idx.astype(np.int64) - 1000, g.planted)
+    # device outputs, twice (buffers and communicator are reused)
+    oi = torch.empty(m, dtype=torch.int32, device="cuda")
+    oc = torch.empty(m, dtype=torch.float64, device="cuda")
+    for _ in range(2):
+        sharding.match_sharded(e, comm, d, q, 1000, out_idx=oi, out_cost=oc, distance=dist, prune=prune)
+        e.synchronize()
+        assert np.array_equal(oi.cpu().numpy().view(np.uint32), want_idx) and np.array_equal(oc.cpu().numpy(), want_cost)
+    comm.close()
+    e.close()
+
+
+def test_world1_sharded_outside_the_filter_and_refcos(oracle):
+    # frames of 100 values with per-target distances: the exact kernel on every pair (no filter, no bounds)
+    rsrc, rtgt = synth.make_ragged(40, 24, 3, 20, 100, 0x5EED0A10)
+    sf, so = pack_segments(rsrc, 100, np.float32)
+    tf, to = pack_segments(rtgt, 100, np.float32)
+    e = Engine(metric="dtw", dtype="f32")
+    d, q = e.dictionary(sf, so, 100), e.queries(tf, to, 100)
+    dist = np.linspace(1.0, 50.0, 24)
+    want = e.match(d, q, distance=dist, index_base=5)
+    comm = sharding.init_comm(e, 0, 1)
+    got = sharding.match_sharded(e, comm, d, q, 5, distance=dist)
+    assert e.timings()["used_filter"] == 0
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    comm.close()
+    e.close()
+    # refcos: the keys travel, the merge compares them as they are
+    r = Engine(metric="refcos", dtype="f64")
+    rs, rt = synth.make_ragged(90, 33, 2, 25, 12, 0x5EED0A11)
+    sf, so = pack_segments([s.astype(np.float64) * 0.05 for s in rs], 12)
+    tf, to = pack_segments([t.astype(np.float64) * 0.05 for t in rt], 12)
+    d, q = r.dictionary(sf, so, 12), r.queries(tf, to, 12)
+    want = r.match(d, q)
+    comm = sharding.init_comm(r, 0, 1)
+    got = sharding.match_sharded(r, comm, d, q, 0)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    want_idx, want_val = oracle.refcos_match_all(sf, so, tf, to, 12)
+    assert np.array_equal(got[0], want_idx) and np.array_equal(got[1], want_val)
+    comm.close()
+    r.close()
+
+
+def test_world1_empty_shard_reports_the_fold_start():
+    e = Engine(metric="dtw", dtype="f32")
+    g = synth.make_grid(8, 5, 10, 13, 0x5EED0A20)
+    d = e.dictionary(np.zeros(0, dtype=np.float32), np.zeros(1, dtype=np.uint64), 13)
+    q = e.queries(g.targets.reshape(-1), np.arange(6, dtype=np.uint64) * 10, 13)
+    comm = sharding.init_comm(e, 0, 1)
+    idx, cost = sharding.match_sharded(e, comm, d, q, 77)
+    assert (idx == 77).all() and np.isinf(cost).all()
+    idx, cost = sharding.match_sharded(e, comm, d, q, 77, prune=True)
+    assert (idx == 77).all() and np.isinf(cost).all()
+    comm.close()
+    e.close()
+
+
+def test_world1_overflowing_candidate_list_repeats_the_tail(oracle):
+    # every source identical: list 1 wants all 600 x 200 pairs; the gathered status tells every rank,
+    # and the tail (selection ... merge) is repeated once with the room asked for
+    n, m, f = 600, 200, 8
+    one = synth.make_grid(1, 1, f, 13, 0x5EED0395).sources[0]
+    src = np.repeat(one[None], n, axis=0)
+    tgt = synth.make_grid(m, 1, f, 13, 0x5EED0396).sources
+    so = np.arange(n + 1, dtype=np.uint64) * f
+    to = np.arange(m + 1, dtype=np.uint64) * f
+    e = Engine(metric="dtw", dtype="f32")
+    d, q = e.dictionary(src.reshape(-1), so, 13), e.queries(tgt.reshape(-1), to, 13)
+    want = e.match(d, q)
+    comm = sharding.init_comm(e, 0, 1)
+    got = sharding.match_sharded(e, comm, d, q, 0)
+    tm = e.timings()
+    assert tm["attempts"] == 2 and tm["n_refined"] == n * m
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and (got[0] == 0).all()
+    comm.close()
+    e.close()

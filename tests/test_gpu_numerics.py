@@ -1,0 +1,118 @@
+"""GPU numerics corner cases of the dtw filter's f16 records (csrc/dtw_filter.hip, csrc/select.hip).
+
+* Flat spectra: frames of 17...42 values whose scaled squared norm would pass the f16 maximum with
+  max |s v| in [32, 64) -- the norm pieces must stay finite (the common scale steps down), the pair
+  must stay in the search and the filter matrix inside its bound.
+* Subnormal second pieces: values 2^8 and more below the set's largest have a subnormal second f16
+  piece; the error model prices it at 2^-25 (scaled units) per value, which holds only if the matrix
+  pipe does not flush subnormal inputs.  Single-frame segments make the filter's output one local
+  cost, so the per-cell claim of select.hip is checked directly.
+"""
+import math
+
+import numpy as np
+import pytest
+
+from soundsym_amd import Engine
+from soundsym_amd.engine import pack_segments
+
+pytestmark = pytest.mark.gpu
+EXACT_RTOL = 1e-12
+
+
+def _common_scale(vmax, sqmax):
+    """csrc/dtw_filter.hip common_scale: max |s v| < 64 and s^2 * max |frame|^2 * 1.01 < 65000."""
+    if not vmax > 0:
+        return 1.0
+    e = 6 - math.frexp(vmax)[1]
+    while sqmax * 2.0 ** (2 * e) * 1.01 >= 65000.0:
+        e -= 1
+    return 2.0 ** e
+
+
+def _worst_case_bound(src, tgt, dim_used, fa, fb):
+    """|C~ - C| of the filter with the worst-case cell error (csrc/dtw_margin.hpp, xmin = 0)."""
+    u = 2.0 ** -24
+    in_round = 2.0 ** -22 if dim_used <= 13 else 2.0 ** -11
+    sq = lambda a: float((a.astype(np.float64)[..., :dim_used] ** 2).sum(-1).max())
+    na, nb = sq(src), sq(tgt)
+    full = lambda a: float((np.float32(1.000001) * (a.astype(np.float64) ** 2).sum(-1).astype(np.float32)).max())
+    vmax = max(float(np.abs(src).max()), float(np.abs(tgt).max())) * 1.000001
+    s = _common_scale(vmax, max(full(src), full(tgt)))
+    E = 256 * u * (na + nb) + 2.0 ** -12 / s ** 2
+    cell = math.sqrt(E) + 1.001 * in_round * (math.sqrt(na) + math.sqrt(nb)) + 2.0 ** -20 / s
+    return 1.02 * (fa + fb - 1) * cell, s
+
+
+@pytest.mark.parametrize("dim", [18, 40, 42, 64])
+@pytest.mark.parametrize("kind", ["constant", "uniform"])
+def test_dtw_flat_spectrum_norm_pieces_stay_finite(oracle, dim, kind):
+    rng = np.random.default_rng(0xF1A7 + dim)
+    n, m, f = 24, 16, 20
+    if kind == "constant":       # every value near the set's maximum: |frame|^2 = dim * max^2
+        src = (1.9 + 0.01 * rng.standard_normal((n, f, dim))).astype(np.float32)   # scaled by 32: ~61
+        src *= np.where(rng.random((n, f, dim)) < 0.5, -1.0, 1.0).astype(np.float32)
+    else:
+        src = rng.uniform(-1.0, 1.0, (n, f, dim)).astype(np.float32)
+    pick = rng.permutation(n)[:m]
+    tgt = (src[pick] + 0.01 * rng.standard_normal((m, f, dim))).astype(np.float32)
+    so = np.arange(n + 1, dtype=np.uint64) * f
+    to = np.arange(m + 1, dtype=np.uint64) * f
+    e = Engine(metric="dtw", dtype="f32")
+    d, q = e.dictionary(src.reshape(-1), so, dim), e.queries(tgt.reshape(-1), to, dim)
+    idx, cost = e.match(d, q)
+    assert e.timings()["used_filter"] == 1
+    want_idx, want_cost, mat = oracle.dtw_match_all(src.reshape(-1).astype(np.float64), so,
+                                                    tgt.reshape(-1).astype(np.float64), to, dim, want_matrix=True)
+    assert np.array_equal(idx, want_idx) and np.array_equal(idx, pick)
+    assert np.allclose(cost, want_cost, rtol=EXACT_RTOL, atol=0)
+    filt = e.pair_matrix(d, q, exact=False)
+    assert np.isfinite(filt).all(), "a norm piece overflowed f16: the pair dropped out of the filter"
+    used = min(dim, 42)
+    bound, s = _worst_case_bound(src, tgt, used, f, f)
+    if dim <= 42:
+        assert (np.abs(filt - mat) <= bound + 1e-5 * mat).all(), (np.abs(filt - mat).max(), bound)
+    else:                         # the first 42 values only: a lower bound of the cost
+        assert (filt <= mat + bound + 1e-5 * mat).all()
+    if kind == "constant":
+        assert s * float(np.abs(src).max()) < 32.0, "the scale should have stepped down for the norms"
+    e.close()
+
+
+def test_dtw_filter_subnormal_second_pieces_stay_inside_the_cell_bound():
+    # single-frame segments: the filter's cost IS one local cost c~(a, b)
+    dim = 13
+    # sources: every value 2^-4 + ~2^-15, so H1 = 2^-4 and H2 ~ 2^-15 (subnormal f16); a few variations
+    k = np.arange(64, dtype=np.float64)
+    a = 2.0 ** -4 + (0.45 + 0.049 * ((k[:, None] * 7 + np.arange(dim)[None, :] * 3) % 10) / 10.0) * 2.0 ** -14
+    a[1::2] *= -1.0
+    # one extra source whose single large value fixes the common scale at 1 (max |v| = 40)
+    big = np.zeros((1, dim))
+    big[0, 0] = 40.0
+    src = np.concatenate([a, big]).astype(np.float32)
+    # targets: mid-sized values (|b| well below 29, where the norm term of E does not cover a flush)
+    tv = np.array([0.5, 1.0, 2.0, 3.0, 4.0, 6.0, 8.0, 2.0 ** -4])
+    tgt = np.repeat(tv[:, None], dim, axis=1).astype(np.float32)
+    tgt[::2, ::2] *= -1.0
+    so = np.arange(src.shape[0] + 1, dtype=np.uint64)
+    to = np.arange(tgt.shape[0] + 1, dtype=np.uint64)
+    e = Engine(metric="dtw", dtype="f32")
+    d, q = e.dictionary(src.reshape(-1), so, dim), e.queries(tgt.reshape(-1), to, dim)
+    filt = e.pair_matrix(d, q, exact=False)
+    exact = e.pair_matrix(d, q, exact=True)
+    e.close()
+    a64, b64 = src.astype(np.float64), tgt.astype(np.float64)
+    want = np.sqrt(((a64[:, None, :] - b64[None, :, :]) ** 2).sum(-1))
+    assert np.allclose(exact, want, rtol=1e-14, atol=0)
+    u = 2.0 ** -24
+    na = (a64 ** 2).sum(-1)[:, None] * 1.000002      # the kernel's norms are f32, rounded up
+    nb = (b64 ** 2).sum(-1)[None, :] * 1.000002
+    E = 256 * u * (na + nb) + 2.0 ** -12             # common scale 1: max |v| = 40 in [32, 64)
+    x = want ** 2
+    certified = x > 8 * E                            # (x >= m - E with m > 6E certain)
+    cell = np.where(certified, E / (2 * np.sqrt(np.maximum(x - 3 * E, 1e-300))), np.sqrt(E))
+    cell = cell + 1.001 * 2.0 ** -22 * (np.sqrt(na) + np.sqrt(nb)) + 2.0 ** -20
+    bound = 1.02 * cell + 7 * u * filt
+    worst = np.abs(filt - want) / bound
+    assert (worst <= 1.0).all(), ("filter cell outside the bound of select.hip -- subnormal f16 pieces flushed?",
+                                  float(worst.max()), np.unravel_index(worst.argmax(), worst.shape))
