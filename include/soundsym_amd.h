@@ -114,6 +114,10 @@ typedef struct ssym_timings {
     float collective_ms;   /* ssym_match_sharded: the RCCL all-reduce(s) + all-gather, device time  */
     int32_t attempts;      /* ssym_match_sharded: selection attempts of the step (1 unless a rank's
                               candidate list overflowed and every rank redid the tail)             */
+    int32_t exact_redone;  /* dtw: launches of the exact kernel whose wave-pipelined variant gave up
+                              waiting and whose list was scored again by the plain variant (0 in any
+                              healthy run; results are correct either way)                          */
+    int32_t reserved;
 } ssym_timings;
 
 SSYM_API int32_t ssym_abi_version(void);

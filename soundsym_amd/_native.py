@@ -94,6 +94,8 @@ class Timings(ctypes.Structure):
         ("n_filter_cells", ctypes.c_uint64),
         ("collective_ms", ctypes.c_float),
         ("attempts", ctypes.c_int32),
+        ("exact_redone", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
     ]
 
     def as_dict(self):

@@ -21,6 +21,7 @@ const char *ssym_last_error(const ssym_ctx *ctx)
 
 int32_t ssym_ctx_create(const ssym_config *cfg, ssym_ctx **out)
 {
+    return guarded((ssym_ctx *)nullptr, [&]() -> int32_t {
     if (!cfg || !out || cfg->struct_size != sizeof(ssym_config)) {
         g_create_err = "ssym_ctx_create: bad config (NULL or struct_size mismatch)";
         return SSYM_E_INVALID;
@@ -88,17 +89,20 @@ int32_t ssym_ctx_create(const ssym_config *cfg, ssym_ctx **out)
     }
     *out = ctx;
     return SSYM_OK;
+    });
 }
 
 int32_t ssym_ctx_destroy(ssym_ctx *ctx)
 {
+    return guarded(ctx, [&]() -> int32_t {
     if (!ctx)
         return SSYM_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     DeviceBuf *bufs[] = {&ctx->handoff, &ctx->cmat, &ctx->tmin, &ctx->cand, &ctx->cand2, &ctx->cand_xmin,
                          &ctx->cand_cost, &ctx->best, &ctx->selmask, &ctx->selcnt, &ctx->topk,
-                         &ctx->abandon, &ctx->prune_pairs, &ctx->prune_cost, &ctx->one_ticket, &ctx->dist, &ctx->part, &ctx->out_idx, &ctx->out_cost};
+                         &ctx->abandon, &ctx->prune_pairs, &ctx->prune_cost, &ctx->one_ticket, &ctx->dist, &ctx->part, &ctx->out_idx, &ctx->out_cost,
+                         &ctx->pipe_flag, &ctx->tmin2};
     for (DeviceBuf *b : bufs)
         if (b->ptr)
             (void)hipFree(b->ptr);
@@ -112,14 +116,17 @@ int32_t ssym_ctx_destroy(ssym_ctx *ctx)
         (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return SSYM_OK;
+    });
 }
 
 int32_t ssym_ctx_synchronize(ssym_ctx *ctx)
 {
+    return guarded(ctx, [&]() -> int32_t {
     if (!ctx)
         return SSYM_E_INVALID;
     SSYM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return SSYM_OK;
+    });
 }
 
 int32_t ssym_get_timings(const ssym_ctx *ctx, ssym_timings *out)
@@ -144,6 +151,7 @@ static int32_t make_set(ssym_ctx *ctx, SegmentSet &set, const void *feats, bool 
 int32_t ssym_dict_create(ssym_ctx *ctx, const void *feats, const uint64_t *frame_offsets,
                          uint32_t n_segments, uint32_t dim, ssym_dict **out)
 {
+    return guarded(ctx, [&]() -> int32_t {
     if (!ctx || !out)
         return SSYM_E_INVALID;
     *out = nullptr;
@@ -157,11 +165,13 @@ int32_t ssym_dict_create(ssym_ctx *ctx, const void *feats, const uint64_t *frame
     }
     *out = d;
     return SSYM_OK;
+    });
 }
 
 int32_t ssym_dict_create_device(ssym_ctx *ctx, const void *feats_dev, const uint64_t *frame_offsets,
                                 uint32_t n_segments, uint32_t dim, ssym_dict **out)
 {
+    return guarded(ctx, [&]() -> int32_t {
     if (!ctx || !out)
         return SSYM_E_INVALID;
     *out = nullptr;
@@ -175,15 +185,18 @@ int32_t ssym_dict_create_device(ssym_ctx *ctx, const void *feats_dev, const uint
     }
     *out = d;
     return SSYM_OK;
+    });
 }
 
 int32_t ssym_dict_append(ssym_ctx *ctx, ssym_dict *dict, const void *feats,
                          const uint64_t *frame_offsets, uint32_t n_segments)
 {
+    return guarded(ctx, [&]() -> int32_t {
     if (!ctx || !dict)
         return SSYM_E_INVALID;
     SSYM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     return append_segments(ctx, dict->set, feats, frame_offsets, n_segments);
+    });
 }
 
 int32_t ssym_dict_size(const ssym_dict *dict, uint32_t *out_n_segments)
@@ -196,6 +209,7 @@ int32_t ssym_dict_size(const ssym_dict *dict, uint32_t *out_n_segments)
 
 int32_t ssym_dict_destroy(ssym_ctx *ctx, ssym_dict *dict)
 {
+    return guarded(ctx, [&]() -> int32_t {
     if (!dict)
         return SSYM_OK;
     if (ctx) {
@@ -207,11 +221,13 @@ int32_t ssym_dict_destroy(ssym_ctx *ctx, ssym_dict *dict)
         (void)hipFree(dict->selfsim.ptr);
     delete dict;
     return SSYM_OK;
+    });
 }
 
 int32_t ssym_queries_create(ssym_ctx *ctx, const void *feats, const uint64_t *frame_offsets,
                             uint32_t n_targets, uint32_t dim, ssym_queries **out)
 {
+    return guarded(ctx, [&]() -> int32_t {
     if (!ctx || !out)
         return SSYM_E_INVALID;
     *out = nullptr;
@@ -225,11 +241,13 @@ int32_t ssym_queries_create(ssym_ctx *ctx, const void *feats, const uint64_t *fr
     }
     *out = q;
     return SSYM_OK;
+    });
 }
 
 int32_t ssym_queries_create_device(ssym_ctx *ctx, const void *feats_dev, const uint64_t *frame_offsets,
                                    uint32_t n_targets, uint32_t dim, ssym_queries **out)
 {
+    return guarded(ctx, [&]() -> int32_t {
     if (!ctx || !out)
         return SSYM_E_INVALID;
     *out = nullptr;
@@ -243,10 +261,12 @@ int32_t ssym_queries_create_device(ssym_ctx *ctx, const void *feats_dev, const u
     }
     *out = q;
     return SSYM_OK;
+    });
 }
 
 int32_t ssym_queries_destroy(ssym_ctx *ctx, ssym_queries *q)
 {
+    return guarded(ctx, [&]() -> int32_t {
     if (!q)
         return SSYM_OK;
     if (ctx)
@@ -254,6 +274,7 @@ int32_t ssym_queries_destroy(ssym_ctx *ctx, ssym_queries *q)
     free_segments(ctx, q->set);      // blocks go back to the context's cache; reuse is stream-ordered
     delete q;
     return SSYM_OK;
+    });
 }
 
 // ---- the hot path -----------------------------------------------------------------------------------
@@ -345,6 +366,8 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
     SSYM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const bool outDev = (flags & SSYM_OUT_DEVICE) != 0;
+    if (phase != 2)
+        ctx->pipe_mask = 0;            // give-up counters of the exact kernel's pipelined variant: this call's start here
     if (phase == 0) {
         // any other call that uses the context's scratch ends a begin .. finish in progress (finish then reports
         // "without begin") and drops the candidates of ssym_match_candidates: their buffers are shared
@@ -532,9 +555,16 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
                     return SSYM_OK;
                 }
                 uint32_t h1[2] = {0, 0}, h2[2] = {0, 0};
+                unsigned gave[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                 SSYM_HIP_CHECK(ctx, hipMemcpyAsync(h1, hdr1, sizeof(h1), hipMemcpyDeviceToHost, st));
                 SSYM_HIP_CHECK(ctx, hipMemcpyAsync(h2, hdr2, sizeof(h2), hipMemcpyDeviceToHost, st));
+                if (ctx->pipe_mask)
+                    SSYM_HIP_CHECK(ctx, hipMemcpyAsync(gave, ctx->pipe_flag.ptr, sizeof(gave), hipMemcpyDeviceToHost, st));
                 SSYM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+                for (int i = 0; i < 8; ++i)
+                    if ((ctx->pipe_mask >> i & 1u) && gave[i])
+                        ++tm.exact_redone;
+                ctx->pipe_mask = 0;
                 if (attempt == 0 && phase != 2)
                     sel_ms += ev_ms(ev[1], ev[2]);      // the per-target threshold (bounds) belongs to selection
                 sel_ms += ev_ms(ev[2], ev[3]);
@@ -585,7 +615,13 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
                 ctx->timings = tm;
                 return SSYM_OK;
             }
+            unsigned gave[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (ctx->pipe_mask)
+                SSYM_HIP_CHECK(ctx, hipMemcpyAsync(gave, ctx->pipe_flag.ptr, sizeof(gave), hipMemcpyDeviceToHost, st));
             SSYM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+            for (int i = 0; i < 8; ++i)
+                if ((ctx->pipe_mask >> i & 1u) && gave[i])
+                    ++tm.exact_redone;
             tm.refine_ms = ev_ms(ev[0], ev[1]);
             tm.reduce_ms = ev_ms(ev[1], ev[2]);
             tm.total_ms = ev_ms(ev[0], ev[2]);
@@ -623,12 +659,15 @@ int32_t ssym_match_queries(ssym_ctx *ctx, const ssym_dict *dict, const ssym_quer
                            const double *distance, uint32_t index_base, uint32_t *out_idx,
                            double *out_cost, uint32_t flags)
 {
+    return guarded(ctx, [&]() -> int32_t {
     return match_impl(ctx, dict, q, distance, index_base, 1, out_idx, out_cost, flags);
+    });
 }
 
 int32_t ssym_match_topk(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queries *q, const double *distance,
                         uint32_t k, uint32_t index_base, uint32_t *out_idx, double *out_cost, uint32_t flags)
 {
+    return guarded(ctx, [&]() -> int32_t {
     if (!ctx)
         return SSYM_E_INVALID;
     if (k == 0 || k > SSYM_TOPK_MAX) {
@@ -636,6 +675,7 @@ int32_t ssym_match_topk(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queries
         return SSYM_E_INVALID;
     }
     return match_impl(ctx, dict, q, distance, index_base, k, out_idx, out_cost, flags);
+    });
 }
 
 // Two-phase match for source-sharded runs (see the header).  A tiny kernel-free helper fills the
@@ -757,37 +797,46 @@ extern "C" {
 
 int32_t ssym_match_candidates(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queries *q, double *cost_dev)
 {
+    return guarded(ctx, [&]() -> int32_t {
     return match_candidates_impl(ctx, dict, q, cost_dev);
+    });
 }
 
 int32_t ssym_match_begin(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queries *q, const double *distance,
                          uint32_t index_base, double *bounds_dev)
 {
+    return guarded(ctx, [&]() -> int32_t {
     return match_begin_impl(ctx, dict, q, distance, index_base, bounds_dev, nullptr);
+    });
 }
 
 int32_t ssym_match_begin_pruned(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queries *q, uint32_t index_base,
                                 const double *cost_dev, double *bounds_dev)
 {
+    return guarded(ctx, [&]() -> int32_t {
     if (ctx && !cost_dev) {
         ctx->err = "ssym_match_begin_pruned: cost_dev is NULL";
         return SSYM_E_INVALID;
     }
     return match_begin_impl(ctx, dict, q, nullptr, index_base, bounds_dev, cost_dev);
+    });
 }
 
 int32_t ssym_match_finish(ssym_ctx *ctx, const double *bounds_dev, uint32_t *out_idx, double *out_cost,
                           uint32_t flags)
 {
+    return guarded(ctx, [&]() -> int32_t {
     if (!ctx)
         return SSYM_E_INVALID;
     return match_finish_impl(ctx, bounds_dev, out_idx, out_cost, flags);
+    });
 }
 
 int32_t ssym_match_batch(ssym_ctx *ctx, const ssym_dict *dict, const void *tgt_feats,
                          const uint64_t *tgt_frame_offsets, uint32_t n_targets, const double *distance,
                          uint32_t *out_idx, double *out_cost)
 {
+    return guarded(ctx, [&]() -> int32_t {
     if (!ctx)
         return SSYM_E_INVALID;
     if (!dict) {
@@ -872,19 +921,23 @@ int32_t ssym_match_batch(ssym_ctx *ctx, const ssym_dict *dict, const void *tgt_f
         (void)hipStreamSynchronize(ctx->stream);
     ssym_queries_destroy(ctx, q);
     return rc;
+    });
 }
 
 int32_t ssym_match_one(ssym_ctx *ctx, const ssym_dict *dict, const void *feats, uint64_t n_frames,
                        double distance, uint32_t *out_idx, double *out_cost)
 {
+    return guarded(ctx, [&]() -> int32_t {
     const uint64_t off[2] = {0, n_frames};
     return ssym_match_batch(ctx, dict, feats, off, 1, &distance, out_idx, out_cost);
+    });
 }
 
 /* from_distances (src/sound.rs:405-417) on the device; see chain.hip. */
 int32_t ssym_chain(ssym_ctx *ctx, ssym_dict *dict, const void *start_feats, uint64_t start_frames,
                    const double *distances, uint32_t n_steps, uint32_t *out_idx, double *out_cost)
 {
+    return guarded(ctx, [&]() -> int32_t {
     if (!ctx)
         return SSYM_E_INVALID;
     if (!dict) {
@@ -981,11 +1034,13 @@ int32_t ssym_chain(ssym_ctx *ctx, ssym_dict *dict, const void *start_feats, uint
         return SSYM_E_HIP;
     }
     return rc;
+    });
 }
 
 int32_t ssym_pair_matrix(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queries *q, int32_t exact,
                          double *out_matrix)
 {
+    return guarded(ctx, [&]() -> int32_t {
     int32_t rc = check_match_args(ctx, dict, q);
     if (rc != SSYM_OK)
         return rc;
@@ -1032,12 +1087,14 @@ int32_t ssym_pair_matrix(ssym_ctx *ctx, const ssym_dict *dict, const ssym_querie
                                        hipMemcpyDeviceToHost, st));
     SSYM_HIP_CHECK(ctx, hipStreamSynchronize(st));
     return SSYM_OK;
+    });
 }
 
 int32_t ssym_merge_shards_at(ssym_ctx *ctx, uint32_t n_shards, uint32_t n_targets, const double *costs_dev,
                              const uint32_t *idx_dev, const double *distance, uint32_t *out_idx_dev,
                              double *out_cost_dev)
 {
+    return guarded(ctx, [&]() -> int32_t {
     if (!ctx)
         return SSYM_E_INVALID;
     if (n_shards == 0 || !costs_dev || !idx_dev || !out_idx_dev) {
@@ -1060,12 +1117,15 @@ int32_t ssym_merge_shards_at(ssym_ctx *ctx, uint32_t n_shards, uint32_t n_target
         return rc;
     SSYM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return SSYM_OK;
+    });
 }
 
 int32_t ssym_merge_shards(ssym_ctx *ctx, uint32_t n_shards, uint32_t n_targets, const double *costs_dev,
                           const uint32_t *idx_dev, uint32_t *out_idx_dev, double *out_cost_dev)
 {
+    return guarded(ctx, [&]() -> int32_t {
     return ssym_merge_shards_at(ctx, n_shards, n_targets, costs_dev, idx_dev, nullptr, out_idx_dev, out_cost_dev);
+    });
 }
 
 }  // extern "C"

@@ -82,8 +82,6 @@ const Rccl &rccl()
     return r;
 }
 
-thread_local std::string g_comm_err;
-
 }  // namespace
 
 struct ssym_comm {
@@ -148,6 +146,7 @@ int32_t ssym_comm_unique_id(void *out_id)
 
 int32_t ssym_comm_create(ssym_ctx *ctx, const void *id, int32_t rank, int32_t world, ssym_comm **out)
 {
+    return guarded(ctx, [&]() -> int32_t {
     if (!ctx)
         return SSYM_E_INVALID;
     if (!id || !out || world < 1 || rank < 0 || rank >= world) {
@@ -184,10 +183,12 @@ int32_t ssym_comm_create(ssym_ctx *ctx, const void *id, int32_t rank, int32_t wo
     }
     *out = c;
     return SSYM_OK;
+    });
 }
 
 int32_t ssym_comm_destroy(ssym_ctx *ctx, ssym_comm *c)
 {
+    return guarded(ctx, [&]() -> int32_t {
     if (!c)
         return SSYM_OK;
     if (ctx) {
@@ -206,6 +207,7 @@ int32_t ssym_comm_destroy(ssym_ctx *ctx, ssym_comm *c)
             (void)hipEventDestroy(ev);
     delete c;
     return SSYM_OK;
+    });
 }
 
 }  // extern "C"
@@ -426,15 +428,7 @@ extern "C" int32_t ssym_match_sharded(ssym_ctx *ctx, ssym_comm *comm, const ssym
 {
     if (!ctx)
         return SSYM_E_INVALID;
-    try {
+    return guarded(ctx, [&]() -> int32_t {
         return match_sharded_impl(ctx, comm, dict, q, distance, index_base, out_idx, out_cost, flags);
-    } catch (const std::bad_alloc &) {
-        ctx->stream_only = false;
-        ctx->err = "out of host memory";
-        return SSYM_E_NOMEM;
-    } catch (...) {
-        ctx->stream_only = false;
-        ctx->err = "unexpected C++ exception";
-        return SSYM_E_HIP;
-    }
+    });
 }

@@ -205,7 +205,8 @@ __global__ __launch_bounds__(64) void dtw_exact_reg_kernel(
     const double *__restrict__ tgtRaw, const uint64_t *__restrict__ tgtOff, uint32_t nSrc,
     uint32_t nTgt, uint32_t dim, int band, int squared, const uint2 *__restrict__ pairs,
     const uint32_t *__restrict__ countDev, uint32_t maxPairs, uint32_t fbCap,
-    double *__restrict__ out, uint64_t totalLo = 0, uint64_t totalHi = ~0ull)
+    double *__restrict__ out, uint64_t totalLo = 0, uint64_t totalHi = ~0ull,
+    const unsigned *__restrict__ redoFlag = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr bool BF32 = sizeof(BT) == 4;
@@ -224,7 +225,10 @@ __global__ __launch_bounds__(64) void dtw_exact_reg_kernel(
     } else {
         total = (uint64_t)nSrc * nTgt;
     }
-    if (total < totalLo || total > totalHi)      // the list length decides between this kernel and its sibling (see the launcher)
+    // the list length decides between this kernel and its pipelined sibling (see the launcher) -- unless a wave of
+    // the sibling gave up waiting (its failure count is not zero): then this kernel scores the whole list again
+    const bool redo = redoFlag && *redoFlag != 0;
+    if (!redo && (total < totalLo || total > totalHi))
         return;
     for (uint64_t k = blockIdx.x; k < total; k += gridDim.x) {
         uint32_t s, t;
@@ -381,7 +385,10 @@ __global__ __launch_bounds__(64) void dtw_exact_reg_kernel(
 // only when it has caught up and then waits for 16 columns more than it needs, so it polls once per 16
 // steps.  Nobody waits for a wave BELOW it, wave 0 waits for nobody, and every wave publishes "all
 // final" when it leaves its chunk, so the chain always drains; the spin is bounded all the same, and a
-// wave that gives up reports NaN (never a candidate) instead of hanging the GPU.
+// wave that gives up counts itself in `failCount` instead of hanging the GPU: the one-wave-per-pair kernel,
+// launched right behind this one, reads the count and, when it is not zero, scores the whole list again
+// (no host in between; ssym_timings.exact_redone reports it).  SSYM_EXACT_PIPE_FORCE_GIVEUP=1 makes wave 1
+// of the first pair give up at once (tests).
 constexpr int kPipeLag = 16;
 constexpr int kPipeDone = 0x7fffffff;
 
@@ -391,7 +398,7 @@ __global__ __launch_bounds__(512) void dtw_exact_pipe_kernel(
     const double *__restrict__ tgtRaw, const uint64_t *__restrict__ tgtOff, uint32_t nSrc,
     uint32_t nTgt, uint32_t dim, int band, int squared, const uint2 *__restrict__ pairs,
     const uint32_t *__restrict__ countDev, uint32_t maxPairs, uint32_t fbCap,
-    double *__restrict__ out, uint64_t totalLo = 0, uint64_t totalHi = ~0ull)
+    double *__restrict__ out, uint64_t totalLo, uint64_t totalHi, unsigned *__restrict__ failCount, int forceGiveUp)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr bool BF32 = sizeof(BT) == 4;
@@ -483,6 +490,10 @@ __global__ __launch_bounds__(512) void dtw_exact_pipe_kernel(
             for (int tau = jlo; tau < tauEnd; ++tau) {
                 const int j = tau - lane;
                 const int need = min(tau + 1, Fb);   // lane 0 reads boundPrev[tau] and boundPrev[tau - 1]
+                if (forceGiveUp && k == 0 && wave == 1 && tau == jlo) {      // test knob: the give-up path, once
+                    gaveUp = true;
+                    break;
+                }
                 if (known < need) {                  // wave-uniform
                     const int want = min(need + kPipeLag, Fb);
                     int spins = 0;
@@ -550,8 +561,10 @@ __global__ __launch_bounds__(512) void dtw_exact_pipe_kernel(
                 if (lane == 63)
                     prog[wave] = tau - 62;
             }
-            if (gaveUp && lane == 0)
+            if (gaveUp && lane == 0) {
                 *failed = 1;
+                atomicAdd(failCount, 1u);            // the launcher's next kernel sees it and scores the list again
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 63)
                 prog[wave] = kPipeDone;              // also when this wave gave up: the waves below must not wait for it
@@ -777,7 +790,18 @@ int32_t launch_dtw_exact(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet 
     const uint64_t pipeMax = (uint64_t)ctx->num_cus * 64 / std::max<uint32_t>(pipeW, 1);
     const bool pipeOk = !pipeOff && ctx->band < 0 && dimr && dimr <= 48 && pipeW >= 2 && pipeW <= 8 &&
                         pipeLds <= 150 * 1024 && regLds <= 64 * 1024;
+    const unsigned *redoFlag = nullptr;
     if (pipeOk && !(pairs == nullptr && total > pipeMax)) {
+        int32_t rcf = ensure(ctx, ctx->pipe_flag, 8 * sizeof(unsigned));
+        if (rcf != SSYM_OK)
+            return rcf;
+        const int slot = ctx->pipe_slot++ & 7;
+        unsigned *failCount = (unsigned *)ctx->pipe_flag.ptr + slot;
+        SSYM_HIP_CHECK(ctx, hipMemsetAsync(failCount, 0, sizeof(unsigned), st));
+        ctx->pipe_mask |= 1u << slot;
+        redoFlag = failCount;
+        const char *fg = getenv("SSYM_EXACT_PIPE_FORCE_GIVEUP");
+        const int forceGiveUp = fg && atoi(fg) != 0 ? 1 : 0;
 #define SSYM_EXACT_PIPE2(D_, T_)                                                                               \
     do {                                                                                                       \
         auto kern = dtw_exact_pipe_kernel<D_, T_>;                                                             \
@@ -786,7 +810,7 @@ int32_t launch_dtw_exact(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet 
                                                     (int)pipeLds));                                            \
         kern<<<std::min<unsigned>(grid, (unsigned)pipeMax), 64 * pipeW, pipeLds, st>>>(                       \
             src.raw, src.off, tgt.raw, tgt.off, src.n, tgt.n, dim, ctx->band, ctx->squared, pairs, count_dev,  \
-            max_pairs, fbEven, out, (uint64_t)0, pipeMax);                                                     \
+            max_pairs, fbEven, out, (uint64_t)0, pipeMax, failCount, forceGiveUp);                             \
     } while (0)
 #define SSYM_EXACT_PIPE(D_)                                                                                    \
     do {                                                                                                       \
@@ -805,9 +829,9 @@ int32_t launch_dtw_exact(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet 
 #undef SSYM_EXACT_PIPE
 #undef SSYM_EXACT_PIPE2
         SSYM_HIP_CHECK(ctx, hipGetLastError());
-        if (!pairs || max_pairs <= pipeMax)      // the list cannot be longer than the pipelined kernel takes
-            return SSYM_OK;
-        regLo = pipeMax + 1;                     // longer lists: the one-wave-per-pair kernel below
+        // longer lists: the one-wave-per-pair kernel below; a list the pipelined kernel certainly took: that kernel
+        // only as the redo of a give-up (it leaves at once otherwise)
+        regLo = (!pairs || max_pairs <= pipeMax) ? ~0ull : pipeMax + 1;
     }
     if (dimr && regLds <= (size_t)(dimr >= 64 ? 150 : 64) * 1024) {
 #define SSYM_EXACT_REG(...)                                                                                    \
@@ -824,7 +848,8 @@ int32_t launch_dtw_exact(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet 
             SSYM_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                                     (int)regLds));                                             \
         kern<<<grid, 64, regLds, st>>>(src.raw, src.off, tgt.raw, tgt.off, src.n, tgt.n, dim, ctx->band,      \
-                                       ctx->squared, pairs, count_dev, max_pairs, fbEven, out, regLo, ~0ull);  \
+                                       ctx->squared, pairs, count_dev, max_pairs, fbEven, out, regLo, ~0ull,   \
+                                       redoFlag);                                                              \
     } while (0)
         switch (dimr) {
         case 12: SSYM_EXACT_REG(12, 1); break;

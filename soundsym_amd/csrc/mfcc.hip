@@ -133,6 +133,7 @@ int32_t ssym_mfcc(ssym_ctx *ctx, const double *samples, uint64_t n_samples, doub
                   uint32_t n_coeffs, double f_lo, double f_hi, uint32_t flags, double *out_mfccs,
                   double *out_mean)
 {
+    return guarded(ctx, [&]() -> int32_t {
     if (!ctx)
         return SSYM_E_INVALID;
     if (n_coeffs == 0 || n_coeffs > 64 || !(sample_rate > 0.0) || !(f_lo >= 0.0) || !(f_hi > f_lo)) {
@@ -252,6 +253,7 @@ int32_t ssym_mfcc(ssym_ctx *ctx, const double *samples, uint64_t n_samples, doub
         return SSYM_E_HIP;
     }
     return SSYM_OK;
+    });
 }
 
 }  // extern "C"

@@ -74,6 +74,7 @@ extern "C" {
 int32_t ssym_samples_create(ssym_ctx *ctx, const double *samples, const uint64_t *sample_offsets,
                             uint32_t n_sounds, ssym_samples **out)
 {
+    return guarded(ctx, [&]() -> int32_t {
     if (!ctx || !out)
         return SSYM_E_INVALID;
     *out = nullptr;
@@ -116,10 +117,12 @@ int32_t ssym_samples_create(ssym_ctx *ctx, const double *samples, const uint64_t
     }
     *out = h;
     return SSYM_OK;
+    });
 }
 
 int32_t ssym_samples_destroy(ssym_ctx *ctx, ssym_samples *s)
 {
+    return guarded(ctx, [&]() -> int32_t {
     if (!s)
         return SSYM_OK;
     if (ctx) {
@@ -130,11 +133,13 @@ int32_t ssym_samples_destroy(ssym_ctx *ctx, ssym_samples *s)
     if (s->off) (void)hipFree(s->off);
     delete s;
     return SSYM_OK;
+    });
 }
 
 int32_t ssym_reconstruct(ssym_ctx *ctx, const ssym_samples *s, const uint32_t *idx, const uint64_t *out_offsets,
                          uint32_t n_targets, double *out_samples, int32_t *out_pcm32)
 {
+    return guarded(ctx, [&]() -> int32_t {
     if (!ctx)
         return SSYM_E_INVALID;
     if (!s || !idx || !out_offsets || out_offsets[0] != 0) {
@@ -189,6 +194,7 @@ int32_t ssym_reconstruct(ssym_ctx *ctx, const ssym_samples *s, const uint32_t *i
     tm.main_launches = 1;
     ctx->timings = tm;
     return SSYM_OK;
+    });
 }
 
 }  // extern "C"

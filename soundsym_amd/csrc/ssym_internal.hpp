@@ -5,7 +5,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <exception>
 #include <map>
+#include <new>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -112,6 +114,11 @@ struct ssym_ctx {
     ssym::DeviceBuf part;       // refcos partial argmin
     ssym::DeviceBuf one_ticket; // refcos_match_one_kernel: the "last workgroup" counter (zero between calls)
     ssym::DeviceBuf out_idx, out_cost;  // staging for host outputs
+    // dtw_exact_pipe_kernel: 8 give-up counters, one per launch (round robin); pipe_mask = the slots this API
+    // call used, read back with the call's results into ssym_timings.exact_redone
+    ssym::DeviceBuf pipe_flag;
+    int pipe_slot = 0;
+    unsigned pipe_mask = 0;
     hipEvent_t ev[8]{};
     float prune_swept = 1.f;               // share of the filter's cells the last pruned call swept (picks the pass height)
     unsigned long long pruned_cells = 0;   // SSYM_DTW_PRUNE: the filter's counter of the last call (host copy)
@@ -178,6 +185,36 @@ namespace ssym {
     } while (0)
 
 int32_t ensure(ssym_ctx *ctx, DeviceBuf &b, size_t bytes);
+
+// Every extern "C" entry point runs its body through this: the header promises that no C++ exception crosses
+// the boundary (a Rust or C caller cannot unwind through it).  std::bad_alloc from the host-side containers
+// becomes SSYM_E_NOMEM, anything else SSYM_E_HIP; the per-call mode flags of the context are put back.
+template <class F>
+inline int32_t guarded(ssym_ctx *ctx, F &&body) noexcept
+{
+    int32_t rc;
+    const char *what = nullptr;
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        rc = SSYM_E_NOMEM;
+        what = "out of host memory";
+    } catch (const std::exception &e) {
+        rc = SSYM_E_HIP;
+        what = "unexpected C++ exception inside the library";
+    } catch (...) {
+        rc = SSYM_E_HIP;
+        what = "unexpected C++ exception inside the library";
+    }
+    if (ctx) {
+        ctx->stream_only = ctx->defer_sync = ctx->pack_light = false;
+        try {
+            ctx->err = what;
+        } catch (...) {
+        }
+    }
+    return rc;
+}
 
 // pack.hip
 int32_t pack_segments(ssym_ctx *ctx, SegmentSet &set, const void *feats, bool feats_on_device,

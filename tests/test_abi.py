@@ -24,9 +24,9 @@ def test_library_exports_every_declared_symbol(native_lib):
 
 
 def test_struct_layouts_match_header():
-    # ssym_config: u32 + 5 x i32 + pointer + 2 x i32; ssym_timings: 6 floats, 2 x u64, 2 x i32, float, i32, u64, float, i32
+    # ssym_config: u32 + 5 x i32 + pointer + 2 x i32; ssym_timings: 6 floats, 2 x u64, 2 x i32, float, i32, u64, float, 3 x i32
     assert ctypes.sizeof(nat.Config) == 40
-    assert ctypes.sizeof(nat.Timings) == 72
+    assert ctypes.sizeof(nat.Timings) == 80
 
 
 def test_no_cpu_fallback_without_a_device(native_lib):

@@ -11,10 +11,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(extra):
+def _run(extra, env=None, shape=("--src-per-gpu", "512", "--targets", "256", "--frames", "64")):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1",
-                          "--src-per-gpu", "512", "--targets", "256", "--frames", "64", "--no-cpu-baseline"] + extra,
-                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+                          "--no-cpu-baseline"] + list(shape) + extra,
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, **(env or {})))
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -43,3 +43,19 @@ def test_bench_early_abandon_leg_is_identical_to_the_full_search():
     assert ea["identical_to_full_search"] is True and ea["value"] > 0
     assert 0 < ea["filter_cells_swept_frac"] <= 1
     assert set(line["secondary"]) >= {"refcos", "chain", "mfcc", "match_one"}
+    ncp = ea["no_close_pair"]
+    assert ncp["identical_to_full_search"] is True and ncp["pruned_ms_per_step"] > 0
+
+
+def test_bench_sharded_path_through_the_library_collectives():
+    # one rank, but the N > 1 code path: RCCL communicator behind the C ABI, ssym_match_sharded per step
+    line = _run(["--no-secondary"], env={"SSYM_BENCH_FORCE_DIST": "1", "MASTER_PORT": "29547"},
+                shape=("--sources", "512", "--targets", "256", "--frames", "64"))
+    assert line["config"]["indices_equal_planted"] is True and line["config"]["collective_ms"] > 0
+    assert line["config"]["per_rank"][0]["attempts"] == 1
+    assert line["scaling"] == "weak" and line["n_gpus"] == 1      # (strong is reported from 2 GPUs on)
+
+
+def test_bench_banded_workload_shape():
+    line = _run(["--no-secondary", "--workload", "c5"], shape=("--sources", "256", "--targets", "256", "--frames", "96"))
+    assert line["roofline"]["kernel"] == "dtw_band_kernel" and line["config"]["indices_equal_planted"] is True

@@ -94,6 +94,68 @@ def test_config5_shape_banded_512x512x256x40():
     e.close()
 
 
+def _banded_grid(n, m, f, dim, seed):
+    """configs[4]-shaped data from numpy's generator (synth.make_grid takes ~10 s at this size): sources with the
+    MFCC-like 4/(1+k) decay and a slow per-segment drift, targets = a permutation's sources, time-warped by
+    repeating / dropping <= 8 % of the frames (well inside the band) plus noise -- the planted neighbour of
+    target t is perm[t] by construction."""
+    rng = np.random.default_rng(seed)
+    sig = (4.0 / (1.0 + np.arange(dim))).astype(np.float32)
+    src = rng.standard_normal((n, f, dim), dtype=np.float32) * sig
+    src += (rng.standard_normal((n, 1, dim), dtype=np.float32) * sig) * np.linspace(0, 1, f, dtype=np.float32)[None, :, None]
+    perm = rng.permutation(n)[:m]
+    pos = np.cumsum(rng.choice(np.array([0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2]),
+                               size=(m, f)), axis=1)
+    pos = np.clip(np.round(pos * (f - 1) / np.maximum(pos[:, -1:], 1)), 0, f - 1).astype(np.int64)
+    tgt = np.take_along_axis(src[perm], pos[:, :, None], axis=1)
+    tgt = tgt + 0.05 * sig * rng.standard_normal((m, f, dim), dtype=np.float32)
+    return src, tgt.astype(np.float32), perm
+
+
+def test_config5_full_size_4096x4096x256x40_band32(oracle):
+    """BASELINE configs[4] at FULL size on one GPU: 4096 x 4096 segments, 256 frames x 40 dims, Sakoe-Chiba
+    r = 32.  Planted indices, run-to-run identical bits, 16 sampled targets' winners against the oracle over
+    all 4096 sources, and 1024 sampled pairs of the banded filter's matrix against ssym_oracle_dtw(band = 32)
+    under the filter's derived bound."""
+    from bounds import worst_case_bound
+    n = m = 4096
+    f, dim, band = 256, 40, 32
+    src, tgt, perm = _banded_grid(n, m, f, dim, 0x5EED0C05)
+    so = np.arange(n + 1, dtype=np.uint64) * f
+    to = np.arange(m + 1, dtype=np.uint64) * f
+    e = Engine(metric="dtw", dtype="f32", band=band)
+    d, q = e.dictionary(src.reshape(-1), so, dim), e.queries(tgt.reshape(-1), to, dim)
+    idx, cost = e.match(d, q)
+    tm = e.timings()
+    assert tm["used_filter"] == 1 and tm["n_pairs"] == n * m
+    assert np.array_equal(idx, perm)
+    idx2, cost2 = e.match(d, q)
+    assert np.array_equal(idx, idx2) and np.array_equal(cost, cost2)              # run-to-run identical
+    # 16 sampled targets end to end against the oracle (all 4096 sources each)
+    pick = np.arange(100, m, 256)
+    assert pick.size == 16
+    tsel = np.ascontiguousarray(tgt[pick]).reshape(-1).astype(np.float64)
+    tosel = np.arange(pick.size + 1, dtype=np.uint64) * f
+    want_idx, want_cost = oracle.dtw_match_all(src.reshape(-1).astype(np.float64), so, tsel, tosel, dim, band=band,
+                                               nthreads=oracle.max_threads())
+    assert np.array_equal(idx[pick], want_idx)
+    assert np.allclose(cost[pick], want_cost, rtol=1e-5, atol=0)                  # the north star's tolerance
+    assert np.allclose(cost[pick], want_cost, rtol=1e-12, atol=0)                 # what the exact kernel delivers
+    # 1024 sampled pairs of the filter's matrix (winners, near and far pairs) under its bound
+    filt = e.pair_matrix(d, q, exact=False)
+    e.close()
+    rng = np.random.default_rng(5)
+    ss = np.concatenate([rng.integers(0, n, 960), perm[:64]])
+    tt = np.concatenate([rng.integers(0, m, 960), np.arange(64)])
+    bound, _ = worst_case_bound(src, tgt, dim, f, f)
+    worst = 0.0
+    for s_, t_ in zip(ss, tt):
+        want = oracle.dtw(src[s_].astype(np.float64), tgt[t_].astype(np.float64), dim, band=band)
+        assert np.isfinite(filt[s_, t_]) and abs(filt[s_, t_] - want) <= bound + 1e-5 * want, (s_, t_, filt[s_, t_], want, bound)
+        worst = max(worst, abs(filt[s_, t_] - want) / want)
+    assert worst < 1e-2, worst        # (in practice the f16 filter is within ~1e-3 relative at this shape)
+
+
 def test_config4_16384x4096_source_sharded_on_one_gpu(dtw):
     """BASELINE configs[3]: 16384 x 4096 segments, 128 frames x 13 dims, source axis split in 8
     shards.  The 8 ranks' work is run one after the other on this GPU (same calls a rank makes:

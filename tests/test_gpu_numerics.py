@@ -15,33 +15,10 @@ import pytest
 
 from soundsym_amd import Engine
 from soundsym_amd.engine import pack_segments
+from bounds import worst_case_bound as _worst_case_bound
 
 pytestmark = pytest.mark.gpu
 EXACT_RTOL = 1e-12
-
-
-def _common_scale(vmax, sqmax):
-    """csrc/dtw_filter.hip common_scale: max |s v| < 64 and s^2 * max |frame|^2 * 1.01 < 65000."""
-    if not vmax > 0:
-        return 1.0
-    e = 6 - math.frexp(vmax)[1]
-    while sqmax * 2.0 ** (2 * e) * 1.01 >= 65000.0:
-        e -= 1
-    return 2.0 ** e
-
-
-def _worst_case_bound(src, tgt, dim_used, fa, fb):
-    """|C~ - C| of the filter with the worst-case cell error (csrc/dtw_margin.hpp, xmin = 0)."""
-    u = 2.0 ** -24
-    in_round = 2.0 ** -22 if dim_used <= 13 else 2.0 ** -11
-    sq = lambda a: float((a.astype(np.float64)[..., :dim_used] ** 2).sum(-1).max())
-    na, nb = sq(src), sq(tgt)
-    full = lambda a: float((np.float32(1.000001) * (a.astype(np.float64) ** 2).sum(-1).astype(np.float32)).max())
-    vmax = max(float(np.abs(src).max()), float(np.abs(tgt).max())) * 1.000001
-    s = _common_scale(vmax, max(full(src), full(tgt)))
-    E = 256 * u * (na + nb) + 2.0 ** -12 / s ** 2
-    cell = math.sqrt(E) + 1.001 * in_round * (math.sqrt(na) + math.sqrt(nb)) + 2.0 ** -20 / s
-    return 1.02 * (fa + fb - 1) * cell, s
 
 
 @pytest.mark.parametrize("dim", [18, 40, 42, 64])
@@ -116,3 +93,36 @@ def test_dtw_filter_subnormal_second_pieces_stay_inside_the_cell_bound():
     worst = np.abs(filt - want) / bound
     assert (worst <= 1.0).all(), ("filter cell outside the bound of select.hip -- subnormal f16 pieces flushed?",
                                   float(worst.max()), np.unravel_index(worst.argmax(), worst.shape))
+
+
+def test_dtw_exact_pipelined_wave_giving_up_is_redone_not_dropped(oracle, monkeypatch):
+    # dtw_exact_pipe_kernel bounds its spin; a wave that gives up must not turn its pair into "never a
+    # candidate".  SSYM_EXACT_PIPE_FORCE_GIVEUP=1 makes wave 1 of the first pair give up at once: the
+    # one-wave-per-pair kernel behind it scores the list again, results stay exact, exact_redone says so.
+    from soundsym_amd import synth
+    dim, n, m = 13, 6, 5
+    st = synth.Stream(0x5EED6100)
+    ls = 200 + st.integers(n, 200)
+    lt = 100 + st.integers(m, 200)
+    src = [st.normal(int(f) * dim).reshape(int(f), dim) * synth.sigma(dim) for f in ls]
+    tgt = [st.normal(int(f) * dim).reshape(int(f), dim) * synth.sigma(dim) for f in lt]
+    tgt[0] = src[0][3:].copy()           # pair 0 of the all-pairs list holds target 0's neighbour
+    sf, so = pack_segments(src, dim, np.float32)
+    tf, to = pack_segments(tgt, dim, np.float32)
+    want_idx, want_cost = oracle.dtw_match_all(sf.astype(np.float64), so, tf.astype(np.float64), to, dim)
+    assert want_idx[0] == 0
+    e = Engine(metric="dtw", dtype="f32")
+    d, q = e.dictionary(sf, so, dim), e.queries(tf, to, dim)
+    idx, cost = e.match(d, q, force_exact=True)
+    assert e.timings()["exact_redone"] == 0
+    assert np.array_equal(idx, want_idx) and np.allclose(cost, want_cost, rtol=EXACT_RTOL, atol=0)
+    monkeypatch.setenv("SSYM_EXACT_PIPE_FORCE_GIVEUP", "1")
+    idx2, cost2 = e.match(d, q, force_exact=True)
+    assert e.timings()["exact_redone"] == 1
+    assert np.array_equal(idx2, idx) and np.array_equal(cost2, cost)
+    # through the filter path as well (the candidates' re-scoring uses the same launcher)
+    idx3, cost3 = e.match(d, q)
+    assert e.timings()["used_filter"] == 1 and e.timings()["exact_redone"] >= 1
+    assert np.array_equal(idx3, idx) and np.array_equal(cost3, cost)
+    monkeypatch.delenv("SSYM_EXACT_PIPE_FORCE_GIVEUP")
+    e.close()

@@ -305,7 +305,8 @@ def test_dtw_wide_frames_use_single_piece_records(oracle, dim, f):
 
 
 @pytest.mark.parametrize("n,m,f,dim,band", [(24, 40, 30, 13, 3), (16, 33, 64, 13, 8), (10, 12, 100, 40, 32),
-                                              (12, 9, 48, 12, 0), (8, 8, 70, 20, 40), (9, 11, 90, 13, 28)])
+                                              (12, 9, 48, 12, 0), (8, 8, 70, 20, 40), (9, 11, 90, 13, 28),
+                                              (12, 10, 256, 40, 32)])      # the last: configs[4]'s segment shape
 def test_dtw_banded_filter_vs_oracle(oracle, n, m, f, dim, band):
     # Sakoe-Chiba band on the MFMA path: diagonal-coordinate kernel, source pair in LDS
     e = Engine(metric="dtw", dtype="f32", band=band)
