@@ -212,7 +212,9 @@ SSYM_API int32_t ssym_chain(ssym_ctx *ctx, ssym_dict *dict, const void *start_fe
                    const double *distances, uint32_t n_steps, uint32_t *out_idx, double *out_cost);
 
 /* The whole [n_sources][n_targets] matrix in HOST memory, row-major, f64:
- *   refcos: cosine_sim(source, target) (src/sound.rs:22-33), bit for bit;
+ *   refcos: cosine_sim(source, target) (src/sound.rs:22-33), bit for bit (exact = 0 or 1); exact = 2 -> the
+ *           similarities the f64 matrix pipe's dots give (the filter of the refcos search: FMA chains in another
+ *           summation order, within (3 L + 16) 2^-53 sqrt(norm(me) norm(you)) / nrm of the reference's);
  *   dtw:    exact = 0 -> the f32 MFMA filter's costs (frames wider than 42 values: of their first 42
  *           values only; a Sakoe-Chiba band beyond the banded kernel, r > 47: the unbanded cost --
  *           either way a lower bound of every pair's cost); exact = 1 -> the exact f64 costs. */

@@ -405,6 +405,30 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
 
     hipEvent_t *ev = ctx->ev;
     if (ctx->metric == SSYM_METRIC_REFCOS) {
+        // The plain first-minimum search goes through the f64 matrix pipe (refcos_mfma.hip): every pair's dot as a
+        // GEMM, a rigorous interval per key, and the reference's own arithmetic only on the few pairs that can
+        // hold a target's minimum -- same bits out.  Top-k, the sharded phases (no host look at the list) and small
+        // problems keep the exact tile kernel on every pair; so does a call whose candidate list overflowed.
+        bool viaMfma = k_top == 1 && !ctx->stream_only && refcos_mfma_supported(ctx, src, tgt);
+        if (viaMfma) {
+            const uint32_t *h1dev = nullptr, *h2dev = nullptr;
+            uint32_t h1[2] = {0, 0}, h2[2] = {0, 0};
+            SSYM_HIP_CHECK(ctx, hipEventRecord(ev[0], st));
+            rc = launch_refcos_match_mfma(ctx, src, tgt, distDev, index_base, idxDev, costDev, &h1dev, &h2dev);
+            if (rc != SSYM_OK)
+                return rc;
+            SSYM_HIP_CHECK(ctx, hipEventRecord(ev[2], st));
+            SSYM_HIP_CHECK(ctx, hipMemcpyAsync(h1, h1dev, sizeof(h1), hipMemcpyDeviceToHost, st));
+            SSYM_HIP_CHECK(ctx, hipMemcpyAsync(h2, h2dev, sizeof(h2), hipMemcpyDeviceToHost, st));
+            SSYM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+            if (h1[1])
+                viaMfma = false;             // more near-ties than the list holds: the exact kernel on every pair
+            else {
+                tm.used_filter = 1;
+                tm.n_refined = h2[0];
+            }
+        }
+        if (!viaMfma) {
         rc = ensure(ctx, ctx->cmat, sizeof(double) * (size_t)N * M);
         if (rc != SSYM_OK)
             return rc;
@@ -418,6 +442,7 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
         if (rc != SSYM_OK)
             return rc;
         SSYM_HIP_CHECK(ctx, hipEventRecord(ev[2], st));
+        }
         tm.main_launches = 1;          // event times are read after the one synchronisation below
     } else {
         // frames wider than the filter's 42 values: the filter scores the first 42 and bounds the cost from
@@ -1062,7 +1087,7 @@ int32_t ssym_pair_matrix(ssym_ctx *ctx, const ssym_dict *dict, const ssym_querie
         return rc;
     double *mat = (double *)ctx->part.ptr;
     if (ctx->metric == SSYM_METRIC_REFCOS) {
-        rc = launch_refcos_sims(ctx, src, tgt, mat);
+        rc = exact == 2 ? launch_refcos_mfma_sims(ctx, src, tgt, mat) : launch_refcos_sims(ctx, src, tgt, mat);
     } else if (exact) {
         rc = launch_dtw_exact(ctx, src, tgt, nullptr, nullptr, 0, mat);
     } else {

@@ -17,6 +17,15 @@
 namespace ssym {
 
 constexpr int kBandTgtQuantum = 256;   // targets are padded to this (8 groups of 32)
+// The waves of a workgroup take the target groups of the staged source pair from an LDS counter instead of owning
+// one group per block: the two waves of a SIMD do not advance at the same pace (the older one wins the VALU
+// arbitration), and with a fixed share the faster wave of every SIMD sat at the workgroup barrier while the slower
+// one finished alone.
+#ifndef SSYM_BAND_DYNAMIC_GROUPS
+#define SSYM_BAND_DYNAMIC_GROUPS 1
+#endif
+constexpr bool kBandDynamicGroups = SSYM_BAND_DYNAMIC_GROUPS != 0;
+constexpr int kBandImagePad = 8;       // halfs between the two sources' LDS images (16 bytes = 4 banks, see the kernel)
 
 // Records of one source in the banded layout: slot s holds frame s - lead, lead = r.
 // WB = waves per workgroup = target groups (of 32) per task; OCC = waves per SIMD the register
@@ -41,7 +50,7 @@ __global__ __launch_bounds__(64 * WB, OCC) void dtw_band_kernel(
     constexpr int REC = kFilterRecHalfs;
     constexpr int KB = (NTB - 1) * 16 + LASTN;   // diagonals held in registers (>= 2r+1)
     const float INF = __builtin_inff();
-    extern __shared__ __attribute__((aligned(16))) _Float16 ldsSrc[];   // [2][srcSlots][48]
+    extern __shared__ __attribute__((aligned(16))) _Float16 ldsSrc[];   // [srcSlots][48], 16 bytes, [srcSlots][48]
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -53,7 +62,11 @@ __global__ __launch_bounds__(64 * WB, OCC) void dtw_band_kernel(
     const int arow = lane & 31;
     const int a_h = (arow >> 2) & 1;
     const int a_local = (arow & 3) + 4 * (arow >> 3);
-    const _Float16 *const aLane = ldsSrc + ((size_t)a_h * srcSlots + a_local) * REC + half * 24;
+    // The second source's image starts 16 bytes late: records are 96 bytes, so every record starts on a bank that is a
+    // multiple of 8 and the eight records per source that one 16-lane group of a ds_read_b128 touches fill the same
+    // eight 4-bank slots in both images -- a two-way conflict on every read (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
+    // = 0.50 measured); shifted by 4 banks the two images interleave.
+    const _Float16 *const aLane = ldsSrc + ((size_t)a_h * srcSlots + a_local) * REC + half * 24 + a_h * kBandImagePad;
 
     // Workgroups take SOURCE PAIRS from one counter, longest first (record slots are ordered by segment
     // length, so the list is walked from its end), and sweep all target blocks against the pair while
@@ -76,14 +89,14 @@ __global__ __launch_bounds__(64 * WB, OCC) void dtw_band_kernel(
         {
             const uint4 *g = reinterpret_cast<const uint4 *>(srcRec + (size_t)(2 * sp) * srcSlots * REC);
             uint4 *l = reinterpret_cast<uint4 *>(ldsSrc);
-            const int n16 = 2 * srcSlots * REC * 2 / 16;
+            const int n16 = 2 * srcSlots * REC * 2 / 16, per = n16 / 2;
             for (int i = threadIdx.x; i < n16; i += 64 * WB)
-                l[i] = g[i];
+                l[i + (i >= per ? kBandImagePad * 2 / 16 : 0)] = g[i];
             __syncthreads();
         }
       for (int tb = nTgtBlocks - 1;; --tb) {
         int tg;
-        if (PRUNE) {                                   // next target group of this source pair, longest first
+        if (PRUNE || kBandDynamicGroups) {             // next target group of this source pair, longest first
             unsigned g = 0;
             if (lane == 0)
                 g = atomicAdd(&sGroup, 1u);

@@ -102,7 +102,7 @@ static uint32_t band_slots(int radius, const SegmentSet &src, const SegmentSet &
 }
 static size_t band_lds_bytes(int radius, const SegmentSet &src, const SegmentSet &tgt)
 {
-    return (size_t)2 * band_slots(radius, src, tgt) * kFilterRecHalfs * sizeof(_Float16);
+    return ((size_t)2 * band_slots(radius, src, tgt) * kFilterRecHalfs + kBandImagePad) * sizeof(_Float16);
 }
 
 // A Sakoe-Chiba band the banded kernel cannot take -- more than 6 tiles of diagonals (r > 47), or a source pair that

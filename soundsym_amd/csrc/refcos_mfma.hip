@@ -1,0 +1,472 @@
+// refcos_mfma.hip -- the reference's own search (cosine_sim + at_distance) through the f64 matrix pipe,
+// results still bit for bit the reference's.
+//
+// Role on the path: SoundDictionary::at_distance (src/sound.rs:351-370) maps every dictionary entry to
+// |cosine_sim(entry, other) - distance| (src/sound.rs:22-33, 359) and folds to the first minimum.  N x M
+// prefix dot products are one zero-padded GEMM: a segment's values beyond its length are
+// staged as zeros, so the product over the padded length equals rulinalg's dot over the common prefix.
+//
+//   1. refcos_mfma_kernel    every pair's dot on v_mfma_f64_16x16x4_f64 (FMA chains, another summation
+//                            order than the reference's -- so only a FILTER), turned at once into a rigorous
+//                            interval [key_lo, key_hi] for the reference's key |dot/nrm - distance|; the
+//                            smallest key_hi per target is the target's threshold, pairs whose key_lo does
+//                            not exceed the threshold seen so far are listed (list 1)
+//   2. refcos_keep_kernel    list 1 against the FINAL thresholds -> candidates
+//   3. refcos_pairs_kernel   the candidates' keys in the reference's own operation order (eight running sums,
+//                            separately rounded products and sums, the same code shape as refcos.hip)
+//   4. refcos_fold_*         first minimum among the candidates in index order, strict '<' from (0, 2.0)
+//
+// Interval (u = 2^-53, L = common prefix length, P = sum |a_i b_i| <= sqrt(norm(me) norm(you)) by
+// Cauchy-Schwarz, norm = the reference's sum of squares):
+//   any floating-point evaluation of the L-term dot, products rounded or fused, sums in any order, stays
+//   within gamma_n P of the exact dot with n = number of roundings on a path <= 2 L + 8; the reference's
+//   value and the matrix pipe's therefore differ by at most E = (3 L + 16) u * 1.02 * sqrt(na nb) (+ a floor
+//   for products that underflow).  nrm = fl(na * nb) is the reference's own (norms are computed in its order at
+//   pack time), division and subtraction are correctly rounded, hence monotone:
+//       dot in [lo, hi]  =>  fl(fl(dot / nrm) - d) in [fl(fl(lo / nrm) - d), fl(fl(hi / nrm) - d)],
+//   and |.| of an interval is an interval.  Instead of two divisions per pair the kernel multiplies by
+//   fl(1/na) fl(1/nb), which is 1/nrm up to 4.1 u, and moves both ends outwards by 8 u.  nrm = 0 or NaN: the
+//   reference's key is NaN or +inf and never wins (src/sound.rs:362) -- the pair is dropped; anything else
+//   that is not finite: the pair is kept with [0, +inf].
+// The true first minimum w has key(w) <= key(s) <= key_hi(s) for all s, so key_lo(w) <= threshold: it is
+// among the candidates, and the fold over exact keys in index order returns what the reference returns.
+#include "ssym_internal.hpp"
+
+#include <algorithm>
+#include <cmath>
+
+namespace ssym {
+
+namespace {
+
+constexpr int kMT = 128;            // sources per workgroup tile
+constexpr int kNT = 128;            // targets per workgroup tile
+constexpr int kKC = 16;             // elements per staged chunk (one 128-byte line per segment)
+constexpr int kLdk = kKC + 2;       // LDS row stride in doubles (16-byte aligned rows)
+typedef double double4v __attribute__((ext_vector_type(4)));
+typedef double double2v __attribute__((ext_vector_type(2)));
+
+constexpr unsigned long long kInfBitsU = 0x7ff0000000000000ull;
+
+struct PairEntry {                  // list 1: a pair that may hold its target's first minimum
+    uint32_t s, t;
+    double key_lo;
+};
+
+__device__ __forceinline__ void refcos_key_interval(double dotm, double sa, double sb, double ia, double ib,
+                                                    double nrm, unsigned len, double d, double &klo, double &khi)
+{
+    const double INF = __builtin_inf();
+    if (d != d || nrm != nrm || nrm == 0.0) {      // the reference's key is NaN or +inf: never a winner (src/sound.rs:362)
+        klo = khi = INF;
+        return;
+    }
+    const double u = 1.1102230246251565e-16;
+    const double E = ((3.0 * (double)len + 16.0) * u * 1.02) * (sa * sb) + (double)len * 1e-300;
+    const double slackDot = fabs(dotm) * 4.0 * u;                 // roundings of the two additions below
+    const double lo = dotm - E - slackDot, hi = dotm + E + slackDot;
+    const double inv = ia * ib;                                    // 1 / nrm within 4.1 u
+    double slo = lo * inv, shi = hi * inv;
+    const bool tiny = !(fabs(slo) > 1e-290) || !(fabs(shi) > 1e-290);   // (near the subnormals the 8 u steps do not move)
+    slo -= fabs(slo) * 8.0 * u;                                    // outwards: below fl(lo / nrm), above fl(hi / nrm)
+    shi += fabs(shi) * 8.0 * u;
+    const double ylo = slo - d, yhi = shi - d;                     // correctly rounded, monotone
+    const bool fin = inv > 0.0 && inv < INF && E < INF && dotm == dotm && ylo == ylo && yhi == yhi && !tiny;
+    if (!fin) {                                                    // anything odd: the pair stays in, bounds nothing
+        klo = 0.0;
+        khi = INF;
+        return;
+    }
+    klo = ylo > 0.0 ? ylo : (yhi < 0.0 ? -yhi : 0.0);
+    khi = fmax(fabs(ylo), fabs(yhi));
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// 128 x 128 pairs per workgroup, four waves of 64 x 64, K in chunks of 16 elements staged through LDS
+// (zero beyond each segment's length).  MFMA operand layout (gfx950 v_mfma_f64_16x16x4_f64): A[m][k] in lane
+// m + 16 k, B[k][n] in lane n + 16 k, D[4 (lane / 16) + i][lane % 16] in register pair i.  The summation index
+// is free to permute: lane group g = lane / 16 takes elements 4 g .. 4 g + 3 of a chunk, one per MFMA step, so
+// a lane's four A (or B) values of a chunk are 32 contiguous bytes of LDS -- two ds_read_b128.
+__global__ __launch_bounds__(256, 2) void refcos_mfma_kernel(
+    const double *__restrict__ srcRaw, const uint64_t *__restrict__ srcOff, const double *__restrict__ srcNorm,
+    const double *__restrict__ tgtRaw, const uint64_t *__restrict__ tgtOff, const double *__restrict__ tgtNorm,
+    uint32_t nSrc, uint32_t nTgt, uint32_t dim, const double *__restrict__ dist, double defaultDist,
+    unsigned long long *__restrict__ thr /* [nTgt] smallest key_hi so far (bits) */,
+    uint32_t *__restrict__ hdr /* {count, overflow} */, PairEntry *__restrict__ list, uint32_t cap,
+    double *__restrict__ dotOut /* nullable: [nSrc][nTgt] sims from the matrix pipe's dots (ssym_pair_matrix, exact = 2) */)
+{
+    __shared__ __attribute__((aligned(16))) double sA[2][kMT * kLdk];
+    __shared__ __attribute__((aligned(16))) double sB[2][kNT * kLdk];
+    __shared__ unsigned long long sBase[kMT + kNT];
+    __shared__ unsigned sLen[kMT + kNT];
+    __shared__ unsigned sMaxLen[2];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;              // this wave's 64 x 64 quadrant
+    const uint32_t sTile = blockIdx.y * kMT, tTile = blockIdx.x * kNT;
+
+    if (tid < 2)
+        sMaxLen[tid] = 0;
+    __syncthreads();
+    {
+        const bool isS = tid < kMT;
+        const uint32_t g = isS ? sTile + tid : tTile + (tid - kMT);
+        const uint32_t n = isS ? nSrc : nTgt;
+        const uint64_t *off = isS ? srcOff : tgtOff;
+        unsigned long long base = 0;
+        unsigned len = 0;
+        if (g < n) {
+            base = off[g] * dim;
+            len = (unsigned)((off[g + 1] - off[g]) * dim);
+        }
+        sBase[tid] = base;
+        sLen[tid] = len;
+        atomicMax(&sMaxLen[isS ? 0 : 1], len);
+    }
+    __syncthreads();
+    const unsigned kMax = min(sMaxLen[0], sMaxLen[1]);    // beyond it every product of the tile is zero
+    const unsigned nChunks = (kMax + kKC - 1) / kKC;
+
+    // staging: thread -> (row = tid / 16 + 16 p, element tid % 16) for p = 0..7, both sides: 16 doubles in flight
+    const int se = tid & 15, sr = tid >> 4;
+    double stA[8], stB[8];
+    auto fetch = [&](unsigned c) {
+        const unsigned e = c * kKC + se;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int row = sr + 16 * p;
+            stA[p] = e < sLen[row] ? srcRaw[sBase[row] + e] : 0.0;
+            stB[p] = e < sLen[kMT + row] ? tgtRaw[sBase[kMT + row] + e] : 0.0;
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int row = sr + 16 * p;
+            sA[buf][row * kLdk + se] = stA[p];
+            sB[buf][row * kLdk + se] = stB[p];
+        }
+    };
+
+    double4v acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            acc[a][b] = double4v{0.0, 0.0, 0.0, 0.0};
+
+    const int lr = lane & 15, lg = lane >> 4;
+    if (nChunks > 0) {
+        fetch(0);
+        stash(0);
+    }
+    __syncthreads();
+    for (unsigned c = 0; c < nChunks; ++c) {
+        const int buf = (int)(c & 1);
+        if (c + 1 < nChunks)
+            fetch(c + 1);                                  // global loads in flight under the MFMAs
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {                   // two MFMA steps per 16-byte LDS read
+            double av[4][2], bv[4][2];                     // [block][step]
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk) {
+                const double2v a2 = *reinterpret_cast<const double2v *>(&sA[buf][(wm * 64 + blk * 16 + lr) * kLdk + 4 * lg + 2 * hf]);
+                const double2v b2 = *reinterpret_cast<const double2v *>(&sB[buf][(wn * 64 + blk * 16 + lr) * kLdk + 4 * lg + 2 * hf]);
+                av[blk][0] = a2[0]; av[blk][1] = a2[1];
+                bv[blk][0] = b2[0]; bv[blk][1] = b2[1];
+            }
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a][st], bv[b][st], acc[a][b], 0, 0, 0);
+        }
+        if (c + 1 < nChunks)
+            stash(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: dots -> key intervals -> thresholds and list 1 ------------------------------------------
+    // D[4 (lane / 16) + i][lane % 16]: this lane holds, per block pair (a, b), source rows 4 lg + i and target column lr
+    const double INF = __builtin_inf();
+#pragma unroll 1
+    for (int b = 0; b < 4; ++b) {
+        const int col = wn * 64 + b * 16 + lr;
+        const uint32_t t = tTile + col;
+        const unsigned lb = sLen[kMT + col];
+        const double nb = t < nTgt ? tgtNorm[t] : 0.0;
+        const double sb = sqrt(nb) * (1.0 + 4.5e-16), ib = 1.0 / nb;
+        const double d = (dist && t < nTgt) ? dist[t] : defaultDist;
+        double klos[4][4];
+        double colMin = INF;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = wm * 64 + a * 16 + 4 * lg + i;
+                const uint32_t s = sTile + row;
+                double klo = INF, khi = INF;
+                if (s < nSrc && t < nTgt) {
+                    const unsigned la = sLen[row];
+                    const double na = srcNorm[s];
+                    const double nrm = __dmul_rn(na, nb);                 // src/sound.rs:30
+                    const unsigned len = la < lb ? la : lb;               // src/sound.rs:24-28
+                    const double dv = b == 0 ? acc[a][0][i] : b == 1 ? acc[a][1][i] : b == 2 ? acc[a][2][i] : acc[a][3][i];
+                    refcos_key_interval(dv, sqrt(na) * (1.0 + 4.5e-16), sb, 1.0 / na, ib, nrm, len, d, klo, khi);
+                    if (dotOut)
+                        dotOut[(size_t)s * nTgt + t] = __ddiv_rn(dv, nrm);
+                }
+                klos[a][i] = klo;
+                colMin = fmin(colMin, khi);
+            }
+        // smallest key_hi of the wave's 64 rows in this column, then against the threshold every tile works on
+        colMin = fmin(colMin, __shfl_xor(colMin, 16));
+        colMin = fmin(colMin, __shfl_xor(colMin, 32));
+        unsigned long long seen = kInfBitsU;
+        if (lg == 0 && t < nTgt)
+            seen = atomicMin(&thr[t], (unsigned long long)__double_as_longlong(colMin));    // keys are >= 0: bits order like values
+        seen = __shfl(seen, lr);
+        const double cur = fmin(colMin, __longlong_as_double((long long)seen));
+        // list 1: pairs the threshold known so far does not exclude (the final threshold can only be smaller)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool real = klos[a][i] <= cur && klos[a][i] < INF;
+                const unsigned long long mask = __ballot(real);
+                if (mask) {
+                    uint32_t base = 0;
+                    if (lane == 0)
+                        base = atomicAdd(&hdr[0], (uint32_t)__popcll(mask));
+                    base = __shfl(base, 0);
+                    if (real) {
+                        const uint32_t pos = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+                        if (pos < cap) {
+                            PairEntry e;
+                            e.s = sTile + wm * 64 + a * 16 + 4 * lg + i;
+                            e.t = t;
+                            e.key_lo = klos[a][i];
+                            list[pos] = e;
+                        } else {
+                            hdr[1] = 1;
+                        }
+                    }
+                }
+            }
+    }
+}
+
+// list 1 against the final thresholds -> list 2 (pairs only)
+__global__ void refcos_keep_kernel(const uint32_t *__restrict__ hdr1, const PairEntry *__restrict__ list1, uint32_t cap,
+                                   const unsigned long long *__restrict__ thr, uint32_t *__restrict__ hdr2,
+                                   uint2 *__restrict__ pairs)
+{
+    const uint32_t n = min(hdr1[0], cap);
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool keep = false;
+    PairEntry e{};
+    if (i < n) {
+        e = list1[i];
+        keep = e.key_lo <= __longlong_as_double((long long)thr[e.t]);
+    }
+    const unsigned long long mask = __ballot(keep);
+    if (!mask)
+        return;
+    const int lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    if (lane == (int)__builtin_ctzll(mask))
+        base = atomicAdd(&hdr2[0], (uint32_t)__popcll(mask));
+    base = __shfl(base, (int)__builtin_ctzll(mask));
+    if (keep)
+        pairs[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = make_uint2(e.s, e.t);
+}
+
+// The candidates' keys exactly as the reference computes them: eight lanes per pair, lane i keeps rulinalg's
+// running sum p_i (the code shape of refcos_match_one_kernel), combination, tail, division, |sim - distance|;
+// the smallest key below the fold start 2.0 per target is kept with an integer atomic (keys >= 0).
+__global__ __launch_bounds__(256) void refcos_pairs_kernel(
+    const double *__restrict__ srcRaw, const uint64_t *__restrict__ srcOff, const double *__restrict__ srcNorm,
+    const double *__restrict__ tgtRaw, const uint64_t *__restrict__ tgtOff, const double *__restrict__ tgtNorm,
+    uint32_t dim, const double *__restrict__ dist, double defaultDist, const uint32_t *__restrict__ hdr2,
+    const uint2 *__restrict__ pairs, double *__restrict__ keys, unsigned long long *__restrict__ bestKey)
+{
+    const uint32_t n = hdr2[0];
+    const int i8 = threadIdx.x & 7;
+    const int g0 = (threadIdx.x & 63) & ~7;
+    for (uint32_t k = blockIdx.x * 32 + (threadIdx.x >> 3); k < ((n + 31) & ~31u); k += gridDim.x * 32) {
+        const bool live = k < n;
+        const uint2 pr = live ? pairs[k] : make_uint2(0, 0);
+        unsigned long long ba = 0, bb = 0;
+        uint32_t len = 0;
+        if (live) {
+            ba = srcOff[pr.x] * dim;
+            bb = tgtOff[pr.y] * dim;
+            const uint32_t la = (uint32_t)((srcOff[pr.x + 1] - srcOff[pr.x]) * dim);
+            const uint32_t lb = (uint32_t)((tgtOff[pr.y + 1] - tgtOff[pr.y]) * dim);
+            len = la < lb ? la : lb;                                   // src/sound.rs:24-28
+        }
+        const uint32_t qb = len / 8, rem = len % 8;
+        double p = 0.0;
+        for (uint32_t j = 0; j < qb; ++j)
+            p = __dadd_rn(p, __dmul_rn(srcRaw[ba + 8 * j + i8], tgtRaw[bb + 8 * j + i8]));
+        const double p0 = __shfl(p, g0 + 0), p1 = __shfl(p, g0 + 1), p2 = __shfl(p, g0 + 2), p3 = __shfl(p, g0 + 3);
+        const double p4 = __shfl(p, g0 + 4), p5 = __shfl(p, g0 + 5), p6 = __shfl(p, g0 + 6), p7 = __shfl(p, g0 + 7);
+        if (i8 == 0 && live) {
+            double acc = 0.0;
+            acc = __dadd_rn(acc, __dadd_rn(p0, p4));
+            acc = __dadd_rn(acc, __dadd_rn(p1, p5));
+            acc = __dadd_rn(acc, __dadd_rn(p2, p6));
+            acc = __dadd_rn(acc, __dadd_rn(p3, p7));
+            for (uint32_t i = 0; i < rem; ++i)
+                acc = __dadd_rn(acc, __dmul_rn(srcRaw[ba + 8 * qb + i], tgtRaw[bb + 8 * qb + i]));
+            const double nrm = __dmul_rn(srcNorm[pr.x], tgtNorm[pr.y]);   // src/sound.rs:30
+            const double sim = __ddiv_rn(acc, nrm);                       // src/sound.rs:32
+            const double d = dist ? dist[pr.y] : defaultDist;
+            const double key = fabs(__dsub_rn(sim, d));                   // src/sound.rs:359
+            keys[k] = key;
+            if (key < 2.0)                                                // the fold's start value (NaN: false)
+                atomicMin(&bestKey[pr.y], (unsigned long long)__double_as_longlong(key));
+        }
+    }
+}
+
+// lowest index among a target's candidates that reach its smallest key
+__global__ void refcos_fold_idx_kernel(const uint32_t *__restrict__ hdr2, const uint2 *__restrict__ pairs,
+                                       const double *__restrict__ keys, const unsigned long long *__restrict__ bestKey,
+                                       uint32_t *__restrict__ bestIdx)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= hdr2[0])
+        return;
+    const uint2 pr = pairs[k];
+    if ((unsigned long long)__double_as_longlong(keys[k]) == bestKey[pr.y])
+        atomicMin(&bestIdx[pr.y], pr.x);
+}
+
+__global__ void refcos_fold_out_kernel(const unsigned long long *__restrict__ bestKey, const uint32_t *__restrict__ bestIdx,
+                                       uint32_t nTgt, uint32_t indexBase, uint32_t *__restrict__ outIdx,
+                                       double *__restrict__ outCost)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nTgt)
+        return;
+    const bool won = bestIdx[t] != 0xffffffffu;          // something beat the fold start (0, 2.0), src/sound.rs:361-367
+    outIdx[t] = (won ? bestIdx[t] : 0u) + indexBase;
+    if (outCost)
+        outCost[t] = won ? __longlong_as_double((long long)bestKey[t]) : 2.0;
+}
+
+__global__ void refcos_init_kernel(unsigned long long *thr, unsigned long long *bestKey, uint32_t *bestIdx, uint32_t nTgt,
+                                   uint32_t *hdr1, uint32_t *hdr2)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < nTgt) {
+        thr[t] = kInfBitsU;
+        bestKey[t] = 0x4000000000000000ull;              // 2.0: only smaller keys enter
+        bestIdx[t] = 0xffffffffu;
+    }
+    if (t == 0) {
+        hdr1[0] = hdr1[1] = 0;
+        hdr2[0] = hdr2[1] = 0;
+    }
+}
+
+}  // namespace
+
+bool refcos_mfma_supported(const ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt)
+{
+    static const bool off = getenv("SSYM_REFCOS_MFMA") && atoi(getenv("SSYM_REFCOS_MFMA")) == 0;
+    if (off || ctx->metric != SSYM_METRIC_REFCOS || src.dim != tgt.dim)
+        return false;
+    // small problems: the exact tile kernel is one launch and already fast; long segments: the error constant
+    // (3 L + 16) u must stay far below 1
+    const uint64_t maxLen = (uint64_t)std::min(src.max_frames, tgt.max_frames) * src.dim;
+    return (uint64_t)src.n * tgt.n >= 65536 && maxLen <= (1u << 24);
+}
+
+size_t refcos_list_capacity(uint32_t n_src, uint32_t n_tgt)
+{
+    const uint64_t tiles = (n_src + kMT - 1) / kMT;
+    // a tile lists about one pair per target column while thresholds are still loose
+    return (size_t)std::min<uint64_t>((uint64_t)n_src * n_tgt, std::max<uint64_t>(4ull * tiles * n_tgt + 65536, 1u << 20));
+}
+
+// The filtered search.  Everything is enqueued; *overflow_dev_hdr receives the device header of list 1 ({wanted,
+// overflow}) so that the caller can look at it after its synchronisation and fall back to the exact tile kernel.
+int32_t launch_refcos_match_mfma(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, const double *dist_dev,
+                                 uint32_t index_base, uint32_t *out_idx_dev, double *out_cost_dev,
+                                 const uint32_t **list1_hdr, const uint32_t **list2_hdr)
+{
+    const uint32_t N = src.n, M = tgt.n;
+    hipStream_t st = ctx->stream;
+    const size_t cap = refcos_list_capacity(N, M);
+    int32_t rc = ensure(ctx, ctx->cand, 4 * sizeof(uint32_t) + sizeof(PairEntry) * cap);
+    if (rc == SSYM_OK)
+        rc = ensure(ctx, ctx->cand2, 4 * sizeof(uint32_t) + sizeof(uint2) * cap);
+    if (rc == SSYM_OK)
+        rc = ensure(ctx, ctx->cand_cost, sizeof(double) * cap);
+    if (rc == SSYM_OK)
+        rc = ensure(ctx, ctx->tmin, sizeof(unsigned long long) * M);
+    if (rc == SSYM_OK)
+        rc = ensure(ctx, ctx->best, (sizeof(unsigned long long) + sizeof(uint32_t)) * (size_t)M + 16);
+    if (rc != SSYM_OK)
+        return rc;
+    uint32_t *hdr1 = (uint32_t *)ctx->cand.ptr;
+    PairEntry *list1 = (PairEntry *)(hdr1 + 4);
+    uint32_t *hdr2 = (uint32_t *)ctx->cand2.ptr;
+    uint2 *pairs = (uint2 *)(hdr2 + 4);
+    unsigned long long *thr = (unsigned long long *)ctx->tmin.ptr;
+    unsigned long long *bestKey = (unsigned long long *)ctx->best.ptr;
+    uint32_t *bestIdx = (uint32_t *)(bestKey + M);
+    double *keys = (double *)ctx->cand_cost.ptr;
+
+    refcos_init_kernel<<<(M + 255) / 256, 256, 0, st>>>(thr, bestKey, bestIdx, M, hdr1, hdr2);
+    dim3 grid((M + kNT - 1) / kNT, (N + kMT - 1) / kMT);
+    refcos_mfma_kernel<<<grid, 256, 0, st>>>(src.raw, src.off, src.norm, tgt.raw, tgt.off, tgt.norm, N, M, src.dim,
+                                             dist_dev, 1.0, thr, hdr1, list1, (uint32_t)cap, nullptr);
+    SSYM_HIP_CHECK(ctx, hipGetLastError());
+    SSYM_HIP_CHECK(ctx, hipEventRecord(ctx->ev[1], st));          // main kernel | selection, exact keys, fold
+    const unsigned keepBlocks = (unsigned)std::min<size_t>((cap + 255) / 256, 65535u * 16u);
+    refcos_keep_kernel<<<keepBlocks, 256, 0, st>>>(hdr1, list1, (uint32_t)cap, thr, hdr2, pairs);
+    refcos_pairs_kernel<<<std::min<unsigned>((unsigned)((cap + 31) / 32), (unsigned)ctx->num_cus * 16), 256, 0, st>>>(
+        src.raw, src.off, src.norm, tgt.raw, tgt.off, tgt.norm, src.dim, dist_dev, 1.0, hdr2, pairs, keys, bestKey);
+    refcos_fold_idx_kernel<<<keepBlocks, 256, 0, st>>>(hdr2, pairs, keys, bestKey, bestIdx);
+    refcos_fold_out_kernel<<<(M + 255) / 256, 256, 0, st>>>(bestKey, bestIdx, M, index_base, out_idx_dev, out_cost_dev);
+    SSYM_HIP_CHECK(ctx, hipGetLastError());
+    *list1_hdr = hdr1;
+    *list2_hdr = hdr2;
+    return SSYM_OK;
+}
+
+// ssym_pair_matrix(exact = 2): the similarities the matrix pipe's dots give (FMA chains; within the bound above of the
+// reference's), for tests and for looking at the filter
+int32_t launch_refcos_mfma_sims(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, double *sims)
+{
+    const uint32_t N = src.n, M = tgt.n;
+    hipStream_t st = ctx->stream;
+    const size_t cap = 1024;
+    int32_t rc = ensure(ctx, ctx->cand, 4 * sizeof(uint32_t) + sizeof(PairEntry) * cap);
+    if (rc == SSYM_OK)
+        rc = ensure(ctx, ctx->cand2, 4 * sizeof(uint32_t));
+    if (rc == SSYM_OK)
+        rc = ensure(ctx, ctx->tmin, sizeof(unsigned long long) * M);
+    if (rc == SSYM_OK)
+        rc = ensure(ctx, ctx->best, (sizeof(unsigned long long) + sizeof(uint32_t)) * (size_t)M + 16);
+    if (rc != SSYM_OK)
+        return rc;
+    uint32_t *hdr1 = (uint32_t *)ctx->cand.ptr;
+    unsigned long long *bestKey = (unsigned long long *)ctx->best.ptr;
+    refcos_init_kernel<<<(M + 255) / 256, 256, 0, st>>>((unsigned long long *)ctx->tmin.ptr, bestKey, (uint32_t *)(bestKey + M), M,
+                                                       hdr1, (uint32_t *)ctx->cand2.ptr);
+    dim3 grid((M + kNT - 1) / kNT, (N + kMT - 1) / kMT);
+    refcos_mfma_kernel<<<grid, 256, 0, st>>>(src.raw, src.off, src.norm, tgt.raw, tgt.off, tgt.norm, N, M, src.dim, nullptr,
+                                             1.0, (unsigned long long *)ctx->tmin.ptr, hdr1, (PairEntry *)(hdr1 + 4),
+                                             (uint32_t)cap, sims);
+    SSYM_HIP_CHECK(ctx, hipGetLastError());
+    return SSYM_OK;
+}
+
+}  // namespace ssym

@@ -331,6 +331,12 @@ int32_t launch_refcos_match_few(ssym_ctx *ctx, const SegmentSet &src, const void
 bool dtw_few_supported(const ssym_ctx *ctx, const SegmentSet &src, const uint64_t *q_off, uint32_t n_queries);
 int32_t launch_dtw_match_few(ssym_ctx *ctx, const SegmentSet &src, const void *queries, const uint64_t *q_off,
                              uint32_t n_queries, const double *distances, double *out_cost, uint32_t *out_idx);
+// refcos_mfma.hip: the search through the f64 matrix pipe (filter) + exact keys of the candidates; bit-exact results
+bool refcos_mfma_supported(const ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt);
+int32_t launch_refcos_match_mfma(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, const double *dist_dev,
+                                 uint32_t index_base, uint32_t *out_idx_dev, double *out_cost_dev,
+                                 const uint32_t **list1_hdr, const uint32_t **list2_hdr);
+int32_t launch_refcos_mfma_sims(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, double *sims);
 char *stage_take(ssym_ctx *ctx, size_t bytes);      // pack.hip: room in the call's pinned window (NULL: none)
 int32_t launch_refcos_argmin(ssym_ctx *ctx, uint32_t n_src, uint32_t n_tgt, const double *sims,
                              const double *dist_dev, uint32_t index_base, uint32_t k_top,

@@ -126,3 +126,81 @@ def test_dtw_exact_pipelined_wave_giving_up_is_redone_not_dropped(oracle, monkey
     assert np.array_equal(idx3, idx) and np.array_equal(cost3, cost)
     monkeypatch.delenv("SSYM_EXACT_PIPE_FORCE_GIVEUP")
     e.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# refcos through the f64 matrix pipe (csrc/refcos_mfma.hip): filter + exact keys, results bit for bit
+# ---------------------------------------------------------------------------------------------
+def _refcos_sets(seed, n, m, fmin, fmax, dim, scale=0.05):
+    from soundsym_amd import synth
+    rs, rt = synth.make_ragged(n, m, fmin, fmax, dim, seed)
+    src = [s.astype(np.float64) * scale for s in rs]
+    tgt = [t.astype(np.float64) * scale for t in rt]
+    return src, tgt
+
+
+@pytest.mark.parametrize("n,m,fmin,fmax,dim", [(300, 260, 1, 40, 12), (520, 130, 20, 21, 13), (256, 256, 100, 128, 12)])
+def test_refcos_mfma_search_is_bit_exact(oracle, n, m, fmin, fmax, dim):
+    src, tgt = _refcos_sets(0x5EED7000 + n, n, m, fmin, fmax, dim)
+    # planted near-duplicates, exact duplicates (ties: lowest index wins), an all-zero and an empty segment
+    tgt[0] = src[7].copy()
+    src[11] = src[7].copy()
+    tgt[1] = src[3][: max(1, src[3].shape[0] // 2)].copy()
+    src[5] = np.zeros_like(src[5])
+    tgt[2] = np.zeros_like(tgt[2])
+    src[9] = np.zeros((0, dim))
+    tgt[3] = np.zeros((0, dim))
+    sf, so = pack_segments(src, dim)
+    tf, to = pack_segments(tgt, dim)
+    e = Engine(metric="refcos", dtype="f64")
+    d, q = e.dictionary(sf, so, dim), e.queries(tf, to, dim)
+    idx, val = e.match(d, q)
+    tm = e.timings()
+    assert tm["used_filter"] == 1, "the search should have gone through the matrix pipe"
+    want_idx, want_val = oracle.refcos_match_all(sf, so, tf, to, dim)
+    assert np.array_equal(idx, want_idx) and np.array_equal(val, want_val)
+    assert tm["n_refined"] < 8 * m + 64, tm            # a handful of candidates per target, not the matrix
+    # per-target distances (morph_to, src/sound.rs:440-446), NaN distance included
+    dist = np.linspace(-0.5, 1.5, m)
+    dist[4] = np.nan
+    idx2, val2 = e.match(d, q, distance=dist)
+    w_idx, w_val = oracle.refcos_match_all(sf, so, tf, to, dim, distance=dist)
+    assert np.array_equal(idx2, w_idx) and np.array_equal(val2, w_val)
+    # the filter's similarities against the bit-exact ones, inside the bound the kernel uses
+    exact = e.pair_matrix(d, q)
+    filt = nat_pair_matrix(e, d, q, 2)
+    na = np.array([float((s.reshape(-1) ** 2).sum()) for s in src])
+    nb = np.array([float((t.reshape(-1) ** 2).sum()) for t in tgt])
+    L = np.minimum.outer(np.array([s.size for s in src]), np.array([t.size for t in tgt]))
+    nrm = np.outer(na, nb)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        bound = (3 * L + 16) * 2.0 ** -53 * 1.02 * np.sqrt(nrm) / nrm + 4 * 2.0 ** -53 * np.abs(exact)
+    ok = nrm > 0
+    assert np.array_equal(np.isnan(filt[~ok]), np.isnan(exact[~ok]))
+    assert (np.abs(filt[ok] - exact[ok]) <= bound[ok]).all(), float((np.abs(filt[ok] - exact[ok]) / bound[ok]).max())
+    e.close()
+
+
+def nat_pair_matrix(e, d, q, mode):
+    import ctypes
+    from soundsym_amd import _native as nat
+    out = np.zeros((d.n, q.n), dtype=np.float64)
+    nat.check(nat.lib().ssym_pair_matrix(e.ctx, d.ptr, q.ptr, mode, out.ctypes.data), e.ctx)
+    return out
+
+
+def test_refcos_mfma_overflowing_list_falls_back_to_the_exact_kernel(oracle):
+    # every source identical: every pair ties, list 1 cannot hold them -> the exact tile kernel takes the call
+    dim, f, n, m = 12, 6, 2200, 600
+    rng = np.random.default_rng(3)
+    one = rng.standard_normal((f, dim)) * 0.1
+    src = [one.copy() for _ in range(n)]
+    tgt = [rng.standard_normal((f, dim)) * 0.1 for _ in range(m)]
+    sf, so = pack_segments(src, dim)
+    tf, to = pack_segments(tgt, dim)
+    e = Engine(metric="refcos", dtype="f64")
+    idx, val = e.match(e.dictionary(sf, so, dim), e.queries(tf, to, dim))
+    assert e.timings()["used_filter"] == 0
+    want_idx, want_val = oracle.refcos_match_all(sf, so, tf, to, dim)
+    assert np.array_equal(idx, want_idx) and np.array_equal(val, want_val)
+    e.close()
