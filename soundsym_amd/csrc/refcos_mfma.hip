@@ -84,7 +84,7 @@ __device__ __forceinline__ void refcos_key_interval(double dotm, double sa, doub
 // ---------------------------------------------------------------------------------------------------------
 // 128 x 128 pairs per workgroup, four waves of 64 x 64, K in chunks of 16 elements staged through LDS
 // (zero beyond each segment's length).  MFMA operand layout (gfx950 v_mfma_f64_16x16x4_f64): A[m][k] in lane
-// m + 16 k, B[k][n] in lane n + 16 k, D[4 (lane / 16) + i][lane % 16] in register pair i.  The summation index
+// m + 16 k, B[k][n] in lane n + 16 k, D[4 i + lane / 16][lane % 16] in register pair i (measured: not the f32 forms' 4 (lane / 16) + i).  The summation index
 // is free to permute: lane group g = lane / 16 takes elements 4 g .. 4 g + 3 of a chunk, one per MFMA step, so
 // a lane's four A (or B) values of a chunk are 32 contiguous bytes of LDS -- two ds_read_b128.
 __global__ __launch_bounds__(256, 2) void refcos_mfma_kernel(
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void refcos_mfma_kernel(
     }
 
     // ---- epilogue: dots -> key intervals -> thresholds and list 1 ------------------------------------------
-    // D[4 (lane / 16) + i][lane % 16]: this lane holds, per block pair (a, b), source rows 4 lg + i and target column lr
+    // D[4 i + lane / 16][lane % 16]: this lane holds, per block pair (a, b), source rows 4 i + lg and target column lr
     const double INF = __builtin_inf();
 #pragma unroll 1
     for (int b = 0; b < 4; ++b) {
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void refcos_mfma_kernel(
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int row = wm * 64 + a * 16 + 4 * lg + i;
+                const int row = wm * 64 + a * 16 + 4 * i + lg;
                 const uint32_t s = sTile + row;
                 double klo = INF, khi = INF;
                 if (s < nSrc && t < nTgt) {
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void refcos_mfma_kernel(
                         const uint32_t pos = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
                         if (pos < cap) {
                             PairEntry e;
-                            e.s = sTile + wm * 64 + a * 16 + 4 * lg + i;
+                            e.s = sTile + wm * 64 + a * 16 + 4 * i + lg;
                             e.t = t;
                             e.key_lo = klos[a][i];
                             list[pos] = e;
