@@ -115,20 +115,21 @@ def secondary_metrics(device: int) -> dict:
         kms.append(e.timings()["main_ms"])
     dt = (time.perf_counter() - t0) / 5
     k_s = float(np.mean(kms)) * 1e-3
-    # algorithmic work of the reference's metric: 2 L f64 flops per pair, L = F d (one multiply and
-    # one add per element of the common prefix, separately rounded as src/sound.rs:31 / rulinalg's dot does);
-    # f64 vector peak: 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz = 39.3 T separately rounded ops/s (tools/f64_rate.hip:
-    # v_mul_f64 / v_add_f64 issue in 4 cycles per wave on MI355X)
+    # algorithmic work of the reference's metric: 2 L f64 flops per pair, L = F d, as one zero-padded GEMM.
+    # The dominant kernel runs it on v_mfma_f64_16x16x4_f64: 64 cycles per instruction on MI355X (measured:
+    # profiles/r02_refcos_1gpu.md), i.e. 2048 flops / 64 cycles x 1024 SIMDs x 2.4 GHz = 78.6 TFLOP/s, the f64 matrix peak
     flops = 2.0 * n * n * f * dd
+    tmr = e.timings()
     out["refcos"] = {"value": n * n / dt, "unit": "segment-pairs/s", "ms_per_step": dt * 1e3,
                      "workload": f"{n}x{n} segments, {f} frames x {dd} dims, f64, reference metric "
                                  "(cosine_sim + at_distance, bit-exact)",
-                     "phase_ms": {k: round(float(v), 3) for k, v in e.timings().items() if k.endswith("_ms")},
-                     "roofline": {"bound": "f64 valu", "kernel": "refcos main kernel(s)", "kernel_ms": k_s * 1e3,
-                                  "achieved": flops / k_s / 1e12, "peak": 39.3, "unit": "T f64 op/s",
-                                  "frac": flops / k_s / 1e12 / 39.3,
-                                  "model": "2*F*d separately rounded f64 operations per pair (SURVEY.md 8(d)) over the "
-                                           "main kernel time; peak = f64 vector issue rate (one op per lane per 4 cycles)"}}
+                     "phase_ms": {k: round(float(v), 3) for k, v in tmr.items() if k.endswith("_ms")},
+                     "through_matrix_pipe": bool(tmr["used_filter"]), "pairs_rescored_exactly": int(tmr["n_refined"]),
+                     "roofline": {"bound": "mfma", "kernel": "refcos_mfma_kernel" if tmr["used_filter"] else "refcos_sims_kernel",
+                                  "kernel_ms": k_s * 1e3, "achieved": flops / k_s / 1e12, "peak": 78.6, "unit": "TFLOP/s",
+                                  "frac": flops / k_s / 1e12 / 78.6,
+                                  "model": "2*F*d f64 flops per pair (SURVEY.md 8(d)) over the main kernel's time (HIP events); "
+                                           "peak = dense f64 MFMA rate, v_mfma_f64_16x16x4_f64 at 64 cycles per instruction"}}
     dist_ = np.linspace(0.2, 1.2, 256)
     e.chain(d, g.targets[0].astype(np.float64).reshape(-1), dist_[:2])
     t0 = time.perf_counter()

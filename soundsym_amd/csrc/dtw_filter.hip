@@ -189,7 +189,9 @@ static void launch_one(hipStream_t st, const SegmentSet &src, const SegmentSet &
 {
     // sources of at most 16 frames (one tile, one pass): three waves per SIMD, see filter_ring() -- 11 %
     // faster there; at 32 frames the gain was within 3 % and cost spills
-    constexpr int OCC = NT == 1 ? 3 : 2;
+    // NT == 8 (experiment, SSYM_FILTER_NT8=1): the whole 128-row column of a pair in ONE wave's registers, one wave per
+    // SIMD with the whole register file -- no second pass, no hand-off rows
+    constexpr int OCC = NT == 1 ? 3 : NT == 8 ? 1 : 2;
     gridBlocks = gridBlocks / 2 * OCC;
     const int nTgtGroups = (int)tgt.n_pad / 32;
     const int nTasks = nSrcPairs * nTgtGroups;            // one wave's 64 pairs each
@@ -398,8 +400,11 @@ int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
         SSYM_LAUNCH(1, 1, rowsPad - 16, bound[0], bound[1], 0)
         SSYM_LAUNCH(2, 1, rowsPad - 32, bound[1], bound[2], 1)
         SSYM_LAUNCH(3, 1, rowsPad - 48, bound[2], bound[3], 2)
+        static const bool nt8 = getenv("SSYM_FILTER_NT8") != nullptr;
         if (shape.nt == 2) {
             SSYM_LAUNCH(2, shape.rb, 0, bound[3], nPairs, 3)
+        } else if (nt8 && shape.rb == 2 && !abandon) {
+            SSYM_LAUNCH(8, 1, 0, bound[3], nPairs, 3)
         } else {
             SSYM_LAUNCH(4, shape.rb, 0, bound[3], nPairs, 3)
         }

@@ -52,6 +52,10 @@ __global__ void segment_norm_kernel(const double *__restrict__ raw, const uint64
         memo = __dadd_rn(__dmul_rn(v, v), memo);
     }
     norm[s] = memo;
+    // what the matrix-pipe filter of the refcos search needs per segment (refcos_mfma.hip), once instead of per pair:
+    // an upper bound of sqrt(norm) and the correctly rounded 1 / norm
+    norm[n + s] = sqrt(memo) * (1.0 + 4.5e-16);
+    norm[2 * (size_t)n + s] = 1.0 / memo;
 }
 
 // dtw: per-segment frame count and max squared frame norm, and the set-wide max |value|
@@ -236,7 +240,7 @@ static int32_t build_derived(ssym_ctx *ctx, SegmentSet &set)
     }
 
     if (ctx->metric == SSYM_METRIC_REFCOS) {
-        { int32_t rca = dev_alloc(ctx, (void **)&set.norm, sizeof(double) * n); if (rca != SSYM_OK) return rca; }
+        { int32_t rca = dev_alloc(ctx, (void **)&set.norm, sizeof(double) * 3 * (size_t)n); if (rca != SSYM_OK) return rca; }
         segment_norm_kernel<<<(n + 63) / 64, 64, 0, st>>>(set.raw, set.off, n, dim, set.norm);
         SSYM_HIP_CHECK(ctx, hipGetLastError());
     } else if (ctx->pack_light && !set.is_source) {

@@ -20,14 +20,18 @@
 // Cauchy-Schwarz, norm = the reference's sum of squares):
 //   any floating-point evaluation of the L-term dot, products rounded or fused, sums in any order, stays
 //   within gamma_n P of the exact dot with n = number of roundings on a path <= 2 L + 8; the reference's
-//   value and the matrix pipe's therefore differ by at most E = (3 L + 16) u * 1.02 * sqrt(na nb) (+ a floor
-//   for products that underflow).  nrm = fl(na * nb) is the reference's own (norms are computed in its order at
-//   pack time), division and subtraction are correctly rounded, hence monotone:
-//       dot in [lo, hi]  =>  fl(fl(dot / nrm) - d) in [fl(fl(lo / nrm) - d), fl(fl(hi / nrm) - d)],
-//   and |.| of an interval is an interval.  Instead of two divisions per pair the kernel multiplies by
-//   fl(1/na) fl(1/nb), which is 1/nrm up to 4.1 u, and moves both ends outwards by 8 u.  nrm = 0 or NaN: the
-//   reference's key is NaN or +inf and never wins (src/sound.rs:362) -- the pair is dropped; anything else
-//   that is not finite: the pair is kept with [0, +inf].
+//   value d_ref and the matrix pipe's d_m therefore differ by at most E = (3 L + 16) u * 1.02 * sqrt(na nb).
+//   The reference's key is k = |fl(fl(d_ref / nrm) - dist)| with nrm = fl(na nb) (the norms are computed in its
+//   order at pack time); each of its two roundings moves the value by at most u times its magnitude, so with
+//   x = d_ref / nrm:  | k - |x - dist| | <= (2 |x| + |dist|) u (1 + u).  The kernel evaluates
+//   s = fl(d_m * fl(ia * ib)) with ia = fl(1 / na), ib = fl(1 / nb), which is d_m / nrm up to 5.2 u, and
+//   z = fl(s - dist); collecting the terms,
+//       | k - |z| |  <=  R := 1.0001 E ia ib + 9 u (|s| + |dist|) + 1e-290
+//   (the last term covers the subnormal range, where relative bounds stop holding), so
+//       key_lo = (|z| - R)(1 - 4u) or 0,   key_hi = (|z| + R)(1 + 4u).
+//   nrm = 0 or NaN: the reference's key is NaN or +inf and never wins (src/sound.rs:362) -- the pair is dropped;
+//   anything else that is not finite, or norms whose product leaves 1e-280 .. 1e280 (1 / nrm or single products
+//   would leave the normal range, where these relative bounds hold): the pair is kept with [0, +inf].
 // The true first minimum w has key(w) <= key(s) <= key_hi(s) for all s, so key_lo(w) <= threshold: it is
 // among the candidates, and the fold over exact keys in index order returns what the reference returns.
 #include "ssym_internal.hpp"
@@ -53,32 +57,31 @@ struct PairEntry {                  // list 1: a pair that may hold its target's
     double key_lo;
 };
 
-__device__ __forceinline__ void refcos_key_interval(double dotm, double sa, double sb, double ia, double ib,
-                                                    double nrm, unsigned len, double d, double &klo, double &khi)
+struct RowInfo {                   // per segment of the tile, written to LDS once the main loop is done with it
+    double sq;                      // >= sqrt(norm)
+    double inv;                     // fl(1 / norm)
+    double norm;
+    double dist;                    // targets: the distance |sim - dist| is taken to
+};
+
+__device__ __forceinline__ void refcos_key_interval(double dotm, double sasb, double inv, double nrm, double cL, double d,
+                                                    double &klo, double &khi)
 {
     const double INF = __builtin_inf();
-    if (d != d || nrm != nrm || nrm == 0.0) {      // the reference's key is NaN or +inf: never a winner (src/sound.rs:362)
-        klo = khi = INF;
-        return;
-    }
     const double u = 1.1102230246251565e-16;
-    const double E = ((3.0 * (double)len + 16.0) * u * 1.02) * (sa * sb) + (double)len * 1e-300;
-    const double slackDot = fabs(dotm) * 4.0 * u;                 // roundings of the two additions below
-    const double lo = dotm - E - slackDot, hi = dotm + E + slackDot;
-    const double inv = ia * ib;                                    // 1 / nrm within 4.1 u
-    double slo = lo * inv, shi = hi * inv;
-    const bool tiny = !(fabs(slo) > 1e-290) || !(fabs(shi) > 1e-290);   // (near the subnormals the 8 u steps do not move)
-    slo -= fabs(slo) * 8.0 * u;                                    // outwards: below fl(lo / nrm), above fl(hi / nrm)
-    shi += fabs(shi) * 8.0 * u;
-    const double ylo = slo - d, yhi = shi - d;                     // correctly rounded, monotone
-    const bool fin = inv > 0.0 && inv < INF && E < INF && dotm == dotm && ylo == ylo && yhi == yhi && !tiny;
-    if (!fin) {                                                    // anything odd: the pair stays in, bounds nothing
+    const double s = dotm * inv;
+    const double z = fabs(s - d);
+    const double R = 1.0001 * (cL * sasb) * inv + 9.0 * u * (fabs(s) + fabs(d)) + 1e-290;
+    klo = z > R ? (z - R) * (1.0 - 4.0 * u) : 0.0;
+    khi = (z + R) * (1.0 + 4.0 * u);
+    // something is not finite (or NaN), or the norms are so large or small that 1 / nrm or single products leave the
+    // normal range (the relative bounds above need it): the pair stays in, bounds nothing
+    if (!(khi < INF) || !(inv > 1e-280 && inv < 1e280)) {
         klo = 0.0;
         khi = INF;
-        return;
     }
-    klo = ylo > 0.0 ? ylo : (yhi < 0.0 ? -yhi : 0.0);
-    khi = fmax(fabs(ylo), fabs(yhi));
+    if (nrm == 0.0 || nrm != nrm || d != d)        // the reference's key is NaN or +inf: never a winner
+        klo = khi = INF;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -90,8 +93,8 @@ __device__ __forceinline__ void refcos_key_interval(double dotm, double sa, doub
 __global__ __launch_bounds__(256, 2) void refcos_mfma_kernel(
     const double *__restrict__ srcRaw, const uint64_t *__restrict__ srcOff, const double *__restrict__ srcNorm,
     const double *__restrict__ tgtRaw, const uint64_t *__restrict__ tgtOff, const double *__restrict__ tgtNorm,
-    uint32_t nSrc, uint32_t nTgt, uint32_t dim, const double *__restrict__ dist, double defaultDist,
-    unsigned long long *__restrict__ thr /* [nTgt] smallest key_hi so far (bits) */,
+    uint32_t nSrc, uint32_t nTgt, uint32_t dim, unsigned long long srcVals, unsigned long long tgtVals,
+    const double *__restrict__ dist, double defaultDist, unsigned long long *__restrict__ thr /* [nTgt] smallest key_hi so far (bits) */,
     uint32_t *__restrict__ hdr /* {count, overflow} */, PairEntry *__restrict__ list, uint32_t cap,
     double *__restrict__ dotOut /* nullable: [nSrc][nTgt] sims from the matrix pipe's dots (ssym_pair_matrix, exact = 2) */)
 {
@@ -128,24 +131,43 @@ __global__ __launch_bounds__(256, 2) void refcos_mfma_kernel(
     const unsigned kMax = min(sMaxLen[0], sMaxLen[1]);    // beyond it every product of the tile is zero
     const unsigned nChunks = (kMax + kKC - 1) / kKC;
 
-    // staging: thread -> (row = tid / 16 + 16 p, element tid % 16) for p = 0..7, both sides: 16 doubles in flight
+    // staging: thread -> (row = tid / 16 + 16 p, element tid % 16) for p = 0..7, both sides: 16 doubles in flight.
+    // The rows of a tile are consecutive segments, i.e. one contiguous stretch of the value buffer: a row's start is
+    // a 32-bit offset from the tile's first value, kept in registers with the row's length, so that the sixteen loads
+    // of a chunk issue back to back (with the lengths and starts looked up in LDS in front of every load, and a branch
+    // around it, the fetch phase cost ~40 % of a chunk's MFMA time).  Beyond a row's end the tile's first value is
+    // read instead and zeroed afterwards.
     const int se = tid & 15, sr = tid >> 4;
+    const unsigned long long tbA = min(sBase[0], srcVals - 1), tbB = min(sBase[kMT], tgtVals - 1);
+    const double *const tileA = srcRaw + tbA, *const tileB = tgtRaw + tbB;
+    unsigned relA[8], relB[8], lenA[8], lenB[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int row = sr + 16 * p;
+        lenA[p] = sLen[row];
+        lenB[p] = sLen[kMT + row];
+        relA[p] = lenA[p] ? (unsigned)(sBase[row] - tbA) : 0u;
+        relB[p] = lenB[p] ? (unsigned)(sBase[kMT + row] - tbB) : 0u;
+    }
     double stA[8], stB[8];
-    auto fetch = [&](unsigned c) {
-        const unsigned e = c * kKC + se;
+    unsigned stE = 0;
+    auto fetch = [&](unsigned c) {                         // loads only: nothing here waits for them
+        stE = c * kKC + se;
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
-            const int row = sr + 16 * p;
-            stA[p] = e < sLen[row] ? srcRaw[sBase[row] + e] : 0.0;
-            stB[p] = e < sLen[kMT + row] ? tgtRaw[sBase[kMT + row] + e] : 0.0;
+            stA[p] = tileA[stE < lenA[p] ? relA[p] + stE : 0u];
+            stB[p] = tileB[stE < lenB[p] ? relB[p] + stE : 0u];
         }
     };
     auto stash = [&](int buf) {
 #pragma unroll
+        for (int p = 0; p < 8; ++p)                        // (the values count as used whatever the selects below say:
+            asm volatile("" : "+v"(stA[p]), "+v"(stB[p])); //  the loads stay unconditional, no branch around them)
+#pragma unroll
         for (int p = 0; p < 8; ++p) {
             const int row = sr + 16 * p;
-            sA[buf][row * kLdk + se] = stA[p];
-            sB[buf][row * kLdk + se] = stB[p];
+            sA[buf][row * kLdk + se] = stE < lenA[p] ? stA[p] : 0.0;
+            sB[buf][row * kLdk + se] = stE < lenB[p] ? stB[p] : 0.0;
         }
     };
 
@@ -164,8 +186,10 @@ __global__ __launch_bounds__(256, 2) void refcos_mfma_kernel(
     __syncthreads();
     for (unsigned c = 0; c < nChunks; ++c) {
         const int buf = (int)(c & 1);
+#ifndef SSYM_RM_NOFETCH   // (tools only: without it the MFMAs run on the first chunk over and over)
         if (c + 1 < nChunks)
             fetch(c + 1);                                  // global loads in flight under the MFMAs
+#endif
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {                   // two MFMA steps per 16-byte LDS read
             double av[4][2], bv[4][2];                     // [block][step]
@@ -184,22 +208,43 @@ __global__ __launch_bounds__(256, 2) void refcos_mfma_kernel(
                     for (int b = 0; b < 4; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a][st], bv[b][st], acc[a][b], 0, 0, 0);
         }
+#ifndef SSYM_RM_NOFETCH
         if (c + 1 < nChunks)
             stash(buf ^ 1);
         __syncthreads();
+#endif
     }
 
+#ifdef SSYM_RM_NOEPI      // tools only: the main loop alone (results meaningless)
+    if (acc[0][0][0] == 12345.678 && hdr[0] == 77)
+        thr[0] = (unsigned long long)__double_as_longlong(acc[1][2][3] + acc[3][3][0] + acc[2][1][1]);
+    return;
+#endif
     // ---- epilogue: dots -> key intervals -> thresholds and list 1 ------------------------------------------
     // D[4 i + lane / 16][lane % 16]: this lane holds, per block pair (a, b), source rows 4 i + lg and target column lr
+    // per-segment values of the tile into LDS (the staging buffers are free now: the loop's last barrier is behind us)
+    RowInfo *const info = reinterpret_cast<RowInfo *>(&sA[0][0]);          // [kMT + kNT] x 32 bytes = 8 KB
+    {
+        const bool isS = tid < kMT;
+        const uint32_t g = isS ? sTile + tid : tTile + (tid - kMT);
+        const uint32_t n = isS ? nSrc : nTgt;
+        const double *nr = isS ? srcNorm : tgtNorm;
+        RowInfo r;
+        r.norm = g < n ? nr[g] : 0.0;
+        r.sq = g < n ? nr[n + g] : 0.0;
+        r.inv = g < n ? nr[2 * (size_t)n + g] : 0.0;
+        r.dist = (!isS && dist && g < n) ? dist[g] : defaultDist;
+        info[tid] = r;
+    }
+    __syncthreads();
     const double INF = __builtin_inf();
+    const double cUnit = 1.1102230246251565e-16 * 1.02;
 #pragma unroll 1
     for (int b = 0; b < 4; ++b) {
         const int col = wn * 64 + b * 16 + lr;
         const uint32_t t = tTile + col;
         const unsigned lb = sLen[kMT + col];
-        const double nb = t < nTgt ? tgtNorm[t] : 0.0;
-        const double sb = sqrt(nb) * (1.0 + 4.5e-16), ib = 1.0 / nb;
-        const double d = (dist && t < nTgt) ? dist[t] : defaultDist;
+        const RowInfo ci = info[kMT + col];
         double klos[4][4];
         double colMin = INF;
 #pragma unroll
@@ -210,12 +255,13 @@ __global__ __launch_bounds__(256, 2) void refcos_mfma_kernel(
                 const uint32_t s = sTile + row;
                 double klo = INF, khi = INF;
                 if (s < nSrc && t < nTgt) {
+                    const RowInfo ri = info[row];
                     const unsigned la = sLen[row];
-                    const double na = srcNorm[s];
-                    const double nrm = __dmul_rn(na, nb);                 // src/sound.rs:30
                     const unsigned len = la < lb ? la : lb;               // src/sound.rs:24-28
+                    const double nrm = __dmul_rn(ri.norm, ci.norm);       // src/sound.rs:30
                     const double dv = b == 0 ? acc[a][0][i] : b == 1 ? acc[a][1][i] : b == 2 ? acc[a][2][i] : acc[a][3][i];
-                    refcos_key_interval(dv, sqrt(na) * (1.0 + 4.5e-16), sb, 1.0 / na, ib, nrm, len, d, klo, khi);
+                    refcos_key_interval(dv, ri.sq * ci.sq, ri.inv * ci.inv, nrm, (3.0 * (double)len + 16.0) * cUnit, ci.dist,
+                                        klo, khi);
                     if (dotOut)
                         dotOut[(size_t)s * nTgt + t] = __ddiv_rn(dv, nrm);
                 }
@@ -384,7 +430,9 @@ bool refcos_mfma_supported(const ssym_ctx *ctx, const SegmentSet &src, const Seg
     // small problems: the exact tile kernel is one launch and already fast; long segments: the error constant
     // (3 L + 16) u must stay far below 1
     const uint64_t maxLen = (uint64_t)std::min(src.max_frames, tgt.max_frames) * src.dim;
-    return (uint64_t)src.n * tgt.n >= 65536 && maxLen <= (1u << 24);
+    // (its staging reads a tile's first value in place of the values beyond a segment's end: there must be one; a tile's
+    //  128 segments are addressed by 32-bit offsets)
+    return (uint64_t)src.n * tgt.n >= 65536 && maxLen <= (1u << 20) && src.total_frames > 0 && tgt.total_frames > 0;
 }
 
 size_t refcos_list_capacity(uint32_t n_src, uint32_t n_tgt)
@@ -426,7 +474,9 @@ int32_t launch_refcos_match_mfma(ssym_ctx *ctx, const SegmentSet &src, const Seg
     refcos_init_kernel<<<(M + 255) / 256, 256, 0, st>>>(thr, bestKey, bestIdx, M, hdr1, hdr2);
     dim3 grid((M + kNT - 1) / kNT, (N + kMT - 1) / kMT);
     refcos_mfma_kernel<<<grid, 256, 0, st>>>(src.raw, src.off, src.norm, tgt.raw, tgt.off, tgt.norm, N, M, src.dim,
-                                             dist_dev, 1.0, thr, hdr1, list1, (uint32_t)cap, nullptr);
+                                             (unsigned long long)src.total_frames * src.dim,
+                                             (unsigned long long)tgt.total_frames * tgt.dim, dist_dev, 1.0, thr, hdr1, list1,
+                                             (uint32_t)cap, nullptr);
     SSYM_HIP_CHECK(ctx, hipGetLastError());
     SSYM_HIP_CHECK(ctx, hipEventRecord(ctx->ev[1], st));          // main kernel | selection, exact keys, fold
     const unsigned keepBlocks = (unsigned)std::min<size_t>((cap + 255) / 256, 65535u * 16u);
@@ -462,7 +512,9 @@ int32_t launch_refcos_mfma_sims(ssym_ctx *ctx, const SegmentSet &src, const Segm
     refcos_init_kernel<<<(M + 255) / 256, 256, 0, st>>>((unsigned long long *)ctx->tmin.ptr, bestKey, (uint32_t *)(bestKey + M), M,
                                                        hdr1, (uint32_t *)ctx->cand2.ptr);
     dim3 grid((M + kNT - 1) / kNT, (N + kMT - 1) / kMT);
-    refcos_mfma_kernel<<<grid, 256, 0, st>>>(src.raw, src.off, src.norm, tgt.raw, tgt.off, tgt.norm, N, M, src.dim, nullptr,
+    refcos_mfma_kernel<<<grid, 256, 0, st>>>(src.raw, src.off, src.norm, tgt.raw, tgt.off, tgt.norm, N, M, src.dim,
+                                             (unsigned long long)src.total_frames * src.dim,
+                                             (unsigned long long)tgt.total_frames * tgt.dim, nullptr,
                                              1.0, (unsigned long long *)ctx->tmin.ptr, hdr1, (PairEntry *)(hdr1 + 4),
                                              (uint32_t)cap, sims);
     SSYM_HIP_CHECK(ctx, hipGetLastError());

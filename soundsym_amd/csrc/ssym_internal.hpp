@@ -52,7 +52,7 @@ struct SegmentSet {
     uint64_t total_frames = 0;
     uint32_t max_frames = 0;
     // refcos
-    double *norm = nullptr;         // [n]  norm(me) of src/sound.rs:35-38 per segment
+    double *norm = nullptr;         // [n] norm(me) of src/sound.rs:35-38 per segment, then [n] sqrt(norm) rounded up, [n] 1 / norm
     // dtw filter
     int32_t *len = nullptr;         // [n_pad] frames per segment (0 for padding segments)
     float *max_sqnorm = nullptr;    // [n_pad] max_f ||frame||^2 per segment (f32, rounded up)
