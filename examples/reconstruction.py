@@ -23,7 +23,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from soundsym_amd import Engine, Sound, SoundDictionary, SoundSequence  # noqa: E402
 from soundsym_amd.api import HOP  # noqa: E402
-from soundsym_amd.features import frame_features  # noqa: E402
+from soundsym_amd.api import frame_features  # noqa: E402
 from soundsym_amd.io import audacity_labels_to_timestamps, read_wav, write_wav32  # noqa: E402
 
 

@@ -39,6 +39,23 @@ def default_engine() -> Engine:
     return _default_engine
 
 
+def frame_features(samples, sample_rate: float, ncoeffs: int = NCOEFFS, engine: Optional[Engine] = None,
+                   pad_tail: bool = True) -> np.ndarray:
+    """analyze_mfccs (src/sound.rs:215-242) for a whole sound on the GPU (`ssym_mfcc`; this package's own MFCC
+    definition -- the reference's lives in un-vendored crates, PARITY UNPINNED): [n_frames * ncoeffs] f64,
+    frame-major.  pad_tail=True gives len(samples) // 256 frames (the tail windows read zeros past the end), which is
+    what the segment arithmetic of SoundDictionary::add_segments (`seg / HOP * NCOEFFS` values per segment,
+    src/sound.rs:335) expects of a parent sound; pad_tail=False keeps full windows only."""
+    e = engine or default_engine()
+    return e.mfcc(samples, sample_rate, ncoeffs, pad_tail=pad_tail).reshape(-1)
+
+
+def _round_half_away(x: float) -> int:
+    """f64::round (src/sound.rs:422-423): half away from zero -- Python's round() is half to even."""
+    import math
+    return int(math.floor(x + 0.5)) if x >= 0 else -int(math.floor(-x + 0.5))
+
+
 class Sound:
     """Samples + flat frame-major features of one sound (src/sound.rs:73-82)."""
 
@@ -118,7 +135,9 @@ class SoundDictionary:
         self.sounds: List[Sound] = []         # `pub sounds: Vec<Arc<Sound>>`
         self._engine = engine
         self._resident = None
-        self._resident_n = -1
+        self._resident_key = None
+        self._samples_res = None
+        self._samples_key = None
 
     # constructors -----------------------------------------------------------------------------
     @staticmethod
@@ -169,25 +188,49 @@ class SoundDictionary:
     def _dim(self) -> int:
         return self.sounds[0].ncoeffs
 
+    def _content_key(self):
+        """What `sounds` holds now.  `sounds` is the public, mutable list (`pub sounds`): entries may have been
+        replaced, reordered, or popped and pushed since the last pack, so the length alone does not say.  A Sound's
+        arrays are fixed at construction, hence the OBJECTS are the content; the key keeps them alive, so an
+        identity cannot be reused by a new Sound while the key is held."""
+        return list(self.sounds)
+
+    @staticmethod
+    def _same(key, now) -> bool:
+        return key is not None and len(key) == len(now) and all(a is b for a, b in zip(key, now))
+
+    def invalidate(self) -> None:
+        """Drop the GPU copies (they are rebuilt on the next query)."""
+        if self._resident is not None:
+            self._resident.close()
+        self._resident = self._resident_key = None
+        if self._samples_res is not None:
+            self._samples_res.close()
+        self._samples_res = self._samples_key = None
+
     def resident(self):
         """Pack the dictionary's features once per content change, not per query."""
-        if self._resident is None or self._resident_n != len(self.sounds):
+        key = self._content_key()
+        if self._resident is None or not self._same(self._resident_key, key):
             if self._resident is not None:
                 self._resident.close()
             dim = self._dim() if self.sounds else NCOEFFS
             flat, off = pack_segments([s.mfccs() for s in self.sounds], dim, self.engine.np_dtype)
             self._resident = self.engine.dictionary(flat, off, dim)
-            self._resident_n = len(self.sounds)
+            self._resident_key = key
         return self._resident
 
     def resident_samples(self):
         """The sounds' samples on the GPU, for the reconstruction tail (ssym_samples_create)."""
-        if getattr(self, "_samples_res", None) is None or self._samples_n != len(self.sounds):
+        key = self._content_key()
+        if self._samples_res is None or not self._same(self._samples_key, key):
+            if self._samples_res is not None:
+                self._samples_res.close()
             smp = [s.samples() for s in self.sounds]
             off = np.concatenate([[0], np.cumsum([x.size for x in smp])]).astype(np.uint64)
             flat = np.concatenate(smp) if smp else np.zeros(0)
             self._samples_res = self.engine.samples(flat, off)
-            self._samples_n = len(self.sounds)
+            self._samples_key = key
         return self._samples_res
 
     # queries ------------------------------------------------------------------------------------
@@ -253,7 +296,10 @@ class SoundSequence:
         out = []
         smp, rate = sound.samples(), sound.sample_rate()
         for start, end, label in timestamps:
-            a, b = int(round(start * rate)), int(round(end * rate))
+            a, b = _round_half_away(start * rate), _round_half_away(end * rate)      # f64::round, :422-423
+            if a < 0 or b + 1 > smp.size or a > b + 1:
+                # the reference slices `samples[start_sample..end_sample + 1]` (:424) and panics out of range
+                raise IndexError(f"timestamp ({start}, {end}) -> samples [{a}, {b}] outside the sound's {smp.size} samples")
             out.append(Sound.from_samples(smp[a:b + 1].copy(), rate, None, label, sound.ncoeffs, engine=engine))
         return SoundSequence(out)
 

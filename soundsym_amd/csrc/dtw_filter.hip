@@ -149,7 +149,15 @@ static double common_scale(const SegmentSet &src, const SegmentSet &tgt)
     const double sq = std::max(src.max_sqnorm_all, tgt.max_sqnorm_all);
     while (e > -200 && sq * std::ldexp(1.0, 2 * e) * 1.01 >= 65000.0)
         --e;
-    return std::ldexp(1.0, e);
+    const double ideal = std::ldexp(1.0, e);
+    // The dictionary's records are cached on the scale they were built with.  A batch of quieter targets would ask
+    // for a larger scale and the next louder one for the smaller again -- a full pass over the dictionary per call,
+    // its time depending on the previous call.  A smaller scale than the ideal one is always admissible (|s v| < 64
+    // and the norm bound only get easier; the error model prices the scale through 1 / s^2), so the cached scale is
+    // kept while it is at most 16 times smaller than the ideal: four bits of the f16 pieces' headroom, not a rebuild.
+    if (src.rec && src.rec_scale > 0.0 && src.rec_scale <= ideal && src.rec_scale * 16.0 >= ideal)
+        return src.rec_scale;
+    return ideal;
 }
 
 static int32_t ensure_records(ssym_ctx *ctx, const SegmentSet &set, double scale, uint32_t slots, int lead)

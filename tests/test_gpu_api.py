@@ -125,7 +125,7 @@ def _run_and_check_reconstruction(mod, oracle, ps, pt, po, labels, extra):
     """One run of examples/reconstruction.py, then the same segmentation and features through the oracle."""
     from oracle.oracle import pack_segments
     from soundsym_amd import io as sio
-    from soundsym_amd.features import frame_features
+    from soundsym_amd.api import frame_features
     got = mod.main(["-s", ps, "-t", pt, "-o", po] + extra)
     s_smp, srate = sio.read_wav(ps)
     t_smp, rate = sio.read_wav(pt)
@@ -252,8 +252,9 @@ def test_sound_from_path_write_file_from_timestamps(tmp_path, oracle):
     assert d.match_sound(d.sounds[1]) is d.sounds[1]
     # timestamps: inclusive end sample (src/sound.rs:422-424)
     seq = api.SoundSequence.from_timestamps(back, [(0.0, 0.25, "a"), (0.25, 0.6, None)], engine=eng)
-    n0 = int(round(0.25 * rate)) + 1
-    assert [x.samples().size for x in seq.sounds()] == [n0, int(round(0.6 * rate)) - int(round(0.25 * rate)) + 1]
+    rnd = api._round_half_away          # f64::round: 0.25 * 22050 = 5512.5 -> 5513 (Python's round gives 5512)
+    n0 = rnd(0.25 * rate) + 1
+    assert [x.samples().size for x in seq.sounds()] == [n0, rnd(0.6 * rate) - rnd(0.25 * rate) + 1]
     assert seq.sounds()[0].name == "a" and np.array_equal(seq.sounds()[0].samples(), back.samples()[:n0])
     assert seq.sounds()[0].num_frames() == (n0 - 1024) // 256 + 1
     eng.close()
@@ -290,3 +291,22 @@ def test_matcher_example_end_to_end(tmp_path, oracle):
     want = np.trunc(np.clip(d2[:5000] * 32767.0 * 4.0 ** a.max_power(), -32768, 32767)).astype(np.int16)
     assert np.array_equal(pcm[:5000], want)
     assert not pcm[8000 + 6000:].any()                                               # zero padding past the match
+
+
+def test_dictionary_swap_in_place_is_seen_by_the_gpu_copy():
+    # `pub sounds` is mutable: replacing an entry keeps the length, the resident features must follow
+    rng = np.random.default_rng(17)
+    mk = lambda: Sound(np.zeros(8), 1.0, rng.standard_normal(5 * NCOEFFS) * 0.1)
+    d = SoundDictionary.new()
+    d.sounds += [mk() for _ in range(6)]
+    probe = Sound(np.zeros(8), 1.0, d.sounds[3].mfccs().copy())
+    assert d.match_sound(probe) is d.sounds[3] or True          # (refcos self-match is a property, not a guarantee)
+    first = d.match_sound(probe)
+    newcomer = mk()
+    old = d.sounds[d.sounds.index(first)]
+    d.sounds[d.sounds.index(first)] = newcomer                  # same length, other content
+    again = d.match_sound(probe)
+    assert again is not old, "the GPU copy was not rebuilt after an in-place replacement"
+    want = SoundDictionary.new()
+    want.sounds += list(d.sounds)
+    assert again is want.match_sound(probe)

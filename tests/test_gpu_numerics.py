@@ -204,3 +204,31 @@ def test_refcos_mfma_overflowing_list_falls_back_to_the_exact_kernel(oracle):
     want_idx, want_val = oracle.refcos_match_all(sf, so, tf, to, dim)
     assert np.array_equal(idx, want_idx) and np.array_equal(val, want_val)
     e.close()
+
+
+def test_dtw_alternating_amplitudes_reuse_the_dictionary_records(oracle):
+    # quiet and loud target batches in turn: the dictionary's f16 records are built for the loud scale once and
+    # then kept (a smaller common scale is always admissible); results stay exact either way
+    from soundsym_amd import synth
+    g = synth.make_grid(96, 40, 24, 13, 0x5EED0B00)
+    so = np.arange(97, dtype=np.uint64) * 24
+    to = np.arange(41, dtype=np.uint64) * 24
+    e = Engine(metric="dtw", dtype="f32")
+    d = e.dictionary(g.sources.reshape(-1), so, 13)
+    for rep in range(3):
+        for amp in (1.0, 6.0):
+            tgt = (g.targets * np.float32(amp)).astype(np.float32)
+            q = e.queries(tgt.reshape(-1), to, 13)
+            idx, cost = e.match(d, q)
+            assert e.timings()["used_filter"] == 1
+            want_idx, want_cost = oracle.dtw_match_all(g.sources.reshape(-1).astype(np.float64), so,
+                                                       tgt.reshape(-1).astype(np.float64), to, 13)
+            assert np.array_equal(idx, want_idx) and np.allclose(cost, want_cost, rtol=EXACT_RTOL, atol=0)
+            filt = e.pair_matrix(d, q, exact=False)
+            _, _, mat = oracle.dtw_match_all(g.sources.reshape(-1).astype(np.float64), so,
+                                             tgt.reshape(-1).astype(np.float64), to, 13, want_matrix=True)
+            # the bound with the scale actually in use: at most 16 times smaller than this batch's ideal scale
+            bound, s = _worst_case_bound(g.sources, tgt, 13, 24, 24)
+            assert (np.abs(filt - mat) <= 16 * bound + 1e-5 * mat).all()
+            q.close()
+    e.close()

@@ -149,3 +149,29 @@ def test_source_sharding_world2_gloo(oracle):
     want, _ = oracle.dtw_match_all(sf, so, tf, to, 13)
     assert np.array_equal(merged, want)
     assert merged[0] == 2     # the duplicate at index 5 (other shard) must not win
+
+
+def test_from_timestamps_rounds_half_away_from_zero_and_checks_the_range():
+    # f64::round (src/sound.rs:422-423) is half away from zero; the slice [a, b] inclusive panics out of range (:424)
+    from soundsym_amd.api import _round_half_away, Sound, SoundSequence
+    assert [_round_half_away(x) for x in (0.5, 1.5, 2.5, 2.4999, -0.5, -1.5)] == [1, 2, 3, 2, -1, -2]
+    assert [round(x) for x in (0.5, 1.5, 2.5)] == [0, 2, 2]            # what Python's round would have given
+    s = Sound(np.arange(100, dtype=np.float64), 10.0, np.zeros(12))
+    import pytest
+    with pytest.raises(IndexError):
+        SoundSequence.from_timestamps(s, [(0.0, 10.0, "past the end")])   # samples [0, 100] of 100
+
+
+def test_dictionary_residency_follows_the_content_not_the_length():
+    # `sounds` is public and mutable: swapping an entry in place keeps the length but must invalidate the GPU copy
+    from soundsym_amd.api import Sound, SoundDictionary
+    d = SoundDictionary(engine=object())
+    a, b, c = (Sound(np.zeros(4), 1.0, np.full(12, v)) for v in (1.0, 2.0, 3.0))
+    d.sounds += [a, b]
+    key = d._content_key()
+    assert d._same(key, d._content_key())
+    d.sounds[1] = c
+    assert not d._same(key, d._content_key())
+    d.sounds[1] = b
+    d.sounds.reverse()
+    assert not d._same(key, d._content_key())
