@@ -207,10 +207,14 @@ __global__ __launch_bounds__(256, 2) void refcos_mfma_kernel(
 #pragma unroll
                     for (int b = 0; b < 4; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a][st], bv[b][st], acc[a][b], 0, 0, 0);
+#ifndef SSYM_RM_NOFETCH
+            // the next chunk goes to LDS in the shadow of the MFMAs (its loads were issued 32 MFMAs ago; the other
+            // buffer has not been read since the barrier that ended the previous chunk)
+            if (hf == 0 && c + 1 < nChunks)
+                stash(buf ^ 1);
+#endif
         }
 #ifndef SSYM_RM_NOFETCH
-        if (c + 1 < nChunks)
-            stash(buf ^ 1);
         __syncthreads();
 #endif
     }

@@ -180,3 +180,49 @@ def test_topk_and_chain_random_shapes(oracle, case):
     assert np.array_equal(ci, wi)
     assert np.array_equal(cv, wv) if metric == "refcos" else np.allclose(cv, wv, rtol=1e-12, atol=0)
     e.close()
+
+
+_N_REFCOS_MFMA = max(16, _N_DTW // 6)
+
+
+@pytest.mark.parametrize("case", range(_N_REFCOS_MFMA))
+def test_refcos_matrix_pipe_random_shapes(oracle, case):
+    """The refcos search through the f64 matrix pipe (csrc/refcos_mfma.hip; from 65 536 pairs up): random ragged sets,
+    empty / all-zero segments, duplicates and prefixes, per-target distances, amplitudes from 1e-150 to 1e150 (the
+    interval's guards for norms that leave the normal range), f32 inputs -- index and value bit for bit the oracle's."""
+    st = synth.Stream(0x5EED3000 + case)
+    dim = int([1, 5, 12, 13, 40][st.integers(1, 5)[0]])
+    hi = int([3, 20, 60, 130][st.integers(1, 4)[0]])
+    if dim == 40:
+        hi = min(hi, 60)
+    n = int(260 + st.integers(1, 400)[0])
+    m = int((65536 + n - 1) // n + st.integers(1, 120)[0])
+    scale = float([1e-150, 1e-3, 0.05, 1.0, 300.0, 1e150][st.integers(1, 6)[0]])
+    dtype = "f64" if scale in (1e-150, 1e150) else ["f32", "f64"][int(st.integers(1, 2)[0])]
+    src = _ragged(st, n, 0, hi, dim, scale)
+    tgt = _ragged(st, m, 0, hi, dim, scale)
+    for k in range(0, min(m, 40), 3):                    # planted copies, prefixes, scaled copies
+        j = int(st.integers(1, n)[0])
+        if src[j].shape[0]:
+            tgt[k] = [src[j].copy(), src[j][: max(1, src[j].shape[0] // 2)].copy(), src[j] * 0.5][k % 3]
+    src[n // 2] = src[1].copy()                          # duplicates: the lower index wins
+    src[n // 3] = np.zeros_like(src[n // 3])             # norm 0: never a winner
+    tgt[m // 2] = np.zeros_like(tgt[m // 2])
+    npdt = np.float32 if dtype == "f32" else np.float64
+    sf, so = pack_segments(src, dim, npdt)
+    tf, to = pack_segments(tgt, dim, npdt)
+    use_dist = bool(st.integers(1, 3)[0] == 0)
+    dist = None
+    if use_dist:
+        dist = np.asarray(st.normal(m)) * 0.7 + 0.5
+        dist[0] = 0.0
+    e = Engine(metric="refcos", dtype=dtype)
+    d, q = e.dictionary(sf, so, dim), e.queries(tf, to, dim)
+    idx, val = e.match(d, q, distance=dist)
+    tm = e.timings()
+    want_idx, want_val = oracle.refcos_match_all(sf.astype(np.float64), so, tf.astype(np.float64), to, dim, distance=dist)
+    info = dict(case=case, dim=dim, hi=hi, n=n, m=m, scale=scale, dtype=dtype, dist=use_dist, mfma=tm["used_filter"],
+                refined=tm["n_refined"])
+    assert np.array_equal(idx, want_idx), info
+    assert np.array_equal(val, want_val), info
+    e.close()
