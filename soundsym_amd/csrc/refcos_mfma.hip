@@ -90,6 +90,7 @@ __device__ __forceinline__ void refcos_key_interval(double dotm, double sasb, do
 // m + 16 k, B[k][n] in lane n + 16 k, D[4 i + lane / 16][lane % 16] in register pair i (measured: not the f32 forms' 4 (lane / 16) + i).  The summation index
 // is free to permute: lane group g = lane / 16 takes elements 4 g .. 4 g + 3 of a chunk, one per MFMA step, so
 // a lane's four A (or B) values of a chunk are 32 contiguous bytes of LDS -- two ds_read_b128.
+template <bool WRITE_SIMS>
 __global__ __launch_bounds__(256, 2) void refcos_mfma_kernel(
     const double *__restrict__ srcRaw, const uint64_t *__restrict__ srcOff, const double *__restrict__ srcNorm,
     const double *__restrict__ tgtRaw, const uint64_t *__restrict__ tgtOff, const double *__restrict__ tgtNorm,
@@ -219,10 +220,18 @@ __global__ __launch_bounds__(256, 2) void refcos_mfma_kernel(
 #endif
     }
 
-#ifdef SSYM_RM_NOEPI      // tools only: the main loop alone (results meaningless)
-    if (acc[0][0][0] == 12345.678 && hdr[0] == 77)
-        thr[0] = (unsigned long long)__double_as_longlong(acc[1][2][3] + acc[3][3][0] + acc[2][1][1]);
-    return;
+#ifdef SSYM_RM_NOEPI      // tools only: the main loop alone, every accumulator kept alive (results meaningless)
+    {
+        double4v t = acc[0][0];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                t += acc[a][b];
+        if (t[0] + t[1] + t[2] + t[3] == 12345.678 && hdr[0] == 77)
+            thr[0] = 1;
+        return;
+    }
 #endif
     // ---- epilogue: dots -> key intervals -> thresholds and list 1 ------------------------------------------
     // D[4 i + lane / 16][lane % 16]: this lane holds, per block pair (a, b), source rows 4 i + lg and target column lr
@@ -243,7 +252,8 @@ __global__ __launch_bounds__(256, 2) void refcos_mfma_kernel(
     __syncthreads();
     const double INF = __builtin_inf();
     const double cUnit = 1.1102230246251565e-16 * 1.02;
-#pragma unroll 1
+    // (segments beyond the sets' ends carry norm 0 in `info`: their pairs come out as [+inf, +inf] without a test)
+#pragma unroll
     for (int b = 0; b < 4; ++b) {
         const int col = wn * 64 + b * 16 + lr;
         const uint32_t t = tTile + col;
@@ -256,18 +266,17 @@ __global__ __launch_bounds__(256, 2) void refcos_mfma_kernel(
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = wm * 64 + a * 16 + 4 * i + lg;
-                const uint32_t s = sTile + row;
-                double klo = INF, khi = INF;
-                if (s < nSrc && t < nTgt) {
-                    const RowInfo ri = info[row];
-                    const unsigned la = sLen[row];
-                    const unsigned len = la < lb ? la : lb;               // src/sound.rs:24-28
-                    const double nrm = __dmul_rn(ri.norm, ci.norm);       // src/sound.rs:30
-                    const double dv = b == 0 ? acc[a][0][i] : b == 1 ? acc[a][1][i] : b == 2 ? acc[a][2][i] : acc[a][3][i];
-                    refcos_key_interval(dv, ri.sq * ci.sq, ri.inv * ci.inv, nrm, (3.0 * (double)len + 16.0) * cUnit, ci.dist,
-                                        klo, khi);
-                    if (dotOut)
-                        dotOut[(size_t)s * nTgt + t] = __ddiv_rn(dv, nrm);
+                const RowInfo ri = info[row];
+                const unsigned la = sLen[row];
+                const unsigned len = la < lb ? la : lb;                   // src/sound.rs:24-28
+                const double nrm = __dmul_rn(ri.norm, ci.norm);           // src/sound.rs:30
+                double klo, khi;
+                refcos_key_interval(acc[a][b][i], ri.sq * ci.sq, ri.inv * ci.inv, nrm, (3.0 * (double)len + 16.0) * cUnit,
+                                    ci.dist, klo, khi);
+                if (WRITE_SIMS) {
+                    const uint32_t s = sTile + row;
+                    if (s < nSrc && t < nTgt)
+                        dotOut[(size_t)s * nTgt + t] = __ddiv_rn(acc[a][b][i], nrm);
                 }
                 klos[a][i] = klo;
                 colMin = fmin(colMin, khi);
@@ -280,20 +289,31 @@ __global__ __launch_bounds__(256, 2) void refcos_mfma_kernel(
             seen = atomicMin(&thr[t], (unsigned long long)__double_as_longlong(colMin));    // keys are >= 0: bits order like values
         seen = __shfl(seen, lr);
         const double cur = fmin(colMin, __longlong_as_double((long long)seen));
-        // list 1: pairs the threshold known so far does not exclude (the final threshold can only be smaller)
+        // list 1: pairs the threshold known so far does not exclude (the final threshold can only be smaller).  A lane
+        // counts its own, one prefix sum over the wave and ONE atomic reserve the room, then every lane writes its entries.
+        unsigned mine = 0;
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bool real = klos[a][i] <= cur && klos[a][i] < INF;
-                const unsigned long long mask = __ballot(real);
-                if (mask) {
-                    uint32_t base = 0;
-                    if (lane == 0)
-                        base = atomicAdd(&hdr[0], (uint32_t)__popcll(mask));
-                    base = __shfl(base, 0);
-                    if (real) {
-                        const uint32_t pos = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            for (int i = 0; i < 4; ++i)
+                mine += (klos[a][i] <= cur && klos[a][i] < INF) ? 1u : 0u;
+        unsigned incl = mine;                                             // inclusive prefix sum over the 64 lanes
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned up = __shfl_up(incl, o);
+            incl += lane >= o ? up : 0u;
+        }
+        const unsigned total = __shfl(incl, 63);
+        if (total) {                                                      // wave-uniform
+            uint32_t base = 0;
+            if (lane == 0)
+                base = atomicAdd(&hdr[0], total);
+            uint32_t pos = __shfl(base, 0) + incl - mine;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (klos[a][i] <= cur && klos[a][i] < INF) {
                         if (pos < cap) {
                             PairEntry e;
                             e.s = sTile + wm * 64 + a * 16 + 4 * i + lg;
@@ -303,9 +323,9 @@ __global__ __launch_bounds__(256, 2) void refcos_mfma_kernel(
                         } else {
                             hdr[1] = 1;
                         }
+                        ++pos;
                     }
-                }
-            }
+        }
     }
 }
 
@@ -477,7 +497,7 @@ int32_t launch_refcos_match_mfma(ssym_ctx *ctx, const SegmentSet &src, const Seg
 
     refcos_init_kernel<<<(M + 255) / 256, 256, 0, st>>>(thr, bestKey, bestIdx, M, hdr1, hdr2);
     dim3 grid((M + kNT - 1) / kNT, (N + kMT - 1) / kMT);
-    refcos_mfma_kernel<<<grid, 256, 0, st>>>(src.raw, src.off, src.norm, tgt.raw, tgt.off, tgt.norm, N, M, src.dim,
+    refcos_mfma_kernel<false><<<grid, 256, 0, st>>>(src.raw, src.off, src.norm, tgt.raw, tgt.off, tgt.norm, N, M, src.dim,
                                              (unsigned long long)src.total_frames * src.dim,
                                              (unsigned long long)tgt.total_frames * tgt.dim, dist_dev, 1.0, thr, hdr1, list1,
                                              (uint32_t)cap, nullptr);
@@ -516,7 +536,7 @@ int32_t launch_refcos_mfma_sims(ssym_ctx *ctx, const SegmentSet &src, const Segm
     refcos_init_kernel<<<(M + 255) / 256, 256, 0, st>>>((unsigned long long *)ctx->tmin.ptr, bestKey, (uint32_t *)(bestKey + M), M,
                                                        hdr1, (uint32_t *)ctx->cand2.ptr);
     dim3 grid((M + kNT - 1) / kNT, (N + kMT - 1) / kMT);
-    refcos_mfma_kernel<<<grid, 256, 0, st>>>(src.raw, src.off, src.norm, tgt.raw, tgt.off, tgt.norm, N, M, src.dim,
+    refcos_mfma_kernel<true><<<grid, 256, 0, st>>>(src.raw, src.off, src.norm, tgt.raw, tgt.off, tgt.norm, N, M, src.dim,
                                              (unsigned long long)src.total_frames * src.dim,
                                              (unsigned long long)tgt.total_frames * tgt.dim, nullptr,
                                              1.0, (unsigned long long *)ctx->tmin.ptr, hdr1, (PairEntry *)(hdr1 + 4),
