@@ -380,7 +380,7 @@ int32_t pack_segments(ssym_ctx *ctx, SegmentSet &set, const void *feats, bool fe
         return SSYM_E_INVALID;
     }
     set.raw_capacity_vals = std::max<size_t>(vals, 1);
-    { int32_t rca = dev_alloc(ctx, (void **)&set.raw, set.raw_capacity_vals * sizeof(double)); if (rca != SSYM_OK) return rca; }
+    { int32_t rca = dev_alloc(ctx, (void **)&set.raw, (set.raw_capacity_vals + kRawTailPad) * sizeof(double)); if (rca != SSYM_OK) return rca; }
     if (vals > 0) {
         size_t esz = ctx->dtype == SSYM_DTYPE_F64 ? sizeof(double) : sizeof(float);
         const char *base = (const char *)feats + (size_t)frame_offsets[0] * dim * esz;
@@ -410,7 +410,7 @@ int32_t append_segments(ssym_ctx *ctx, SegmentSet &set, const void *feats,
     if (old_vals + add_vals > set.raw_capacity_vals) {
         size_t cap = std::max(old_vals + add_vals, set.raw_capacity_vals * 2);
         double *nraw = nullptr;
-        { int32_t rca = dev_alloc(ctx, (void **)&nraw, cap * sizeof(double)); if (rca != SSYM_OK) return rca; }
+        { int32_t rca = dev_alloc(ctx, (void **)&nraw, (cap + kRawTailPad) * sizeof(double)); if (rca != SSYM_OK) return rca; }
         if (old_vals)
             SSYM_HIP_CHECK(ctx, hipMemcpyAsync(nraw, set.raw, old_vals * sizeof(double),
                                                hipMemcpyDeviceToDevice, ctx->stream));

@@ -84,159 +84,20 @@ __device__ __forceinline__ void refcos_key_interval(double dotm, double sasb, do
         klo = khi = INF;
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// 128 x 128 pairs per workgroup, four waves of 64 x 64, K in chunks of 16 elements staged through LDS
-// (zero beyond each segment's length).  MFMA operand layout (gfx950 v_mfma_f64_16x16x4_f64): A[m][k] in lane
-// m + 16 k, B[k][n] in lane n + 16 k, D[4 i + lane / 16][lane % 16] in register pair i (measured: not the f32 forms' 4 (lane / 16) + i).  The summation index
-// is free to permute: lane group g = lane / 16 takes elements 4 g .. 4 g + 3 of a chunk, one per MFMA step, so
-// a lane's four A (or B) values of a chunk are 32 contiguous bytes of LDS -- two ds_read_b128.
+// Epilogue shared by the two main loops: dots -> key intervals -> thresholds and list 1.  `info` is LDS no wave reads
+// any more (the caller has passed its last barrier); sLen holds the tile's segment lengths.
 template <bool WRITE_SIMS>
-__global__ __launch_bounds__(256, 2) void refcos_mfma_kernel(
-    const double *__restrict__ srcRaw, const uint64_t *__restrict__ srcOff, const double *__restrict__ srcNorm,
-    const double *__restrict__ tgtRaw, const uint64_t *__restrict__ tgtOff, const double *__restrict__ tgtNorm,
-    uint32_t nSrc, uint32_t nTgt, uint32_t dim, unsigned long long srcVals, unsigned long long tgtVals,
-    const double *__restrict__ dist, double defaultDist, unsigned long long *__restrict__ thr /* [nTgt] smallest key_hi so far (bits) */,
-    uint32_t *__restrict__ hdr /* {count, overflow} */, PairEntry *__restrict__ list, uint32_t cap,
-    double *__restrict__ dotOut /* nullable: [nSrc][nTgt] sims from the matrix pipe's dots (ssym_pair_matrix, exact = 2) */)
+__device__ __forceinline__ void refcos_epilogue(double4v (&acc)[4][4], RowInfo *info, const unsigned *sLen, int tid, int lane,
+                                                int wm, int wn, int lr, int lg, uint32_t sTile, uint32_t tTile, uint32_t nSrc,
+                                                uint32_t nTgt, const double *__restrict__ srcNorm,
+                                                const double *__restrict__ tgtNorm, const double *__restrict__ dist,
+                                                double defaultDist, unsigned long long *__restrict__ thr,
+                                                uint32_t *__restrict__ hdr, PairEntry *__restrict__ list, uint32_t cap,
+                                                double *__restrict__ dotOut)
 {
-    __shared__ __attribute__((aligned(16))) double sA[2][kMT * kLdk];
-    __shared__ __attribute__((aligned(16))) double sB[2][kNT * kLdk];
-    __shared__ unsigned long long sBase[kMT + kNT];
-    __shared__ unsigned sLen[kMT + kNT];
-    __shared__ unsigned sMaxLen[2];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;              // this wave's 64 x 64 quadrant
-    const uint32_t sTile = blockIdx.y * kMT, tTile = blockIdx.x * kNT;
-
-    if (tid < 2)
-        sMaxLen[tid] = 0;
-    __syncthreads();
-    {
-        const bool isS = tid < kMT;
-        const uint32_t g = isS ? sTile + tid : tTile + (tid - kMT);
-        const uint32_t n = isS ? nSrc : nTgt;
-        const uint64_t *off = isS ? srcOff : tgtOff;
-        unsigned long long base = 0;
-        unsigned len = 0;
-        if (g < n) {
-            base = off[g] * dim;
-            len = (unsigned)((off[g + 1] - off[g]) * dim);
-        }
-        sBase[tid] = base;
-        sLen[tid] = len;
-        atomicMax(&sMaxLen[isS ? 0 : 1], len);
-    }
-    __syncthreads();
-    const unsigned kMax = min(sMaxLen[0], sMaxLen[1]);    // beyond it every product of the tile is zero
-    const unsigned nChunks = (kMax + kKC - 1) / kKC;
-
-    // staging: thread -> (row = tid / 16 + 16 p, element tid % 16) for p = 0..7, both sides: 16 doubles in flight.
-    // The rows of a tile are consecutive segments, i.e. one contiguous stretch of the value buffer: a row's start is
-    // a 32-bit offset from the tile's first value, kept in registers with the row's length, so that the sixteen loads
-    // of a chunk issue back to back (with the lengths and starts looked up in LDS in front of every load, and a branch
-    // around it, the fetch phase cost ~40 % of a chunk's MFMA time).  Beyond a row's end the tile's first value is
-    // read instead and zeroed afterwards.
-    const int se = tid & 15, sr = tid >> 4;
-    const unsigned long long tbA = min(sBase[0], srcVals - 1), tbB = min(sBase[kMT], tgtVals - 1);
-    const double *const tileA = srcRaw + tbA, *const tileB = tgtRaw + tbB;
-    unsigned relA[8], relB[8], lenA[8], lenB[8];
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-        const int row = sr + 16 * p;
-        lenA[p] = sLen[row];
-        lenB[p] = sLen[kMT + row];
-        relA[p] = lenA[p] ? (unsigned)(sBase[row] - tbA) : 0u;
-        relB[p] = lenB[p] ? (unsigned)(sBase[kMT + row] - tbB) : 0u;
-    }
-    double stA[8], stB[8];
-    unsigned stE = 0;
-    auto fetch = [&](unsigned c) {                         // loads only: nothing here waits for them
-        stE = c * kKC + se;
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            stA[p] = tileA[stE < lenA[p] ? relA[p] + stE : 0u];
-            stB[p] = tileB[stE < lenB[p] ? relB[p] + stE : 0u];
-        }
-    };
-    auto stash = [&](int buf) {
-#pragma unroll
-        for (int p = 0; p < 8; ++p)                        // (the values count as used whatever the selects below say:
-            asm volatile("" : "+v"(stA[p]), "+v"(stB[p])); //  the loads stay unconditional, no branch around them)
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const int row = sr + 16 * p;
-            sA[buf][row * kLdk + se] = stE < lenA[p] ? stA[p] : 0.0;
-            sB[buf][row * kLdk + se] = stE < lenB[p] ? stB[p] : 0.0;
-        }
-    };
-
-    double4v acc[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-            acc[a][b] = double4v{0.0, 0.0, 0.0, 0.0};
-
-    const int lr = lane & 15, lg = lane >> 4;
-    if (nChunks > 0) {
-        fetch(0);
-        stash(0);
-    }
-    __syncthreads();
-    for (unsigned c = 0; c < nChunks; ++c) {
-        const int buf = (int)(c & 1);
-#ifndef SSYM_RM_NOFETCH   // (tools only: without it the MFMAs run on the first chunk over and over)
-        if (c + 1 < nChunks)
-            fetch(c + 1);                                  // global loads in flight under the MFMAs
-#endif
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {                   // two MFMA steps per 16-byte LDS read
-            double av[4][2], bv[4][2];                     // [block][step]
-#pragma unroll
-            for (int blk = 0; blk < 4; ++blk) {
-                const double2v a2 = *reinterpret_cast<const double2v *>(&sA[buf][(wm * 64 + blk * 16 + lr) * kLdk + 4 * lg + 2 * hf]);
-                const double2v b2 = *reinterpret_cast<const double2v *>(&sB[buf][(wn * 64 + blk * 16 + lr) * kLdk + 4 * lg + 2 * hf]);
-                av[blk][0] = a2[0]; av[blk][1] = a2[1];
-                bv[blk][0] = b2[0]; bv[blk][1] = b2[1];
-            }
-#pragma unroll
-            for (int st = 0; st < 2; ++st)
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-#pragma unroll
-                    for (int b = 0; b < 4; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a][st], bv[b][st], acc[a][b], 0, 0, 0);
-#ifndef SSYM_RM_NOFETCH
-            // the next chunk goes to LDS in the shadow of the MFMAs (its loads were issued 32 MFMAs ago; the other
-            // buffer has not been read since the barrier that ended the previous chunk)
-            if (hf == 0 && c + 1 < nChunks)
-                stash(buf ^ 1);
-#endif
-        }
-#ifndef SSYM_RM_NOFETCH
-        __syncthreads();
-#endif
-    }
-
-#ifdef SSYM_RM_NOEPI      // tools only: the main loop alone, every accumulator kept alive (results meaningless)
-    {
-        double4v t = acc[0][0];
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-                t += acc[a][b];
-        if (t[0] + t[1] + t[2] + t[3] == 12345.678 && hdr[0] == 77)
-            thr[0] = 1;
-        return;
-    }
-#endif
     // ---- epilogue: dots -> key intervals -> thresholds and list 1 ------------------------------------------
     // D[4 i + lane / 16][lane % 16]: this lane holds, per block pair (a, b), source rows 4 i + lg and target column lr
     // per-segment values of the tile into LDS (the staging buffers are free now: the loop's last barrier is behind us)
-    RowInfo *const info = reinterpret_cast<RowInfo *>(&sA[0][0]);          // [kMT + kNT] x 32 bytes = 8 KB
     {
         const bool isS = tid < kMT;
         const uint32_t g = isS ? sTile + tid : tTile + (tid - kMT);
@@ -327,6 +188,166 @@ __global__ __launch_bounds__(256, 2) void refcos_mfma_kernel(
                     }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// 128 x 128 pairs per workgroup, four waves of 64 x 64, K in chunks of 16 elements staged through LDS
+// (zero beyond each segment's length).  MFMA operand layout (gfx950 v_mfma_f64_16x16x4_f64): A[m][k] in lane
+// m + 16 k, B[k][n] in lane n + 16 k, D[4 i + lane / 16][lane % 16] in register pair i (measured: not the f32 forms' 4 (lane / 16) + i).  The summation index
+// is free to permute: lane group g = lane / 16 takes elements 4 g .. 4 g + 3 of a chunk, one per MFMA step, so
+// a lane's four A (or B) values of a chunk are 32 contiguous bytes of LDS -- two ds_read_b128.
+template <bool WRITE_SIMS>
+__global__ __launch_bounds__(256, 2) void refcos_mfma_kernel(
+    const double *__restrict__ srcRaw, const uint64_t *__restrict__ srcOff, const double *__restrict__ srcNorm,
+    const double *__restrict__ tgtRaw, const uint64_t *__restrict__ tgtOff, const double *__restrict__ tgtNorm,
+    uint32_t nSrc, uint32_t nTgt, uint32_t dim, unsigned long long srcVals, unsigned long long tgtVals,
+    const double *__restrict__ dist, double defaultDist, unsigned long long *__restrict__ thr /* [nTgt] smallest key_hi so far (bits) */,
+    uint32_t *__restrict__ hdr /* {count, overflow} */, PairEntry *__restrict__ list, uint32_t cap,
+    double *__restrict__ dotOut /* nullable: [nSrc][nTgt] sims from the matrix pipe's dots (ssym_pair_matrix, exact = 2) */)
+{
+    __shared__ __attribute__((aligned(16))) double sA[2][kMT * kLdk];
+    __shared__ __attribute__((aligned(16))) double sB[2][kNT * kLdk];
+    __shared__ unsigned long long sBase[kMT + kNT];
+    __shared__ unsigned sLen[kMT + kNT];
+    __shared__ unsigned sMaxLen[2];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;              // this wave's 64 x 64 quadrant
+    const uint32_t sTile = blockIdx.y * kMT, tTile = blockIdx.x * kNT;
+
+    if (tid < 2)
+        sMaxLen[tid] = 0;
+    __syncthreads();
+    {
+        const bool isS = tid < kMT;
+        const uint32_t g = isS ? sTile + tid : tTile + (tid - kMT);
+        const uint32_t n = isS ? nSrc : nTgt;
+        const uint64_t *off = isS ? srcOff : tgtOff;
+        unsigned long long base = 0;
+        unsigned len = 0;
+        if (g < n) {
+            base = off[g] * dim;
+            len = (unsigned)((off[g + 1] - off[g]) * dim);
+        }
+        sBase[tid] = base;
+        sLen[tid] = len;
+        atomicMax(&sMaxLen[isS ? 0 : 1], len);
+    }
+    __syncthreads();
+    const unsigned kMax = min(sMaxLen[0], sMaxLen[1]);    // beyond it every product of the tile is zero
+    const unsigned nChunks = (kMax + kKC - 1) / kKC;
+
+    // staging: thread -> (row = tid / 8 + 32 p, elements 2 (tid % 8), + 1) for p = 0..3, both sides: 16 doubles in flight.
+    // The rows of a tile are consecutive segments, i.e. one contiguous stretch of the value buffer: a row's start is
+    // a 32-bit offset from the tile's first value, kept in registers with the row's length, so that the eight loads
+    // of a chunk issue back to back (with the lengths and starts looked up in LDS in front of every load, and a branch
+    // around it, the fetch phase cost ~40 % of a chunk's MFMA time).  Beyond a row's end the tile's first value is
+    // read instead and zeroed afterwards.
+    const int se = 2 * (tid & 7), sr = tid >> 3;          // two elements (16 bytes) per lane, 32 rows per sweep, 4 sweeps
+    const unsigned long long tbA = min(sBase[0], srcVals - 1), tbB = min(sBase[kMT], tgtVals - 1);
+    const double *const tileA = srcRaw + tbA, *const tileB = tgtRaw + tbB;
+    unsigned relA[4], relB[4], lenA[4], lenB[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int row = sr + 32 * p;
+        lenA[p] = sLen[row];
+        lenB[p] = sLen[kMT + row];
+        relA[p] = lenA[p] ? (unsigned)(sBase[row] - tbA) : 0u;
+        relB[p] = lenB[p] ? (unsigned)(sBase[kMT + row] - tbB) : 0u;
+    }
+    // (a 16-byte load may start on a segment's last value: the value behind it is read too and zeroed; the buffers
+    //  carry kRawTailPad doubles behind their end, pack.hip; 8-byte alignment is all a segment's start guarantees)
+    double2v stA[4], stB[4];
+    unsigned stE = 0;
+    auto fetch = [&](unsigned c) {                         // loads only: nothing here waits for them
+        stE = c * kKC + se;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            stA[p] = *reinterpret_cast<const double2v *>(tileA + (stE < lenA[p] ? relA[p] + stE : 0u));
+            stB[p] = *reinterpret_cast<const double2v *>(tileB + (stE < lenB[p] ? relB[p] + stE : 0u));
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)                        // (the values count as used whatever the selects below say:
+            asm volatile("" : "+v"(stA[p]), "+v"(stB[p])); //  the loads stay unconditional, no branch around them)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int row = sr + 32 * p;
+            double2v a = stA[p], b = stB[p];
+            a[0] = stE < lenA[p] ? a[0] : 0.0;
+            a[1] = stE + 1 < lenA[p] ? a[1] : 0.0;
+            b[0] = stE < lenB[p] ? b[0] : 0.0;
+            b[1] = stE + 1 < lenB[p] ? b[1] : 0.0;
+            *reinterpret_cast<double2v *>(&sA[buf][row * kLdk + se]) = a;
+            *reinterpret_cast<double2v *>(&sB[buf][row * kLdk + se]) = b;
+        }
+    };
+
+    double4v acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            acc[a][b] = double4v{0.0, 0.0, 0.0, 0.0};
+
+    const int lr = lane & 15, lg = lane >> 4;
+    if (nChunks > 0) {
+        fetch(0);
+        stash(0);
+    }
+    __syncthreads();
+    for (unsigned c = 0; c < nChunks; ++c) {
+        const int buf = (int)(c & 1);
+#ifndef SSYM_RM_NOFETCH   // (tools only: without it the MFMAs run on the first chunk over and over)
+        if (c + 1 < nChunks)
+            fetch(c + 1);                                  // global loads in flight under the MFMAs
+#endif
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {                   // two MFMA steps per 16-byte LDS read
+            double av[4][2], bv[4][2];                     // [block][step]
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk) {
+                const double2v a2 = *reinterpret_cast<const double2v *>(&sA[buf][(wm * 64 + blk * 16 + lr) * kLdk + 4 * lg + 2 * hf]);
+                const double2v b2 = *reinterpret_cast<const double2v *>(&sB[buf][(wn * 64 + blk * 16 + lr) * kLdk + 4 * lg + 2 * hf]);
+                av[blk][0] = a2[0]; av[blk][1] = a2[1];
+                bv[blk][0] = b2[0]; bv[blk][1] = b2[1];
+            }
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a][st], bv[b][st], acc[a][b], 0, 0, 0);
+#ifndef SSYM_RM_NOFETCH
+            // the next chunk goes to LDS in the shadow of the MFMAs (its loads were issued 32 MFMAs ago; the other
+            // buffer has not been read since the barrier that ended the previous chunk)
+            if (hf == 0 && c + 1 < nChunks)
+                stash(buf ^ 1);
+#endif
+        }
+#ifndef SSYM_RM_NOFETCH
+        __syncthreads();
+#endif
+    }
+
+#ifdef SSYM_RM_NOEPI      // tools only: the main loop alone, every accumulator kept alive (results meaningless)
+    {
+        double4v t = acc[0][0];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                t += acc[a][b];
+        if (t[0] + t[1] + t[2] + t[3] == 12345.678 && hdr[0] == 77)
+            thr[0] = 1;
+        return;
+    }
+#endif
+    refcos_epilogue<WRITE_SIMS>(acc, reinterpret_cast<RowInfo *>(&sA[0][0]), sLen, tid, lane, wm, wn, lr, lg, sTile, tTile, nSrc,
+                                nTgt, srcNorm, tgtNorm, dist, defaultDist, thr, hdr, list, cap, dotOut);
 }
 
 // list 1 against the final thresholds -> list 2 (pairs only)

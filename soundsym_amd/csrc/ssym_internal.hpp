@@ -37,6 +37,9 @@ inline int filter_pieces(int dim) { return dim <= 13 ? 2 : 1; }
 // makes the filter's cost a LOWER bound of the pair's cost ("wide frames")
 inline int filter_dim_used(int dim) { return dim <= 42 ? dim : 42; }
 
+// doubles allocated behind a set's values: 16-byte loads that start on a segment's last value stay inside the buffer
+constexpr size_t kRawTailPad = 2;
+
 struct DeviceBuf {
     void *ptr = nullptr;
     size_t bytes = 0;
