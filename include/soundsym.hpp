@@ -256,14 +256,16 @@ class SoundDictionary {
     // the dictionary's features are packed once per content change, not per query
     const ssym_dict *resident() const
     {
-        if (!dict_ || packed_n_ != sounds.size()) {
+        // `sounds` is public and mutable (`pub sounds`): entries may have been replaced or reordered in place, so the
+        // packed copy is compared by content (the Arcs themselves), not by length; the copy keeps them alive
+        if (!dict_ || packed_ != sounds) {
             release();
             std::vector<double> flat;
             std::vector<uint64_t> off;
             pack_features(sounds, flat, off);
             ctx_->check(ssym_dict_create(ctx_->get(), flat.data(), off.data(), (uint32_t)sounds.size(),
                                          (uint32_t)NCOEFFS, &dict_));
-            packed_n_ = sounds.size();
+            packed_ = sounds;
         }
         return dict_;
     }
@@ -275,7 +277,71 @@ class SoundDictionary {
     }
     std::shared_ptr<Context> ctx_;
     mutable ssym_dict *dict_ = nullptr;
-    mutable std::size_t packed_n_ = 0;
+    mutable std::vector<ArcSound> packed_;
+};
+
+// One rank of a SoundDictionary split over the GPUs of one node (source-axis shards, one rank -- thread or process --
+// per GPU): rank g holds sounds [lo, lo + shard.size()) of the whole dictionary and is handed the same targets as every
+// other rank; match_indices returns GLOBAL indices, the same complete answer on every rank, bit for bit the unsharded
+// one.  The collectives (RCCL all-reduce(MIN) of the per-target bounds, all-gather of (cost, index)) run inside the
+// library on the context's stream (ssym_match_sharded): the loop of clone_from_dictionary / morph_to,
+// src/sound.rs:451-455 / 440-446, for a dictionary too large or too slow for one GPU.
+class ShardedDictionary {
+  public:
+    using Id = std::vector<unsigned char>;
+    // rank 0 draws the id (ncclGetUniqueId) and hands it to the other ranks by whatever means the host has
+    static Id unique_id()
+    {
+        Id id(SSYM_COMM_ID_BYTES);
+        int rc = ssym_comm_unique_id(id.data());
+        if (rc != SSYM_OK)
+            throw Error(rc, "ssym_comm_unique_id failed (is RCCL available?)");
+        return id;
+    }
+    // collective over all `world` ranks (ncclCommInitRank)
+    ShardedDictionary(std::shared_ptr<Context> ctx, const Id &id, int rank, int world, std::vector<ArcSound> shard,
+                      uint32_t lo)
+        : ctx_(std::move(ctx)), shard_(std::move(shard)), lo_(lo)
+    {
+        ctx_->check(ssym_comm_create(ctx_->get(), id.data(), rank, world, &comm_));
+        std::vector<double> flat;
+        std::vector<uint64_t> off;
+        pack_features(shard_, flat, off);
+        int rc = ssym_dict_create(ctx_->get(), flat.data(), off.data(), (uint32_t)shard_.size(), (uint32_t)NCOEFFS, &dict_);
+        if (rc != SSYM_OK) {
+            ssym_comm_destroy(ctx_->get(), comm_);
+            ctx_->check(rc);
+        }
+    }
+    ~ShardedDictionary()
+    {
+        ssym_dict_destroy(ctx_->get(), dict_);
+        ssym_comm_destroy(ctx_->get(), comm_);
+    }
+    ShardedDictionary(const ShardedDictionary &) = delete;
+    ShardedDictionary &operator=(const ShardedDictionary &) = delete;
+
+    std::vector<uint32_t> match_indices(const std::vector<ArcSound> &targets, const double *distances) const
+    {
+        std::vector<double> flat;
+        std::vector<uint64_t> off;
+        pack_features(targets, flat, off);
+        ssym_queries *q = nullptr;
+        ctx_->check(ssym_queries_create(ctx_->get(), flat.data(), off.data(), (uint32_t)targets.size(),
+                                        (uint32_t)NCOEFFS, &q));
+        std::vector<uint32_t> idx(targets.size());
+        int32_t rc = ssym_match_sharded(ctx_->get(), comm_, dict_, q, distances, lo_, idx.data(), nullptr, 0);
+        ssym_queries_destroy(ctx_->get(), q);
+        ctx_->check(rc);
+        return idx;
+    }
+
+  private:
+    std::shared_ptr<Context> ctx_;
+    std::vector<ArcSound> shard_;
+    uint32_t lo_;
+    ssym_comm *comm_ = nullptr;
+    ssym_dict *dict_ = nullptr;
 };
 
 class SoundSequence {

@@ -167,6 +167,29 @@ int main()
         CHECK(ssym_get_timings(pctx->get(), &tm) == SSYM_OK && tm.pruned == 1);
         CHECK(ssym_get_timings(dctx->get(), &tm) == SSYM_OK && tm.pruned == 0);
     }
+    // an entry replaced in place (same length): the resident copy follows the content
+    {
+        auto d2 = SoundDictionary::from_segments(ctx, src, segs);
+        ArcSound first = d2->match_sound(*d2->sounds[2]);
+        const std::size_t at = (std::size_t)(std::find(d2->sounds.begin(), d2->sounds.end(), first) - d2->sounds.begin());
+        d2->sounds[at] = tdict->sounds[1];
+        ArcSound again = d2->match_sound(*d2->sounds[2]);
+        CHECK(again == d2->sounds[oracle_at_distance(*d2, 1.0, *d2->sounds[2])]);
+    }
+    // a dictionary as ONE rank of a source-sharded run: RCCL communicator of world 1 behind the C ABI, global indices
+    {
+        auto dctx = std::make_shared<Context>(SSYM_METRIC_DTW);
+        auto whole = SoundDictionary::from_segments(dctx, src, segs);
+        std::vector<ArcSound> targets(tdict->sounds.begin(), tdict->sounds.end());
+        const std::vector<uint32_t> want = whole->match_indices(targets, nullptr);
+        ShardedDictionary rank0(dctx, ShardedDictionary::unique_id(), 0, 1, whole->sounds, 100);
+        std::vector<uint32_t> got = rank0.match_indices(targets, nullptr);
+        CHECK(got.size() == want.size());
+        for (std::size_t i = 0; i < got.size() && i < want.size(); ++i)
+            CHECK(got[i] == want[i] + 100);
+        ssym_timings tm{};
+        CHECK(ssym_get_timings(dctx->get(), &tm) == SSYM_OK && tm.attempts == 1);
+    }
     std::printf(g_fail ? "%d checks FAILED\n" : "all checks passed\n", g_fail);
     return g_fail ? 1 : 0;
 }
