@@ -59,3 +59,22 @@ def test_bench_sharded_path_through_the_library_collectives():
 def test_bench_banded_workload_shape():
     line = _run(["--no-secondary", "--workload", "c5"], shape=("--sources", "256", "--targets", "256", "--frames", "96"))
     assert line["roofline"]["kernel"] == "dtw_band_kernel" and line["config"]["indices_equal_planted"] is True
+
+
+def test_bench_two_ranks_rehearsal_over_gloo():
+    # two ranks on the one GPU of the test box (RCCL cannot put two ranks on one device, so the exchange runs as
+    # torch.distributed collectives over gloo around the two-phase C-ABI calls): the strong-scaling split, the
+    # per-rank figures, the planted check and the one JSON line of rank 0
+    env = dict(os.environ, SSYM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29561", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-secondary", "--sources", "512",
+                          "--targets", "256", "--frames", "64"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["sources_per_gpu"] == 256
+    assert line["config"]["indices_equal_planted"] is True and len(line["config"]["per_rank"]) == 2
+    assert abs(line["value"] - 512 * 256 / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-6
