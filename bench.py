@@ -206,6 +206,13 @@ def main():
         wl["band"] = args.band
         custom.append("band")
 
+    # stdout carries ONE line, the JSON record of rank 0: libraries write there too (RCCL prints a five-line version
+    # banner on the first communicator of a process), so file descriptor 1 is pointed at stderr for the run and the
+    # record goes to the saved descriptor at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from soundsym_amd import Engine, sharding, synth
@@ -467,7 +474,8 @@ def main():
             if not args.no_cpu_baseline:
                 secondary_cpu(secondary)
             line["secondary"] = secondary
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if comm is not None:
         comm.close()
     eng.close()

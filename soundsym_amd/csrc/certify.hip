@@ -56,6 +56,13 @@ __global__ __launch_bounds__(64) void certify_run_kernel(const _Float16 *__restr
                 const int fb = tgtLen[p.y], fa = srcLen[p.x];
                 if (c0 >= fb || fa <= 0)
                     continue;                                  // wave-uniform
+                // a target's ONLY candidate (the list is grouped by target) is kept by the second selection whatever
+                // its certificate says: none is computed (0 = "no certificate", the worst-case error).  On data with
+                // one close neighbour per target that is every entry of the list.
+                if ((k == 0 || pairs[k - 1].y != p.y) && (k + 1 >= n || pairs[k + 1].y != p.y)) {
+                    mrun[e] = 0.0f;
+                    continue;                                  // wave-uniform
+                }
                 if (p.y != cachedT) {
                     cachedT = p.y;
                     const _Float16 *tBase = tgtRec + tgt_rec_offset(p.y, tgtSlots, 0, 0, kh);

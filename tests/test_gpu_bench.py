@@ -16,8 +16,8 @@ def _run(extra, env=None, shape=("--src-per-gpu", "512", "--targets", "256", "--
                           "--no-cpu-baseline"] + list(shape) + extra,
                          capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, **(env or {})))
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
-    assert len(lines) == 1
+    lines = out.stdout.strip().splitlines()
+    assert len(lines) == 1, lines          # stdout is the record and nothing else (library banners go to stderr)
     return json.loads(lines[0])
 
 
