@@ -316,8 +316,10 @@ int32_t match_sharded_impl(ssym_ctx *ctx, ssym_comm *comm, const ssym_dict *dict
 
     // ---- phase 2 + exchange; repeated once by EVERY rank when any rank's candidate list overflowed -----------
     uint32_t *status = comm->status_host;
+    // (the merge compares |cost - distance| for dtw; refcos shards report the key |sim - distance| itself, which the
+    //  merge must compare as it is)
     const double *distDev = nullptr;
-    if (distance) {
+    if (distance && !refcos) {
         if (emptyShard) {                           // (otherwise phase 1 has uploaded them)
             rc = ensure(ctx, ctx->dist, sizeof(double) * M);
             if (rc == SSYM_OK)
@@ -387,12 +389,13 @@ int32_t match_sharded_impl(ssym_ctx *ctx, ssym_comm *comm, const ssym_dict *dict
             ctx->err = "dtw: candidate list overflow on a rank of the sharded match";
             return SSYM_E_NOMEM;
         }
+        for (int g = 0; g < G; ++g)
+            if (status[2 * g + 1] && status[2 * g] >= 0xffffffffu) {           // (every rank sees it and stops here)
+                ctx->err = "dtw: too many near-tied candidates for one batch on a rank of the sharded match";
+                return SSYM_E_UNSUPPORTED;
+            }
         if (status[2 * comm->rank + 1])
             ctx->so_cap = status[2 * comm->rank];               // this rank's list wanted that much
-        if (ctx->so_cap >= 0xffffffffull) {
-            ctx->err = "dtw: too many near-tied candidates for one batch";      // (every rank stops: all saw the flag)
-            return SSYM_E_UNSUPPORTED;
-        }
     }
     stage_finish(ctx);
     if (filterPath) {
