@@ -11,6 +11,7 @@ use std::os::raw::{c_char, c_void};
 #[repr(C)] pub struct SsymQueries { _p: [u8; 0] }
 #[repr(C)] pub struct SsymSamples { _p: [u8; 0] }
 #[repr(C)] pub struct SsymComm { _p: [u8; 0] }
+#[repr(C)] pub struct SsymLocalGroup { _p: [u8; 0] }
 
 pub const SSYM_ABI_VERSION: i32 = 2;
 
@@ -129,6 +130,12 @@ extern "C" {
     pub fn ssym_match_sharded(ctx: *mut SsymCtx, comm: *mut SsymComm, dict: *const SsymDict, q: *const SsymQueries,
                               distance: *const f64, index_base: u32, out_idx: *mut u32, out_cost: *mut f64,
                               flags: u32) -> i32;
+
+    // the ranks of ONE process (a thread per rank) without RCCL: host barriers around device copies -- what the
+    // one-GPU tests use to run more than one rank (RCCL refuses two ranks on one device)
+    pub fn ssym_local_group_create(world: i32, out: *mut *mut SsymLocalGroup) -> i32;
+    pub fn ssym_local_group_destroy(group: *mut SsymLocalGroup) -> i32;
+    pub fn ssym_comm_create_local(ctx: *mut SsymCtx, group: *mut SsymLocalGroup, rank: i32, out: *mut *mut SsymComm) -> i32;
 
     // reconstruction tail (src/sound.rs:456-465, 475-480, 139)
     pub fn ssym_samples_create(ctx: *mut SsymCtx, samples: *const f64, sample_offsets: *const u64, n_sounds: u32,

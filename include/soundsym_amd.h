@@ -307,6 +307,16 @@ SSYM_API int32_t ssym_match_sharded(ssym_ctx *ctx, ssym_comm *comm, const ssym_d
                                     const double *distance, uint32_t index_base, uint32_t *out_idx,
                                     double *out_cost, uint32_t flags);
 
+/* The ranks of ONE process (a thread per rank, every rank its own context, on one GPU or several) without RCCL:
+ * the same ssym_match_sharded, its two exchanges done with host barriers around device copies instead of
+ * stream-ordered RCCL calls.  RCCL refuses two ranks on one device; this transport is how the multi-rank logic
+ * (gather layout, merge over G shards, the agreed repeat after an overflow, empty shards) is exercised on a one-GPU
+ * box (tests/test_gpu_comm.py).  Every rank's thread must be inside its ssym_match_sharded call at the same time. */
+typedef struct ssym_local_group ssym_local_group;
+SSYM_API int32_t ssym_local_group_create(int32_t world, ssym_local_group **out);
+SSYM_API int32_t ssym_local_group_destroy(ssym_local_group *group);
+SSYM_API int32_t ssym_comm_create_local(ssym_ctx *ctx, ssym_local_group *group, int32_t rank, ssym_comm **out);
+
 /* Reconstruction tail (the step right after the hot path): the samples of every dictionary sound,
  * resident on the GPU (Sound::samples(), src/sound.rs:181; `sample_offsets` = n_sounds+1 SAMPLE
  * offsets into `samples`, f64, HOST memory). */

@@ -44,6 +44,7 @@ ABI_SYMBOLS = [
     "ssym_match_one", "ssym_chain", "ssym_pair_matrix", "ssym_merge_shards", "ssym_merge_shards_at", "ssym_samples_create",
     "ssym_samples_destroy", "ssym_reconstruct", "ssym_mfcc_num_frames", "ssym_mfcc",
     "ssym_comm_unique_id", "ssym_comm_create", "ssym_comm_destroy", "ssym_match_sharded",
+    "ssym_local_group_create", "ssym_local_group_destroy", "ssym_comm_create_local",
 ]
 COMM_ID_BYTES = 128        # SSYM_COMM_ID_BYTES
 
@@ -242,6 +243,12 @@ def lib() -> ctypes.CDLL:
     L.ssym_comm_destroy.argtypes = [vp, vp]
     L.ssym_match_sharded.restype = i32
     L.ssym_match_sharded.argtypes = [vp, vp, vp, vp, vp, u32, vp, vp, u32]
+    L.ssym_local_group_create.restype = i32
+    L.ssym_local_group_create.argtypes = [i32, pvp]
+    L.ssym_local_group_destroy.restype = i32
+    L.ssym_local_group_destroy.argtypes = [vp]
+    L.ssym_comm_create_local.restype = i32
+    L.ssym_comm_create_local.argtypes = [vp, vp, i32, pvp]
     _lib = L
     return L
 

@@ -17,8 +17,10 @@
 #include <rccl/rccl.h>
 
 #include <cmath>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 
 using namespace ssym;
@@ -84,8 +86,36 @@ const Rccl &rccl()
 
 }  // namespace
 
+// The ranks of ONE process (a thread per rank, each with its own context -- on one GPU or several): the exchange
+// without RCCL.  RCCL refuses two ranks on one device, so this is how the multi-rank logic of ssym_match_sharded
+// (block layout and strides of the gather, merge over G shards, the overflow repeat agreed through the gathered status,
+// an empty shard among full ones) runs on a one-GPU test box; it is not stream-ordered (host barriers around device
+// copies) and not what the multi-GPU bench uses.
+struct ssym_local_group {
+    int world = 0;
+    std::mutex m;
+    std::condition_variable cv;
+    int arrived = 0;
+    unsigned long long gen = 0;
+    std::vector<const void *> slot;     // per rank: the buffer it offers in the current collective
+    void barrier()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        const unsigned long long g = gen;
+        if (++arrived == world) {
+            arrived = 0;
+            ++gen;
+            cv.notify_all();
+        } else {
+            cv.wait(lk, [&] { return gen != g; });
+        }
+    }
+};
+
 struct ssym_comm {
     ncclComm_t nccl = nullptr;
+    ssym_local_group *local = nullptr;   // non-NULL: the in-process transport above instead of RCCL
+    DeviceBuf local_tmp;                 // in-process all-reduce: every rank's values side by side
     int rank = 0, world = 1;
     DeviceBuf bounds;      // M f64: per-target bounds (and, before them, the candidates' costs of a pruned step)
     DeviceBuf cand;        // M f64: candidates' costs
@@ -126,6 +156,59 @@ static float ev_ms2(hipEvent_t a, hipEvent_t b)
 {
     float ms = 0.f;
     return hipEventElapsedTime(&ms, a, b) == hipSuccess ? ms : 0.f;
+}
+
+__global__ void comm_min_rows_kernel(const double *__restrict__ rows, int nRows, uint32_t n, double *__restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    double m = rows[i];
+    for (int r = 1; r < nRows; ++r)
+        m = fmin(m, rows[(size_t)r * n + i]);      // (bounds and costs are never NaN: fmin is a plain minimum here)
+    out[i] = m;
+}
+
+// in-process all-gather: every rank copies every rank's block into its own receive buffer
+static int32_t local_all_gather(ssym_ctx *ctx, ssym_comm *c, const void *send, void *recv, size_t bytes)
+{
+    ssym_local_group *g = c->local;
+    SSYM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));          // my block is complete
+    {
+        std::lock_guard<std::mutex> lk(g->m);
+        g->slot[c->rank] = send;
+    }
+    g->barrier();                                                     // everybody's block is complete and published
+    for (int r = 0; r < c->world; ++r)
+        SSYM_HIP_CHECK(ctx, hipMemcpyAsync((char *)recv + (size_t)r * bytes, g->slot[r], bytes, hipMemcpyDeviceToDevice,
+                                           ctx->stream));
+    SSYM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    g->barrier();                                                     // everybody has read: the blocks may change again
+    return SSYM_OK;
+}
+
+static int32_t comm_all_gather(ssym_ctx *ctx, ssym_comm *c, const void *send, void *recv, size_t bytes)
+{
+    if (c->local)
+        return local_all_gather(ctx, c, send, recv, bytes);
+    SSYM_NCCL_CHECK(ctx, rccl().AllGather(send, recv, bytes, ncclUint8, c->nccl, ctx->stream));
+    return SSYM_OK;
+}
+
+static int32_t comm_all_reduce_min(ssym_ctx *ctx, ssym_comm *c, double *buf, uint32_t n)
+{
+    if (c->local) {
+        int32_t rc = ensure(ctx, c->local_tmp, sizeof(double) * (size_t)n * c->world);
+        if (rc == SSYM_OK)
+            rc = local_all_gather(ctx, c, buf, c->local_tmp.ptr, sizeof(double) * n);
+        if (rc != SSYM_OK)
+            return rc;
+        comm_min_rows_kernel<<<(n + 255) / 256, 256, 0, ctx->stream>>>((const double *)c->local_tmp.ptr, c->world, n, buf);
+        SSYM_HIP_CHECK(ctx, hipGetLastError());
+        return SSYM_OK;
+    }
+    SSYM_NCCL_CHECK(ctx, rccl().AllReduce(buf, buf, n, ncclFloat64, ncclMin, c->nccl, ctx->stream));
+    return SSYM_OK;
 }
 
 extern "C" {
@@ -197,7 +280,7 @@ int32_t ssym_comm_destroy(ssym_ctx *ctx, ssym_comm *c)
     }
     if (c->nccl && rccl().ok)
         (void)rccl().CommDestroy(c->nccl);
-    for (DeviceBuf *b : {&c->bounds, &c->cand, &c->send, &c->recv})
+    for (DeviceBuf *b : {&c->bounds, &c->cand, &c->send, &c->recv, &c->local_tmp})
         if (b->ptr)
             (void)hipFree(b->ptr);
     if (c->status_host)
@@ -206,6 +289,55 @@ int32_t ssym_comm_destroy(ssym_ctx *ctx, ssym_comm *c)
         if (ev)
             (void)hipEventDestroy(ev);
     delete c;
+    return SSYM_OK;
+    });
+}
+
+int32_t ssym_local_group_create(int32_t world, ssym_local_group **out)
+{
+    if (!out || world < 1)
+        return SSYM_E_INVALID;
+    *out = nullptr;
+    return guarded(nullptr, [&]() -> int32_t {
+        ssym_local_group *g = new ssym_local_group();
+        g->world = world;
+        g->slot.assign((size_t)world, nullptr);
+        *out = g;
+        return SSYM_OK;
+    });
+}
+
+int32_t ssym_local_group_destroy(ssym_local_group *group)
+{
+    delete group;
+    return SSYM_OK;
+}
+
+int32_t ssym_comm_create_local(ssym_ctx *ctx, ssym_local_group *group, int32_t rank, ssym_comm **out)
+{
+    if (!ctx)
+        return SSYM_E_INVALID;
+    return guarded(ctx, [&]() -> int32_t {
+    if (!group || !out || rank < 0 || rank >= group->world) {
+        ctx->err = "ssym_comm_create_local: bad arguments";
+        return SSYM_E_INVALID;
+    }
+    *out = nullptr;
+    SSYM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    ssym_comm *c = new ssym_comm();
+    c->local = group;
+    c->rank = rank;
+    c->world = group->world;
+    hipError_t e = hipHostMalloc((void **)&c->status_host, sizeof(uint32_t) * 2 * ((size_t)c->world + 1), hipHostMallocDefault);
+    for (auto &ev : c->ev)
+        if (e == hipSuccess)
+            e = hipEventCreate(&ev);
+    if (e != hipSuccess) {
+        ctx->err = std::string("ssym_comm_create_local: ") + hipGetErrorString(e);
+        ssym_comm_destroy(ctx, c);
+        return SSYM_E_HIP;
+    }
+    *out = c;
     return SSYM_OK;
     });
 }
@@ -295,7 +427,9 @@ int32_t match_sharded_impl(ssym_ctx *ctx, ssym_comm *comm, const ssym_dict *dict
                 return rc;
         }
         SSYM_HIP_CHECK(ctx, hipEventRecord(cev[0], st));
-        SSYM_NCCL_CHECK(ctx, rccl().AllReduce(cand, cand, M, ncclFloat64, ncclMin, comm->nccl, st));
+        rc = comm_all_reduce_min(ctx, comm, cand, M);
+        if (rc != SSYM_OK)
+            return rc;
         SSYM_HIP_CHECK(ctx, hipEventRecord(cev[1], st));
         pruned = true;
     }
@@ -311,7 +445,9 @@ int32_t match_sharded_impl(ssym_ctx *ctx, ssym_comm *comm, const ssym_dict *dict
     tm.used_filter = filterPath ? 1 : 0;
     tm.pruned = filterPath && ctx->pending.pruned ? 1 : 0;
     SSYM_HIP_CHECK(ctx, hipEventRecord(cev[2], st));
-    SSYM_NCCL_CHECK(ctx, rccl().AllReduce(bounds, bounds, M, ncclFloat64, ncclMin, comm->nccl, st));
+    rc = comm_all_reduce_min(ctx, comm, bounds, M);
+    if (rc != SSYM_OK)
+        return rc;
     SSYM_HIP_CHECK(ctx, hipEventRecord(cev[3], st));
 
     // ---- phase 2 + exchange; repeated once by EVERY rank when any rank's candidate list overflowed -----------
@@ -347,7 +483,9 @@ int32_t match_sharded_impl(ssym_ctx *ctx, ssym_comm *comm, const ssym_dict *dict
             SSYM_HIP_CHECK(ctx, hipGetLastError());
         }
         SSYM_HIP_CHECK(ctx, hipEventRecord(cev[5], st));
-        SSYM_NCCL_CHECK(ctx, rccl().AllGather(comm->send.ptr, comm->recv.ptr, blk, ncclUint8, comm->nccl, st));
+        rc = comm_all_gather(ctx, comm, comm->send.ptr, comm->recv.ptr, blk);
+        if (rc != SSYM_OK)
+            return rc;
         SSYM_HIP_CHECK(ctx, hipEventRecord(cev[6], st));
         rc = launch_merge_shards(ctx, (uint32_t)G, M, (const double *)comm->recv.ptr,
                                  (const uint32_t *)((const char *)comm->recv.ptr + sizeof(double) * M), distDev, userIdx,

@@ -84,6 +84,22 @@ class Comm:
             pass
 
 
+class LocalGroup:
+    """The ranks of one process without RCCL (ssym_local_group): a thread per rank, every rank its own Engine.
+    RCCL refuses two ranks on one device; this is how the multi-rank logic of ssym_match_sharded runs on a one-GPU
+    box.  Every rank's thread must be inside match_sharded at the same time (ctypes releases the GIL)."""
+
+    def __init__(self, world: int):
+        out = ctypes.c_void_p()
+        nat.check(nat.lib().ssym_local_group_create(world, ctypes.byref(out)), None)
+        self.ptr, self.world = out.value, world
+
+    def close(self):
+        if self.ptr:
+            nat.lib().ssym_local_group_destroy(self.ptr)
+        self.ptr = None
+
+
 def comm_unique_id() -> bytes:
     """ssym_comm_unique_id: the 128-byte RCCL id rank 0 hands to the other ranks."""
     nat.load_rccl()
@@ -224,6 +240,12 @@ class Engine:
         buf = ctypes.create_string_buffer(bytes(unique_id), nat.COMM_ID_BYTES)
         nat.check(nat.lib().ssym_comm_create(self.ctx, buf, rank, world, ctypes.byref(out)), self.ctx)
         return Comm(self, out.value, rank, world)
+
+    def comm_create_local(self, group: LocalGroup, rank: int) -> Comm:
+        """ssym_comm_create_local: this engine as rank `rank` of an in-process group (no RCCL)."""
+        out = ctypes.c_void_p()
+        nat.check(nat.lib().ssym_comm_create_local(self.ctx, group.ptr, rank, ctypes.byref(out)), self.ctx)
+        return Comm(self, out.value, rank, group.world)
 
     def match_sharded(self, comm: Comm, d: _Handle, q: _Handle, distance=None, index_base: int = 0,
                       out_idx=None, out_cost=None, prune: bool = False, force_exact: bool = False):

@@ -6,6 +6,8 @@ the merge sees one shard, and the result must be bit for bit ssym_match_queries'
 the step has (filter, per-target distances, early abandoning, bands, shapes outside the filter,
 refcos, an empty shard, an overflowing candidate list that makes every rank repeat the tail).
 Range / gather / merge logic with two ranks: tests/test_host.py (gloo), tests/test_gpu_sharded.py.
+MORE than one rank through ssym_match_sharded itself: the second half of this file -- a thread per rank on the one
+GPU with the in-process transport (ssym_comm_create_local) in RCCL's place.
 """
 import numpy as np
 import pytest
@@ -115,3 +117,123 @@ def test_world1_overflowing_candidate_list_repeats_the_tail(oracle):
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and (got[0] == 0).all()
     comm.close()
     e.close()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# More than one rank on the one GPU: a thread per rank, every rank its own context, the in-process transport
+# (ssym_comm_create_local) instead of RCCL.  Same ssym_match_sharded, G > 1: gather layout and strides, merge over
+# G shards, bounds exchange, the agreed repeat after ONE rank's overflow, an empty shard among full ones.
+# ---------------------------------------------------------------------------------------------------------
+def _run_ranks(world, metric, dtype, shards, dim, tflat, toff, bases, band=-1, distance=None, prune=False):
+    """shards: per rank (flat features, frame offsets).  Returns per rank (idx, cost, timings)."""
+    import threading
+    from soundsym_amd.engine import LocalGroup
+    group = LocalGroup(world)
+    out, err = [None] * world, [None] * world
+    ready = threading.Barrier(world)
+
+    def rank_main(r):
+        try:
+            e = Engine(metric=metric, dtype=dtype, band=band)
+            d = e.dictionary(shards[r][0], shards[r][1], dim)
+            q = e.queries(tflat, toff, dim)
+            comm = e.comm_create_local(group, r)
+            ready.wait(timeout=120)
+            for _ in range(2):                                   # twice: buffers and group are reused
+                idx, cost = e.match_sharded(comm, d, q, distance=distance, index_base=bases[r], prune=prune)
+            out[r] = (idx.copy(), cost.copy(), e.timings())
+            comm.close()
+            e.close()
+        except Exception as ex:                                  # noqa: BLE001
+            err[r] = ex
+            try:
+                ready.abort()
+            except Exception:
+                pass
+
+    threads = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    group.close()
+    for r in range(world):
+        assert err[r] is None, (r, err[r])
+        assert out[r] is not None, f"rank {r} did not finish"
+    return out
+
+
+def _split(segs, world, dim, dtype):
+    parts, bases = [], []
+    for r in range(world):
+        lo, hi = sharding.shard_range(len(segs), world, r)
+        parts.append(pack_segments(segs[lo:hi], dim, dtype))
+        bases.append(lo)
+    return parts, bases
+
+
+@pytest.mark.parametrize("world,band,prune,with_dist", [(2, -1, False, False), (3, -1, True, False), (4, -1, False, True),
+                                                         (2, 6, False, False), (3, 6, True, False)])
+def test_multi_rank_in_process_equals_the_unsharded_match(world, band, prune, with_dist):
+    n, m, f, dim = 300, 140, 36, 13
+    g = synth.make_grid(n, m, f, dim, 0x5EED0A40 + world)
+    g.sources[200] = g.sources[17]                       # a duplicate across shard boundaries: the lowest index wins
+    g.targets[3] = g.sources[17]
+    dist = np.linspace(0.0, 25.0, m) if with_dist else None
+    e = Engine(metric="dtw", dtype="f32", band=band)
+    so = np.arange(n + 1, dtype=np.uint64) * f
+    to = np.arange(m + 1, dtype=np.uint64) * f
+    want_idx, want_cost = e.match(e.dictionary(g.sources.reshape(-1), so, dim), e.queries(g.targets.reshape(-1), to, dim),
+                                  distance=dist)
+    e.close()
+    shards, bases = _split(list(g.sources), world, dim, np.float32)
+    res = _run_ranks(world, "dtw", "f32", shards, dim, g.targets.reshape(-1), to, bases, band=band, distance=dist, prune=prune)
+    refined = 0
+    for r in range(world):
+        idx, cost, tm = res[r]
+        assert np.array_equal(idx, want_idx) and np.array_equal(cost, want_cost), r       # every rank: the whole answer
+        assert tm["attempts"] == 1 and tm["used_filter"] == 1
+        refined += tm["n_refined"]
+    assert want_idx[3] == 17
+    if not with_dist and not prune:
+        assert refined <= 3 * m, refined                 # the bound exchange: a shard without the neighbour re-scores (almost) nothing
+
+
+def test_multi_rank_refcos_with_distances_and_an_empty_shard(oracle):
+    # refcos shards report the key |sim - distance| itself: the merge compares keys as they are; rank 2 holds nothing
+    rs, rt = synth.make_ragged(90, 40, 1, 25, 12, 0x5EED0A50)
+    src = [s.astype(np.float64) * 0.05 for s in rs]
+    tgt = [t.astype(np.float64) * 0.05 for t in rt]
+    src[70] = src[5].copy()
+    tgt[0] = src[5].copy()
+    tf, to = pack_segments(tgt, 12)
+    sf, so = pack_segments(src, 12)
+    dist = np.linspace(0.2, 1.4, 40)
+    want_idx, want_val = oracle.refcos_match_all(sf, so, tf, to, 12, distance=dist)
+    cuts = [(0, 40), (40, 90), (90, 90)]
+    shards = [pack_segments(src[a:b], 12) for a, b in cuts]
+    res = _run_ranks(3, "refcos", "f64", shards, 12, tf, to, [a for a, _ in cuts], distance=dist)
+    for r in range(3):
+        assert np.array_equal(res[r][0], want_idx) and np.array_equal(res[r][1], want_val), r
+
+
+def test_multi_rank_one_rank_overflows_and_every_rank_repeats(oracle):
+    # rank 0's sources are all identical (its candidate list wants every pair), rank 1's are ordinary: the gathered
+    # status makes BOTH ranks repeat the tail; the identical sources tie, the lowest global index wins
+    m, f, dim = 200, 8, 13
+    one = synth.make_grid(1, 1, f, dim, 0x5EED0395).sources[0]
+    same = np.repeat(one[None], 600, axis=0)
+    other = synth.make_grid(64, 1, f, dim, 0x5EED0A60).sources
+    rng = np.random.default_rng(4)
+    tgt = (one[None] + 0.01 * rng.standard_normal((m, f, dim))).astype(np.float32)    # every target's best: the 600 ties
+    allsrc = np.concatenate([same, other])
+    so = np.arange(allsrc.shape[0] + 1, dtype=np.uint64) * f
+    to = np.arange(m + 1, dtype=np.uint64) * f
+    want_idx, want_cost = oracle.dtw_match_all(allsrc.reshape(-1).astype(np.float64), so, tgt.reshape(-1).astype(np.float64), to, dim)
+    shards = [(same.reshape(-1), np.arange(601, dtype=np.uint64) * f), (other.reshape(-1), np.arange(65, dtype=np.uint64) * f)]
+    res = _run_ranks(2, "dtw", "f32", shards, dim, tgt.reshape(-1), to, [0, 600])
+    for r in range(2):
+        idx, cost, tm = res[r]
+        assert tm["attempts"] == 2, (r, tm)
+        assert np.array_equal(idx, want_idx) and np.allclose(cost, want_cost, rtol=1e-12, atol=0)
+    assert (want_idx == 0).all()
