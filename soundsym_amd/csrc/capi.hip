@@ -917,7 +917,7 @@ int32_t ssym_match_batch(ssym_ctx *ctx, const ssym_dict *dict, const void *tgt_f
         }
     }
     ssym_queries *q = nullptr;
-    hipEvent_t e0 = ctx->ev[6], e1 = ctx->ev[7];
+    hipEvent_t e0 = ctx->ev[8], e1 = ctx->ev[9];      // (the match below records ev[0..6] itself)
     SSYM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     SSYM_HIP_CHECK(ctx, hipEventRecord(e0, ctx->stream));
     ctx->defer_sync = true;        // this call synchronises once, at the end of the match

@@ -70,30 +70,43 @@ __global__ void segment_stats_kernel(const double *__restrict__ raw, const uint6
     const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t s = perm[slot];
     if (s >= n)
-        return;
+        return;                                   // (block-uniform: a block is one wave of one slot)
     const uint32_t nf = (uint32_t)(off[s + 1] - off[s]);
     if (f == 0)
         len[slot] = (int32_t)nf;
-    if (f >= nf)
-        return;
-    const double *p = raw + (off[s] + f) * dim;
-    double sq = 0.0, ma = 0.0;
-    for (uint32_t e = 0; e < dim; ++e) {
-        const double v = p[e];
-        sq += v * v;
-        const double av = fabs(v);
-        ma = (av > ma || av != av) ? av : ma;     // NaN sticks
+    float sqf = 0.f, maf = 0.f;
+    if (f < nf) {
+        const double *p = raw + (off[s] + f) * dim;
+        double sq = 0.0, ma = 0.0;
+        for (uint32_t e = 0; e < dim; ++e) {
+            const double v = p[e];
+            sq += v * v;
+            const double av = fabs(v);
+            ma = (av > ma || av != av) ? av : ma;     // NaN sticks
+        }
+        sqf = (float)sq * 1.000001f;              // rounded up
+        maf = (float)ma * 1.000001f;
+        if (!(sqf == sqf) || !(maf == maf)) { sqf = __builtin_inff(); maf = __builtin_inff(); }
     }
-    float sqf = (float)sq * 1.000001f;            // rounded up
-    float maf = (float)ma * 1.000001f;
-    if (!(sqf == sqf) || !(maf == maf)) { sqf = __builtin_inff(); maf = __builtin_inff(); }
-    atomicMax(&max_sqnorm_bits[slot], __float_as_uint(sqf));
-    atomicMax(max_abs_bits, __float_as_uint(maf));
+    // one atomic per wave and per slot, none on a set-wide word: half a million atomics on ONE word (the set-wide
+    // maximum) were what this kernel's 0.6 ms at 4096 segments of 128 frames consisted of
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        sqf = fmaxf(sqf, __shfl_xor(sqf, o));
+        maf = fmaxf(maf, __shfl_xor(maf, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&max_sqnorm_bits[slot], __float_as_uint(sqf));
+        atomicMax(&max_abs_bits[slot], __float_as_uint(maf));      // per slot: the host takes the set-wide maximum
+    }
 }
 
 // ---- cached device blocks ----------------------------------------------------------------------
-constexpr size_t kCacheBlockMax = (size_t)16 << 20;     // larger blocks go straight to the driver
-constexpr size_t kCacheTotalMax = (size_t)512 << 20;
+// Blocks up to 512 MB are kept (at most 4 GB per context, of 288): a batch of host targets (ssym_match_batch, the
+// drop-in caller's pattern) allocates and frees ~250 MB of values, records and staging per call, and going to the
+// driver for them cost more than a millisecond of a 39 ms call.  Larger blocks go straight to the driver.
+constexpr size_t kCacheBlockMax = (size_t)512 << 20;
+constexpr size_t kCacheTotalMax = (size_t)4 << 30;
 
 static size_t round_block(size_t bytes)
 {
@@ -265,22 +278,25 @@ static int32_t build_derived(ssym_ctx *ctx, SegmentSet &set)
         { int32_t rcs = stage_h2d(ctx, set.perm, set.h_perm.data(), sizeof(uint32_t) * set.n_pad); if (rcs != SSYM_OK) return rcs; }
         { int32_t rca = dev_alloc(ctx, (void **)&set.len, sizeof(int32_t) * set.n_pad); if (rca != SSYM_OK) return rca; }
         SSYM_HIP_CHECK(ctx, hipMemsetAsync(set.len, 0, sizeof(int32_t) * set.n_pad, st));
-        { int32_t rca = dev_alloc(ctx, (void **)&set.max_sqnorm, sizeof(float) * (set.n_pad + 1)); if (rca != SSYM_OK) return rca; }
-        SSYM_HIP_CHECK(ctx, hipMemsetAsync(set.max_sqnorm, 0, sizeof(float) * (set.n_pad + 1), st));
+        // [n_pad] max squared frame norm per slot (read by the kernels), then [n_pad] max |value| per slot (host only)
+        { int32_t rca = dev_alloc(ctx, (void **)&set.max_sqnorm, sizeof(float) * 2 * (size_t)set.n_pad); if (rca != SSYM_OK) return rca; }
+        SSYM_HIP_CHECK(ctx, hipMemsetAsync(set.max_sqnorm, 0, sizeof(float) * 2 * (size_t)set.n_pad, st));
         dim3 grid((mf + 63) / 64, n);
         segment_stats_kernel<<<grid, 64, 0, st>>>(set.raw, set.off, set.perm, n, dim, set.len,
                                                   (unsigned *)set.max_sqnorm,
                                                   (unsigned *)set.max_sqnorm + set.n_pad);
         SSYM_HIP_CHECK(ctx, hipGetLastError());
-        std::vector<float> h(set.n_pad + 1);
-        SSYM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), set.max_sqnorm, sizeof(float) * (set.n_pad + 1),
+        std::vector<float> h(2 * (size_t)set.n_pad);
+        SSYM_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), set.max_sqnorm, sizeof(float) * 2 * (size_t)set.n_pad,
                                            hipMemcpyDeviceToHost, st));
         SSYM_HIP_CHECK(ctx, hipStreamSynchronize(st));
-        float m = 0.f;
-        for (uint32_t i = 0; i < set.n_pad; ++i)
+        float m = 0.f, ma = 0.f;
+        for (uint32_t i = 0; i < set.n_pad; ++i) {
             m = std::max(m, h[i]);
+            ma = std::max(ma, h[set.n_pad + i]);
+        }
         set.max_sqnorm_all = (double)m;
-        set.max_abs = (double)h[set.n_pad];
+        set.max_abs = (double)ma;
         dev_free(ctx, set.rec);
         set.rec = nullptr;
         set.rec_scale = 0.0;

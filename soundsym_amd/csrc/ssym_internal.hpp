@@ -122,7 +122,7 @@ struct ssym_ctx {
     ssym::DeviceBuf pipe_flag;
     int pipe_slot = 0;
     unsigned pipe_mask = 0;
-    hipEvent_t ev[8]{};
+    hipEvent_t ev[10]{};        // 0-6: phases of a match; 8-9: ssym_match_batch's pack
     float prune_swept = 1.f;               // share of the filter's cells the last pruned call swept (picks the pass height)
     unsigned long long pruned_cells = 0;   // SSYM_DTW_PRUNE: the filter's counter of the last call (host copy)
     // set by ssym_match_batch / ssym_match_one around their internal pack: the call synchronises
