@@ -59,6 +59,7 @@ def test_bench_sharded_path_through_the_library_collectives():
 def test_bench_banded_workload_shape():
     line = _run(["--no-secondary", "--workload", "c5"], shape=("--sources", "256", "--targets", "256", "--frames", "96"))
     assert line["roofline"]["kernel"] == "dtw_band_kernel" and line["config"]["indices_equal_planted"] is True
+    assert line["roofline"]["bound"] == "mfma" and 0 < line["roofline"]["frac"] < 1 and "hbm_streaming_model" in line["roofline"]
 
 
 def test_bench_two_ranks_rehearsal_over_gloo():
