@@ -1,0 +1,114 @@
+"""The key interval of the refcos matrix-pipe filter (csrc/refcos_mfma.hip), restated on the CPU and held against
+adversarial evaluation orders: whatever order (and fusing) the matrix pipe uses for the L-term dot, the reference's key
+|fl(fl(dot_ref / nrm) - distance)| must lie inside [key_lo, key_hi] computed from the other order's dot.
+
+Reference order: rulinalg's eight running sums, products and sums rounded separately (oracle/ssym_oracle.c,
+src/sound.rs:31).  Other orders: a fused multiply-add chain (one rounding per step, emulated exactly with Fractions),
+the same in reverse, four interleaved FMA chains (the MFMA's lane groups), pairwise summation of rounded products."""
+from fractions import Fraction
+
+import numpy as np
+import pytest
+
+U = 2.0 ** -53
+
+
+def dot_reference(a, b):
+    n = a.size
+    q, r = divmod(n, 8)
+    p = [np.float64(0.0)] * 8
+    for k in range(q):
+        for i in range(8):
+            p[i] = p[i] + a[8 * k + i] * b[8 * k + i]          # product rounded, then the sum
+    s = np.float64(0.0)
+    s = s + (p[0] + p[4])
+    s = s + (p[1] + p[5])
+    s = s + (p[2] + p[6])
+    s = s + (p[3] + p[7])
+    for i in range(r):
+        s = s + a[8 * q + i] * b[8 * q + i]
+    return float(s)
+
+
+def fma(x, y, z):
+    return float(Fraction(x) * Fraction(y) + Fraction(z))          # one rounding (float(Fraction) rounds correctly)
+
+
+def dot_fma_chain(a, b, order):
+    s = 0.0
+    for i in order:
+        s = fma(float(a[i]), float(b[i]), s)
+    return s
+
+
+def dot_four_chains(a, b):
+    acc = [0.0] * 4
+    for i in range(a.size):
+        acc[(i // 2) % 4] = fma(float(a[i]), float(b[i]), acc[(i // 2) % 4])
+    return (acc[0] + acc[1]) + (acc[2] + acc[3])
+
+
+def dot_pairwise(a, b):
+    v = [float(x) for x in (a * b)]
+    while len(v) > 1:
+        v = [v[i] + v[i + 1] if i + 1 < len(v) else v[i] for i in range(0, len(v), 2)]
+    return v[0] if v else 0.0
+
+
+def key_interval(dotm, na, nb, length, d):
+    """refcos_key_interval + the per-segment values of pack.hip, same operations in the same order."""
+    sa = float(np.sqrt(np.float64(na))) * (1.0 + 4.5e-16)
+    sb = float(np.sqrt(np.float64(nb))) * (1.0 + 4.5e-16)
+    with np.errstate(all="ignore"):
+        ia, ib = float(np.float64(1.0) / np.float64(na)), float(np.float64(1.0) / np.float64(nb))   # 1 / 0 = inf on the GPU
+    nrm = na * nb
+    cL = (3.0 * length + 16.0) * (U * 1.02)
+    with np.errstate(all="ignore"):
+        inv = float(np.float64(ia) * np.float64(ib))
+        s = float(np.float64(dotm) * np.float64(inv))
+        z = abs(float(np.float64(s) - np.float64(d)))
+        R = float(np.float64(1.0001) * (np.float64(cL) * (np.float64(sa) * np.float64(sb))) * np.float64(inv)
+                  + np.float64(9.0 * U) * (abs(np.float64(s)) + abs(np.float64(d))) + np.float64(1e-290))
+    klo = (z - R) * (1.0 - 4.0 * U) if z > R else 0.0
+    khi = (z + R) * (1.0 + 4.0 * U)
+    if not (khi < np.inf) or not (1e-280 < inv < 1e280):
+        klo, khi = 0.0, np.inf
+    if nrm == 0.0 or nrm != nrm or d != d:
+        klo = khi = np.inf
+    return klo, khi
+
+
+@pytest.mark.parametrize("length", [1, 7, 8, 9, 100, 1536])
+@pytest.mark.parametrize("scale", [1e-120, 1e-3, 1.0, 3e4, 1e100])
+def test_reference_key_lies_inside_the_interval_for_any_order(length, scale):
+    rng = np.random.default_rng(length * 1000 + int(np.log10(scale)) + 500)
+    for trial in range(4):
+        a = rng.standard_normal(length) * scale
+        b = rng.standard_normal(length) * scale
+        if trial == 1:
+            b = a * (1 + 1e-9 * rng.standard_normal(length))        # nearly parallel: sim at its largest
+        if trial == 2:
+            b = b - a * (a @ b) / (a @ a)                           # nearly orthogonal: heavy cancellation in the dot
+        if trial == 3:
+            a[::2] *= 1e6                                           # mixed magnitudes
+        na = 0.0
+        for x in a:                                                 # norm: sequential fold, src/sound.rs:35-38
+            na = float(np.float64(x) * np.float64(x) + np.float64(na))
+        nb = 0.0
+        for x in b:
+            nb = float(np.float64(x) * np.float64(x) + np.float64(nb))
+        d_ref = dot_reference(a, b)
+        nrm = na * nb
+        for d in (1.0, 0.0, 0.37):
+            with np.errstate(all="ignore"):
+                k_ref = abs(float(np.float64(d_ref) / np.float64(nrm)) - d) if nrm != 0 else np.nan
+            orders = [dot_fma_chain(a, b, range(length)), dot_fma_chain(a, b, range(length - 1, -1, -1)),
+                      dot_four_chains(a, b), dot_pairwise(a, b)]
+            for dotm in orders:
+                klo, khi = key_interval(dotm, na, nb, length, d)
+                if nrm == 0.0 or nrm != nrm:
+                    assert klo == np.inf                            # the reference's key is NaN / inf: never a winner
+                    continue
+                assert klo <= k_ref <= khi, (length, scale, trial, d, dotm, d_ref, klo, k_ref, khi)
+                if scale == 1.0 and np.isfinite(khi):               # and it is an interval worth having
+                    assert khi - klo <= 1e-9 * (abs(d_ref / nrm) + abs(d)) + 1e-11 * length / np.sqrt(nrm)
