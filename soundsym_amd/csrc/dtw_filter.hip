@@ -21,6 +21,12 @@
 
 namespace ssym {
 
+int filter_pieces(int dim)
+{
+    static const bool k48 = getenv("SSYM_FILTER_K48") != nullptr;      // measurements: the symmetric K = 48 layout
+    return dim > kFilterMaxDim2 ? 1 : (k48 ? 2 : 3);
+}
+
 // One thread per (segment, record slot).  Frame f of a segment with nf frames goes to slot
 // lead + f (lead = -1: END-ALIGNED, slot frames_pad - nf + f, the unbanded kernel's source layout).
 // Source slots that hold no frame (and all slots of padding segments) get |a|^2 = +inf so that
@@ -43,15 +49,20 @@ __global__ void build_filter_records_kernel(const double *__restrict__ raw, cons
     const uint32_t first = lead < 0 ? frames_pad - nf : (uint32_t)lead;
     const bool real = slot >= first && slot < first + nf;
     const uint32_t f = slot - first;
+    // slot of the first |a|^2 piece: behind the product slots (layout 3: fixed at 28, K = 32)
+    const int nbase = pieces == 3 ? 28 : (pieces == 2 ? 3 : 1) * (int)dimUse;
+    const int npieces = pieces == 3 ? 2 : 3;                       // f16 pieces per squared norm
     if (!real && is_source)
-        out[filter_slot_offset((pieces == 2 ? 3 : 1) * (int)dimUse)] = (_Float16)__builtin_inff();   // |a|^2 = +inf
+        out[filter_slot_offset(nbase)] = (_Float16)__builtin_inff();   // |a|^2 = +inf
     if (real) {
         const double *p = raw + (off[seg] + f) * dim;
         double nrm = 0.0;
         for (uint32_t e = 0; e < dimUse; ++e) {                  // frames wider than 42 values: the first 42
             const double v = p[e] * scale;                       // exact: scale is a power of two
             const _Float16 h1 = (_Float16)v;
-            const _Float16 h2 = pieces == 2 ? (_Float16)(v - (double)h1) : (_Float16)0.0f;
+            // second piece: both sides in layout 2; in layout 3 the source, and the target's first two values
+            const bool two = pieces == 2 || (pieces == 3 && (is_source || e < 2));
+            const _Float16 h2 = two ? (_Float16)(v - (double)h1) : (_Float16)0.0f;
             const double vh = (double)h1 + (double)h2;           // the value the MFMA will see
             nrm += vh * vh;                                      // norms of the REPRESENTED frame
             const _Float16 m1 = (_Float16)(-2.0f * (float)h1), m2 = (_Float16)(-2.0f * (float)h2);
@@ -59,6 +70,13 @@ __global__ void build_filter_records_kernel(const double *__restrict__ raw, cons
                 out[filter_slot_offset(3 * e + 0)] = is_source ? m1 : h1;
                 out[filter_slot_offset(3 * e + 1)] = is_source ? m1 : h2;
                 out[filter_slot_offset(3 * e + 2)] = is_source ? m2 : h1;
+            } else if (pieces == 3) {
+                // a . b~ = (a1 + a2) b1 for every value, + a1 b2 for the first two: b~ = b1 (+ b2), exactly the
+                // frame whose norm rides along, so the accumulator is |a~ - b~|^2 with no cancellation error
+                out[filter_slot_offset(2 * e + 0)] = is_source ? m1 : h1;
+                out[filter_slot_offset(2 * e + 1)] = is_source ? m2 : h1;
+                if (e < 2)
+                    out[filter_slot_offset(26 + e)] = is_source ? m1 : h2;
             } else {
                 out[filter_slot_offset(e)] = is_source ? m1 : h1;
             }
@@ -66,14 +84,15 @@ __global__ void build_filter_records_kernel(const double *__restrict__ raw, cons
         const _Float16 p1 = (_Float16)nrm;
         const _Float16 p2 = (_Float16)(nrm - (double)p1);
         const _Float16 p3 = (_Float16)(nrm - (double)p1 - (double)p2);
-        const int nbase = (pieces == 2 ? 3 : 1) * (int)dimUse;
-        const int mine = nbase + (is_source ? 0 : 3), other = nbase + (is_source ? 3 : 0);
+        const int mine = nbase + (is_source ? 0 : npieces), other = nbase + (is_source ? npieces : 0);
         out[filter_slot_offset(mine + 0)] = p1;
         out[filter_slot_offset(mine + 1)] = p2;
-        out[filter_slot_offset(mine + 2)] = p3;
         out[filter_slot_offset(other + 0)] = (_Float16)1.0f;
         out[filter_slot_offset(other + 1)] = (_Float16)1.0f;
-        out[filter_slot_offset(other + 2)] = (_Float16)1.0f;
+        if (npieces == 3) {
+            out[filter_slot_offset(mine + 2)] = p3;
+            out[filter_slot_offset(other + 2)] = (_Float16)1.0f;
+        }
     }
     if (is_source) {
         _Float16 *dst = rec + ((size_t)s * frames_pad + slot) * kFilterRecHalfs;
@@ -189,7 +208,7 @@ static int32_t ensure_records(ssym_ctx *ctx, const SegmentSet &set, double scale
     return SSYM_OK;
 }
 
-template <int NT, bool SQ>
+template <int NT, bool SQ, int KU>
 static void launch_one(hipStream_t st, const SegmentSet &src, const SegmentSet &tgt, int nPasses,
                        int gridBlocks, float outScale, float *handoff, unsigned *taskCtr, float *cmat,
                        const float *abandon, unsigned long long *colCtr, const uint32_t *candSlot,
@@ -212,12 +231,12 @@ static void launch_one(hipStream_t st, const SegmentSet &src, const SegmentSet &
     int taskChunk = (int)std::max(1L, std::min(8L, 8192 / std::max(1L, cellsPerTask)));
     taskChunk = std::max(1, std::min(taskChunk, nTasks / (grid * kFilterWavesPerBlock * 16)));
     if (abandon)
-        dtw_filter_kernel<NT, SQ, OCC, true><<<dim3(grid), 64 * kFilterWavesPerBlock, 0, st>>>(
+        dtw_filter_kernel<NT, SQ, OCC, true, KU><<<dim3(grid), 64 * kFilterWavesPerBlock, 0, st>>>(
             (const _Float16 *)src.rec, (const _Float16 *)tgt.rec, src.len, tgt.len, (int)src.frames_pad, nPasses,
             (int)tgt.frames_pad, (int)tgt.n_pad, nSrcPairs, nTasks, taskChunk, outScale, handoff, taskCtr, cmat,
             abandon, colCtr, candSlot, rowOrigin, spBase);
     else
-        dtw_filter_kernel<NT, SQ, OCC, false><<<dim3(grid), 64 * kFilterWavesPerBlock, 0, st>>>(
+        dtw_filter_kernel<NT, SQ, OCC, false, KU><<<dim3(grid), 64 * kFilterWavesPerBlock, 0, st>>>(
             (const _Float16 *)src.rec, (const _Float16 *)tgt.rec, src.len, tgt.len, (int)src.frames_pad, nPasses,
             (int)tgt.frames_pad, (int)tgt.n_pad, nSrcPairs, nTasks, taskChunk, outScale, handoff, taskCtr, cmat,
             nullptr, nullptr, nullptr, rowOrigin, spBase);
@@ -396,12 +415,17 @@ int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
     int bound[4] = {0, 0, 0, 0};                    // bound[c]: first pair that needs more than c tiles
     for (int c = 1; c < topTiles; ++c)
         bound[c] = oneLaunch ? 0 : firstAbove(16u * c);
+    // operand planes the kernel multiplies: record layout 3 leaves the third one zero
+    const bool two = filter_mfmas(filter_pieces(filter_dim_used((int)src.dim))) == 2;
+#define SSYM_LAUNCH1(NT_, SQ_, KU_, PASSES_, ORIGIN_, LO_, HI_, K_)                                               \
+    launch_one<NT_, SQ_, KU_>(st, src, tgt, PASSES_, gridBlocks, outScale, hand, taskCtr + (K_) * 8 * kTaskCtrStride, \
+                              cmat, abandon, colCtr, candSlot, LO_, (HI_) - (LO_), ORIGIN_)
 #define SSYM_LAUNCH(NT_, PASSES_, ORIGIN_, LO_, HI_, K_)                                                          \
     if ((HI_) > (LO_)) {                                                                                          \
-        if (sq) launch_one<NT_, true>(st, src, tgt, PASSES_, gridBlocks, outScale, hand, taskCtr + (K_) * 8 * kTaskCtrStride, \
-                                      cmat, abandon, colCtr, candSlot, LO_, (HI_) - (LO_), ORIGIN_);              \
-        else launch_one<NT_, false>(st, src, tgt, PASSES_, gridBlocks, outScale, hand, taskCtr + (K_) * 8 * kTaskCtrStride, \
-                                    cmat, abandon, colCtr, candSlot, LO_, (HI_) - (LO_), ORIGIN_);                \
+        if (sq && two) SSYM_LAUNCH1(NT_, true, 2, PASSES_, ORIGIN_, LO_, HI_, K_);                                \
+        else if (sq) SSYM_LAUNCH1(NT_, true, 3, PASSES_, ORIGIN_, LO_, HI_, K_);                                  \
+        else if (two) SSYM_LAUNCH1(NT_, false, 2, PASSES_, ORIGIN_, LO_, HI_, K_);                                \
+        else SSYM_LAUNCH1(NT_, false, 3, PASSES_, ORIGIN_, LO_, HI_, K_);                                         \
     }
     const int rowsPad = (int)src.frames_pad;
     if (topTiles == 4) {
@@ -427,6 +451,7 @@ int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
         SSYM_LAUNCH(1, 1, 0, 0, nPairs, 0)
     }
 #undef SSYM_LAUNCH
+#undef SSYM_LAUNCH1
     SSYM_HIP_CHECK(ctx, hipGetLastError());
     return SSYM_OK;
 }

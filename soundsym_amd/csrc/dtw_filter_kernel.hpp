@@ -75,17 +75,21 @@ __device__ __forceinline__ f32x16 mfma_tile(const half8 (&a)[KM], const half8 (&
         acc[r] = z + (float)r;
     return acc;
 #else
+#ifndef SSYM_ABL_DROP_MFMA
+#define SSYM_ABL_DROP_MFMA 0      // tools only: issue this many MFMAs fewer per tile (wrong results; what a K = 32 record would save)
+#endif
 #pragma unroll
-    for (int m = 0; m < KM; ++m)
+    for (int m = 0; m < KM - SSYM_ABL_DROP_MFMA; ++m)
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m], b[m], acc, 0, 0, 0);
     return acc;
 #endif
 }
 
-__device__ __forceinline__ void load_rec(const _Float16 *__restrict__ p, half8 (&dst)[kFilterKM])
+template <int KU>
+__device__ __forceinline__ void load_rec(const _Float16 *__restrict__ p, half8 (&dst)[KU])
 {
 #pragma unroll
-    for (int m = 0; m < kFilterKM; ++m)
+    for (int m = 0; m < KU; ++m)
         dst[m] = *reinterpret_cast<const half8 *>(p + 8 * m);
 }
 
@@ -109,18 +113,18 @@ __device__ __forceinline__ void load_tgt_rec(const _Float16 *__restrict__ p, int
 
 // One column of one row block: NT tiles, software-pipelined (the next tile's MFMA chain is in
 // flight while this tile's 16 cells run on the VALU).  Lr = D(., j-1), Lw = D(., j).
-template <int NT, bool SQ>
-__device__ __forceinline__ float dp_column(const half8 (&A)[NT][kFilterKM], const half8 (&Bc)[kFilterKM],
-                                           const half8 (&Bn)[kFilterKM], f32x16 &acc, float up, float diag,
+template <int NT, bool SQ, int KU>
+__device__ __forceinline__ float dp_column(const half8 (&A)[NT][KU], const half8 (&Bc)[KU],
+                                           const half8 (&Bn)[KU], f32x16 &acc, float up, float diag,
                                            const float (&Lr)[NT * 16], float (&Lw)[NT * 16])
 {
 #pragma unroll
     for (int T = 0; T < NT; ++T) {
         f32x16 accn;
         if (T + 1 < NT)
-            accn = mfma_tile<kFilterKM>(A[T + 1], Bc);
+            accn = mfma_tile<KU>(A[T + 1], Bc);
         else
-            accn = mfma_tile<kFilterKM>(A[0], Bn);   // first tile of the next column
+            accn = mfma_tile<KU>(A[0], Bn);   // first tile of the next column
 #if SSYM_FILTER_MODE == 1
         asm volatile("" ::"v"(acc[0]), "v"(acc[15]));
         up = acc[3];
@@ -184,7 +188,10 @@ constexpr int wait_vmcnt(int n) { return 0x0F70 | (n & 15) | ((n >> 4) << 14); }
 // above the thresholds (every path crosses that row; a lane whose source only begins in a later pass
 // keeps the task alive): the remaining passes are skipped and the unfinished lanes report +inf, which
 // selection treats as "never a candidate".  The work per task is then about the area where D <= threshold.
-template <int NT, bool SQ, int OCC = 2, bool PRUNE = false>
+//
+// KU = the operand planes (K = 16 each) a tile multiplies: 3, or 2 for record layout 3 of ssym_internal.hpp, whose
+// third plane is zero -- neither loaded nor staged nor issued (the record strides stay those of three planes).
+template <int NT, bool SQ, int OCC = 2, bool PRUNE = false, int KU = kFilterKM>
 __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_kernel(
     const _Float16 *__restrict__ srcRec, const _Float16 *__restrict__ tgtRec,
     const int *__restrict__ srcLen, const int *__restrict__ tgtLen, int srcRows, int nPasses,
@@ -207,9 +214,9 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_ker
     char *const handRow = reinterpret_cast<char *>(handoff + ((size_t)blockIdx.x * kFilterWavesPerBlock + wave) * handGroups * 256);
     const uint32_t laneOff16 = lane * 16;
     // OCC >= 3 is only instantiated for single-pass shapes: no hand-off traffic is in flight, so the waits
-    // below count column groups of exactly three DMAs
+    // below count column groups of exactly KU DMAs
     constexpr int kFilterRing = filter_ring(OCC);
-    constexpr int kWaitLead = wait_vmcnt(3 * (kFilterRing - 2)), kWaitFirst = wait_vmcnt(3 * (kFilterRing - 1));
+    constexpr int kWaitLead = wait_vmcnt(KU * (kFilterRing - 2)), kWaitFirst = wait_vmcnt(KU * (kFilterRing - 1));
     __shared__ __attribute__((aligned(16))) char ring[kFilterWavesPerBlock][filter_wave_lds(OCC)];
     char *const myRing = ring[wave];
     char *const myTop = myRing + kFilterRing * kFilterSlotBytes;
@@ -303,13 +310,14 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_ker
                 // one LDS base (M0) per column; the instruction offset moves the global and the LDS
                 // address together, which the group-major record layout is made for
                 const char *gb = tgtGroup + (size_t)cc * (kTgtFrameHalfs * 2);       // wave-uniform
-                static_assert(kFilterKM == 3, "three operand planes per column");
+                static_assert(KU == 2 || KU == 3, "two or three operand planes per column");
                 const __attribute__((address_space(1))) void *gp =
                     (const __attribute__((address_space(1))) void *)(gb + laneOff16);
                 __attribute__((address_space(3))) void *lp = (__attribute__((address_space(3))) void *)slot;
                 __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 0);
                 __builtin_amdgcn_global_load_lds(gp, lp, 16, 1024, 0);
-                __builtin_amdgcn_global_load_lds(gp, lp, 16, 2048, 0);
+                if (KU == 3)
+                    __builtin_amdgcn_global_load_lds(gp, lp, 16, 2048, 0);
             };
             // hand-off values of column group g (4 columns) -> top buffer g & 1
             auto stageTop = [&](int g) {
@@ -318,16 +326,16 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_ker
                     (const __attribute__((address_space(1))) void *)(handRow + (size_t)gg * 1024 + laneOff16),
                     (__attribute__((address_space(3))) void *)(myTop + (g & 1) * 1024), 16, 0, 0);
             };
-            auto fetch = [&](int c, half8 (&B)[kFilterKM], float &top) {
+            auto fetch = [&](int c, half8 (&B)[KU], float &top) {
                 const char *slot = myRing + (c & (kFilterRing - 1)) * kFilterSlotBytes;
 #pragma unroll
-                for (int m = 0; m < kFilterKM; ++m)
+                for (int m = 0; m < KU; ++m)
                     B[m] = *reinterpret_cast<const half8 *>(slot + m * 1024 + lane * 16);
                 // read unconditionally (no branch, no wait at a block end); unused when !haveTop
                 top = *reinterpret_cast<const float *>(myTop + ((c >> 2) & 1) * 1024 + lane * 16 + (c & 3) * 4);
             };
             // A operands of this pass: the pad rows above a source carry |a|^2 = +inf
-            half8 A[NT][kFilterKM];
+            half8 A[NT][KU];
             {
                 const int arow = lane & 31;
                 const int a_src = 2 * sp + ((arow >> 2) & 1);
@@ -335,7 +343,7 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_ker
                 const _Float16 *abase = srcRec + ((size_t)a_src * srcRows + a_frm) * REC + half * 24;
 #pragma unroll
                 for (int T = 0; T < NT; ++T)
-                    load_rec(abase + (size_t)T * kFilterRowsPerTile * REC, A[T]);
+                    load_rec<KU>(abase + (size_t)T * kFilterRowsPerTile * REC, A[T]);
             }
 
             asm volatile("" ::: "memory");      // A loads are issued (program order) before the staging DMAs
@@ -356,14 +364,14 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_ker
             float prevTop = INF;                                    // D(rowBase-1, j-1)
 
             // B operands of the current and the next column swap roles every column (no copies)
-            half8 B0[kFilterKM], B1[kFilterKM];
+            half8 B0[KU], B1[KU];
             float topN = INF;                                       // D(rowBase-1, j) for the coming column
             // everything issued so far except the last kFilterRing - 1 column groups has landed
-            // (a group is 3 or 4 DMAs; the A loads are older): column 0 is in its slot
+            // (a group is KU or KU + 1 DMAs; the A loads are older): column 0 is in its slot
             __builtin_amdgcn_s_waitcnt(kWaitFirst);
             asm volatile("" ::: "memory");
             fetch(0, B0, topN);
-            f32x16 acc = mfma_tile<kFilterKM>(A[0], B0);
+            f32x16 acc = mfma_tile<KU>(A[0], B0);
 
             float bq[4] = {INF, INF, INF, INF};                     // bottoms of the current group of 4 columns
             float runBot = INF;                                     // PRUNE: min of this pass's bottoms so far
@@ -381,7 +389,7 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_ker
                         const float diag = (j == 0) ? diagCol0 : prevTop;
                         prevTop = up;
                         // column j+1 was staged kFilterRing - 1 columns ago; at least the two
-                        // groups after it (>= 6 DMAs) are younger, so vmcnt(6) covers it -- and the
+                        // groups after it (>= 2 KU DMAs) are younger, so vmcnt(2 KU) covers it -- and the
                         // hand-off group it may open, which was requested four columns ago
                         __builtin_amdgcn_s_waitcnt(kWaitLead);
                         asm volatile("" ::: "memory");
@@ -396,9 +404,9 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_ker
                             stageTop((j >> 2) + 1);                 // the next group's top values
                         float bottom;
                         if ((q & 1) == 0)
-                            bottom = dp_column<NT, SQ>(A, B0, B1, acc, up, diag, L0, L1);
+                            bottom = dp_column<NT, SQ, KU>(A, B0, B1, acc, up, diag, L0, L1);
                         else
-                            bottom = dp_column<NT, SQ>(A, B1, B0, acc, up, diag, L1, L0);
+                            bottom = dp_column<NT, SQ, KU>(A, B1, B0, acc, up, diag, L1, L0);
                         bq[q] = bottom;
                         if (!lastPass) {
 #ifndef SSYM_ABL_NOHAND

@@ -7,7 +7,8 @@ namespace ssym {
 
 struct MarginParams {
     double inv_scale2;  // 1 / s^2
-    double in_round;    // relative rounding of the operands the filter sees: 2^-22 (two f16 pieces) or 2^-11
+    double in_round_a;  // relative rounding of the SOURCE frames the filter sees: 2^-22 (two f16 pieces) or 2^-11 (one)
+    double in_round_b;  // ... of the TARGET frames (layout 3 of ssym_internal.hpp: source two pieces, target one)
     int squared;
     int lower_only;     // frames wider than the filter takes in: its cost bounds a pair's cost from BELOW only
 };
@@ -18,12 +19,13 @@ __host__ __device__ __forceinline__ double dtw_cell_error(const MarginParams &mp
     const double u = 5.9604644775390625e-8;   // 2^-24
     const double E = 256.0 * u * (na + nb) + 0.000244140625 * mp.inv_scale2;
     double cell;
-    // operands rounded to their f16 piece(s) move every frame by <= in_round * |frame|, hence c by
-    // <= in_round (|a| + |b|) and c^2 by <= 2.05 in_round (|a| + |b|)^2 <= 4.1 in_round (|a|^2 + |b|^2)
+    // operands rounded to their f16 piece(s) move a frame by <= in_round * |frame|, hence c by
+    // <= in_round_a |a| + in_round_b |b| and c^2 by <= 2.05 rho (|a| + |b|)^2 <= 4.1 rho (|a|^2 + |b|^2), rho the larger
     if (mp.squared)
-        cell = E + 4.1 * mp.in_round * (na + nb);
+        cell = E + 4.1 * fmax(mp.in_round_a, mp.in_round_b) * (na + nb);
     else
-        cell = (xmin > 6.0 * E ? E / (2.0 * sqrt(xmin - 2.0 * E)) : sqrt(E)) + 1.001 * mp.in_round * (sqrt(na) + sqrt(nb));
+        cell = (xmin > 6.0 * E ? E / (2.0 * sqrt(xmin - 2.0 * E)) : sqrt(E)) +
+               1.001 * (mp.in_round_a * sqrt(na) + mp.in_round_b * sqrt(nb));
     // f16 pieces below 2^-14 are subnormal: their absolute rounding 2^-25 (scaled units) per value,
     // over at most 42 values of both frames
     cell += 9.5367431640625e-07 * sqrt(mp.inv_scale2);
@@ -53,7 +55,9 @@ inline MarginParams margin_params(const ssym_ctx *ctx, const SegmentSet &src, co
 {
     MarginParams mp;
     mp.inv_scale2 = src.rec_scale > 0.0 ? 1.0 / (src.rec_scale * src.rec_scale) : 1.0;
-    mp.in_round = filter_pieces(filter_dim_used((int)src.dim)) == 2 ? 2.384185791015625e-07 : 4.8828125e-04;
+    const int pieces = filter_pieces(filter_dim_used((int)src.dim));
+    mp.in_round_a = pieces == 1 ? 4.8828125e-04 : 2.384185791015625e-07;
+    mp.in_round_b = pieces == 2 ? 2.384185791015625e-07 : 4.8828125e-04;
     mp.squared = ctx->squared;
     mp.lower_only = filter_lower_bound_only(ctx, src, tgt) ? 1 : 0;
     return mp;

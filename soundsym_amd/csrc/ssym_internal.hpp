@@ -31,8 +31,15 @@ inline FilterShape filter_shape(int max_frames)
     return FilterShape{};   // beyond the filter's reach: exact kernel only
 }
 
-// f16 pieces per value in the filter records: two up to 13 dims, one up to 42 (dtw_filter_kernel.hpp)
-inline int filter_pieces(int dim) { return dim <= 13 ? 2 : 1; }
+// How a frame's values are laid into the filter records (dtw_filter_kernel.hpp):
+//   1  one f16 piece per value, frames of 14...42 values (42 product slots + 6 norm slots of K = 48);
+//   2  two pieces per value on BOTH sides, up to 13 values (3 cross products per value: 39 + 6 slots of K = 48);
+//   3  up to 13 values in K = 32: the SOURCE in two pieces, the TARGET in one (two for its first two values), the
+//      norms those of the represented frames in two pieces each -- two MFMAs per tile instead of three (the third plane
+//      of the records stays zero).  The default for up to 13 values; SSYM_FILTER_K48=1 keeps layout 2 (measurements).
+int filter_pieces(int dim);
+// MFMAs the unbanded filter issues per 32 x 32 tile for that layout
+inline int filter_mfmas(int pieces) { return pieces == 3 ? 2 : 3; }
 // values per frame the filter sees: frames wider than 42 values enter with their first 42 only, which
 // makes the filter's cost a LOWER bound of the pair's cost ("wide frames")
 inline int filter_dim_used(int dim) { return dim <= 42 ? dim : 42; }

@@ -15,7 +15,7 @@ import pytest
 
 from soundsym_amd import Engine
 from soundsym_amd.engine import pack_segments
-from bounds import worst_case_bound as _worst_case_bound
+from bounds import input_rounding, worst_case_bound as _worst_case_bound
 
 pytestmark = pytest.mark.gpu
 EXACT_RTOL = 1e-12
@@ -88,7 +88,10 @@ def test_dtw_filter_subnormal_second_pieces_stay_inside_the_cell_bound():
     x = want ** 2
     certified = x > 8 * E                            # (x >= m - E with m > 6E certain)
     cell = np.where(certified, E / (2 * np.sqrt(np.maximum(x - 3 * E, 1e-300))), np.sqrt(E))
-    cell = cell + 1.001 * 2.0 ** -22 * (np.sqrt(na) + np.sqrt(nb)) + 2.0 ** -20
+    # (the targets are f16 values: whatever the record layout keeps of a target, nothing is rounded away here)
+    in_a, in_b = input_rounding(dim)[0], 0.0
+    assert (tgt.astype(np.float16).astype(np.float32) == tgt).all()
+    cell = cell + 1.001 * (in_a * np.sqrt(na) + in_b * np.sqrt(nb)) + 2.0 ** -20
     bound = 1.02 * cell + 7 * u * filt
     worst = np.abs(filt - want) / bound
     assert (worst <= 1.0).all(), ("filter cell outside the bound of select.hip -- subnormal f16 pieces flushed?",

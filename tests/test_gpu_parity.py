@@ -14,6 +14,7 @@ import pytest
 
 from soundsym_amd import Engine, EmptyDictionaryError, SsymError, synth
 from soundsym_amd.engine import pack_segments
+from bounds import input_rounding
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -134,13 +135,13 @@ def _filter_bound(src, tgt, fa, fb, dim=13):
     """|C~ - C| bound of the f16-split MFMA filter as derived in soundsym_amd/csrc/select.hip
     (worst case over pairs: no use of the per-pair smallest-cell certificate)."""
     u = 2.0 ** -24
-    in_round = 2.0 ** -22 if dim <= 13 else 2.0 ** -11
+    in_a, in_b = input_rounding(min(dim, 42))
     na = max(float((s.astype(np.float64) ** 2).sum(-1).max()) for s in src if s.size)
     nb = max(float((t.astype(np.float64) ** 2).sum(-1).max()) for t in tgt if t.size)
     vmax = max(max(float(np.abs(s).max()) for s in src if s.size), max(float(np.abs(t).max()) for t in tgt if t.size))
     scale = 2.0 ** (6 - math.frexp(vmax)[1]) if vmax > 0 else 1.0
     E = 256 * u * (na + nb) + 2.0 ** -12 / scale ** 2
-    cell = math.sqrt(E) + 1.001 * in_round * (math.sqrt(na) + math.sqrt(nb))
+    cell = math.sqrt(E) + 1.001 * (in_a * math.sqrt(na) + in_b * math.sqrt(nb))
     return (fa + fb - 1) * cell
 
 
@@ -173,9 +174,10 @@ def test_dtw_golden_grid(dtw, oracle):
     bound = _filter_bound(list(g["sources"]), list(g["targets"]), f, f)
     err = np.abs(filt - g["matrix"])
     assert (err <= bound + 1e-5 * g["matrix"]).all(), (err.max(), bound)
-    # non-planted pairs are far from cancellation: there the filter is f32-accurate already
+    # non-planted pairs are far from cancellation: there the filter is f32-accurate already, up to what the record
+    # layout rounds away of the TARGET frames (one f16 piece: 2^-11 per value, far from adding up along a path)
     off_diag = g["matrix"] > 4 * g["cost"].max()
-    assert (err[off_diag] <= 2e-5 * g["matrix"][off_diag]).all()
+    assert (err[off_diag] <= (2e-5 + 0.25 * input_rounding(dim)[1]) * g["matrix"][off_diag]).all()
     # exact kernel on every pair == oracle matrix
     exact = dtw.pair_matrix(d, q, exact=True)
     assert np.allclose(exact, g["matrix"], rtol=EXACT_RTOL, atol=0)
