@@ -25,6 +25,9 @@ constexpr int kBandTgtQuantum = 256;   // targets are padded to this (8 groups o
 #define SSYM_BAND_DYNAMIC_GROUPS 1
 #endif
 constexpr bool kBandDynamicGroups = SSYM_BAND_DYNAMIC_GROUPS != 0;
+#ifndef SSYM_BAND_ABL
+#define SSYM_BAND_ABL 0   // tools only (wrong results, valid timing): 1 = no MFMAs, 2 = no LDS operand reads, 3 = no target loads
+#endif
 constexpr int kBandImagePad = 8;       // halfs between the two sources' LDS images (16 bytes = 4 banks, see the kernel)
 
 // Records of one source in the banded layout: slot s holds frame s - lead, lead = r.
@@ -39,7 +42,8 @@ constexpr int kBandImagePad = 8;       // halfs between the two sources' LDS ima
 // L[k] after column j bounds the pair's cost from below; a wave drops its task when that exceeds the
 // target's threshold on all 64 lanes.  Tasks then differ in length by an order of magnitude, so the
 // waves of a workgroup take target groups from an LDS counter instead of owning one group per block.
-template <int NTB, int WB, int OCC, bool SQ, int LASTN, bool PRUNE = false>
+// KU = operand planes a tile multiplies (2 for record layout 3, whose third plane is zero: dtw_filter_kernel.hpp).
+template <int NTB, int WB, int OCC, bool SQ, int LASTN, bool PRUNE = false, int KU = kFilterKM>
 __global__ __launch_bounds__(64 * WB, OCC) void dtw_band_kernel(
     const _Float16 *__restrict__ srcRec, const _Float16 *__restrict__ tgtRec,
     const int *__restrict__ srcLen, const int *__restrict__ tgtLen, int srcSlots, int radius,
@@ -134,9 +138,9 @@ __global__ __launch_bounds__(64 * WB, OCC) void dtw_band_kernel(
         bool dropped = false;                          // wave-uniform
 
         const _Float16 *bbase = tgtRec + tgt_rec_offset(32 * tg + col, tgtFramesPad, 0, 0, half);
-        half8 B0[kFilterKM], B1[kFilterKM];
+        half8 B0[KU], B1[KU];
 #pragma unroll
-        for (int m = 0; m < kFilterKM; ++m)
+        for (int m = 0; m < KU; ++m)
             B0[m] = half8{0, 0, 0, 0, 0, 0, 0, 0};
         if (nCols > 0)
             load_tgt_rec(bbase, 0, B0);
@@ -146,11 +150,11 @@ __global__ __launch_bounds__(64 * WB, OCC) void dtw_band_kernel(
         // the VALU for ~80 cycles per tile -- and the operands of the step AFTER that are on their way
         // from LDS (An).  Steps run column-major: (j, 0), ..., (j, NTB-1), (j+1, 0), ...
         f32x16 acc;
-        half8 An[kFilterKM];
+        half8 An[KU];
         {
-            half8 A[kFilterKM];
+            half8 A[KU];
             load_rec(aLane, A);                        // column 0, tile 0
-            acc = mfma_tile<kFilterKM>(A, B0);
+            acc = mfma_tile<KU>(A, B0);
             load_rec(aLane + (size_t)(1 / NTB) * REC + (size_t)(1 % NTB) * 16 * REC, An);     // the step after it
         }
 
@@ -162,33 +166,48 @@ __global__ __launch_bounds__(64 * WB, OCC) void dtw_band_kernel(
                 const int j = j0 + par;
                 if (j < nCols) {                       // wave-uniform
                     const int jn = min(j + 1, nCols - 1);
+#if SSYM_BAND_ABL != 3
                     if (par == 0)
                         load_tgt_rec(bbase, jn, B1);
                     else
                         load_tgt_rec(bbase, jn, B0);
+#else
+                    (void)jn;
+                    if (par == 0)
+                        for (int m = 0; m < KU; ++m) B1[m] = B0[m];
+#endif
                     // tile T of column j needs source frames j - r + 16T + local = slots j + 16T + local
                     const _Float16 *aCol = aLane + (size_t)j * REC;
                     float up = INF;
 #pragma unroll
                     for (int T = 0; T < NTB; ++T) {
                         // this step's MFMA operands (loaded during the previous tile) ...
-                        half8 Ac[kFilterKM];
+                        half8 Ac[KU];
 #pragma unroll
-                        for (int m = 0; m < kFilterKM; ++m)
+                        for (int m = 0; m < KU; ++m)
                             Ac[m] = An[m];
                         // ... and the next one's (slots stay inside the staged window)
+#if SSYM_BAND_ABL != 2
                         load_rec(aCol + (size_t)((T + 2) / NTB) * REC + (size_t)((T + 2) % NTB) * 16 * REC, An);
+#else
+                        for (int m = 0; m < KU; ++m)
+                            asm volatile("" : "+v"(An[m]));                               // opaque: no MFMA is merged
+#endif
                         const bool sameCol = T + 1 < NTB;      // the step being issued belongs to column j
                         f32x16 accn = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
                         const int nCells = (T == NTB - 1) ? LASTN : 16;
 #pragma unroll
                         for (int r = 0; r < (T == NTB - 1 ? LASTN : 16); ++r) {
-                            // one MFMA of the chain every few cells (all three at once when the tile has one cell)
+                            // one MFMA of the chain every few cells (all at once when the tile has one cell)
 #pragma unroll
-                            for (int m = 0; m < kFilterKM; ++m)
+                            for (int m = 0; m < KU; ++m)
                                 if (r == (nCells >= 11 ? 5 * m : 0)) {
                                     const half8 &b = ((par == 0) == sameCol) ? B0[m] : B1[m];
+#if SSYM_BAND_ABL == 1
+                                    asm volatile("" : "+v"(accn) : "v"(Ac[m]), "v"(b));   // opaque: nothing folds
+#else
                                     accn = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ac[m], b, accn, 0, 0, 0);
+#endif
                                 }
                             const int k = T * 16 + r;
                             const float x = acc[r];

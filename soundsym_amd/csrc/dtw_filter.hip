@@ -7,10 +7,12 @@
 // The kernel itself is in dtw_filter_kernel.hpp; this file builds its operand records and
 // dispatches the (tiles per wave, row blocks) instantiation for the dictionary's longest segment.
 //
-// Numerics: operands are scaled by a common power of two s so that max |s v| < 64, split into two
-// f16 pieces, squared norms into three; products are exact in the f32 accumulator, the residual
-// per product is <= 2^-22 relative.  The filter's error bound is derived in select.hip; returned
-// costs and indices always come from the exact f64 kernel.
+// Numerics: operands are scaled by a common power of two s so that max |s v| < 64 and split into f16
+// pieces (three record layouts, filter_pieces() in ssym_internal.hpp: up to 13 values per frame the
+// source in two pieces and the target in one, K = 32; wider frames one piece on both sides, K = 48);
+// the squared norms of the REPRESENTED frames ride along in two or three pieces, products are exact in
+// the f32 accumulator.  The filter's error bound is derived in select.hip; returned costs and indices
+// always come from the exact f64 kernel.
 #include "ssym_internal.hpp"
 #include "dtw_filter_kernel.hpp"
 #include "dtw_band_kernel.hpp"
@@ -255,7 +257,9 @@ static int32_t launch_band_cfg2(ssym_ctx *ctx, const SegmentSet &src, const Segm
         return rc;
     unsigned *taskCtr = (unsigned *)ctx->handoff.ptr;
     SSYM_HIP_CHECK(ctx, hipMemsetAsync(taskCtr, 0, sizeof(unsigned), ctx->stream));
-    auto kern = dtw_band_kernel<NTB, WB, OCC, SQ, LASTN, PRUNE>;
+    // operand planes the kernel multiplies: record layout 3 leaves the third one zero
+    const bool two = filter_mfmas(filter_pieces(filter_dim_used((int)src.dim))) == 2;
+    auto kern = two ? dtw_band_kernel<NTB, WB, OCC, SQ, LASTN, PRUNE, 2> : dtw_band_kernel<NTB, WB, OCC, SQ, LASTN, PRUNE, 3>;
     if (lds > 64 * 1024)
         SSYM_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     kern<<<dim3(grid), 64 * WB, lds, ctx->stream>>>(

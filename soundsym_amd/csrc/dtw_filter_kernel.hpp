@@ -11,7 +11,13 @@
 //     f16 pieces each, so the accumulator IS |a - b|^2 (scaled), no VALU add:
 //         K slots 3e+0..3e+2 : (-2a_e)1 * (b_e)1,  (-2a_e)1 * (b_e)2,  (-2a_e)2 * (b_e)1     e < 13
 //         K slots 39..41     : |a|^2 pieces * 1          K slots 42..44 : 1 * |b|^2 pieces
-//     = 45 of the 48 slots of three chained 32x32x16 MFMAs per 32x32 tile.  Frames wider than 13
+//     = 45 of the 48 slots of three chained 32x32x16 MFMAs per 32x32 tile.  That was round 1 (layout 2, still
+//     behind SSYM_FILTER_K48=1); the default for up to 13 values is now layout 3 in K = 32, TWO MFMAs per tile
+//     (template parameter KU = 2), the target rounded to one piece and priced for it by select.hip:
+//         K slots 2e, 2e+1   : (-2a_e)1 * (b_e)1,  (-2a_e)2 * (b_e)1                          e < 13
+//         K slots 26, 27     : (-2a_e)1 * (b_e)2  for e = 0, 1 (the target's first two values keep both pieces)
+//         K slots 28, 29     : |a~|^2 pieces * 1         K slots 30, 31 : 1 * |b~|^2 pieces
+//     Frames wider than 13
 //     values (up to 42) use ONE f16 piece per value (slot e: (-2a_e)1 * (b_e)1, norms after them):
 //     the filter then sees data rounded to 11 bits, which select.hip prices per cell;
 //   * tile = 16 frames of source 0 interleaved (groups of four) with 16 frames of source 1 as the
@@ -40,7 +46,10 @@
 //     recurrence, and the kernel is VALU-bound, not MFMA- or HBM-bound.  Ablations (tools/
 //     filter_bench.hip, -DSSYM_ABL_NOSTAGE / -DSSYM_ABL_NOHAND): the kernel runs 21.1 cycles per
 //     cell at 2.07 GHz; without any per-column memory traffic 19.3 cycles at 2.22 GHz -- the chip
-//     is power-limited, so moving data costs clock as well as cycles.
+//     is power-limited, so moving data costs clock as well as cycles.  The same goes for the matrix pipe: with the
+//     K = 32 records (two MFMAs per tile instead of three) the kernel runs 11.7 % faster (36.8 -> 32.5 ms on
+//     configs[2]) although the pipe was 39 % busy before; WHERE the chain is issued does not matter -- one MFMA every
+//     six cells instead of the compiler's back-to-back placement measured the same to 0.1 ms.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -104,10 +113,11 @@ __host__ __device__ constexpr size_t tgt_rec_offset(uint32_t t, uint32_t slots, 
     return (((size_t)(t >> 5) * slots + j) * kFilterKM + m) * 512 + (size_t)(h * 32 + (t & 31u)) * 8;
 }
 // p = the lane's base for its target and K half (tgt_rec_offset(t, slots, 0, 0, h)); j = frame slot
-__device__ __forceinline__ void load_tgt_rec(const _Float16 *__restrict__ p, int j, half8 (&dst)[kFilterKM])
+template <int KU>
+__device__ __forceinline__ void load_tgt_rec(const _Float16 *__restrict__ p, int j, half8 (&dst)[KU])
 {
 #pragma unroll
-    for (int m = 0; m < kFilterKM; ++m)
+    for (int m = 0; m < KU; ++m)
         dst[m] = *reinterpret_cast<const half8 *>(p + (size_t)j * kTgtFrameHalfs + m * 512);
 }
 

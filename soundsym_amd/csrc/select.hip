@@ -39,6 +39,12 @@ namespace ssym {
 //      frames, so x is the squared distance of the rounded frames; rounding to the f16 piece(s)
 //      moves every frame by <= rho |frame| (rho = 2^-22 with two pieces, 2^-11 with one, dims 14..42)
 //      and therefore c by <= rho (|a| + |b|) -- an absolute term, no square root involved.
+//    * record layout 3 (up to 13 values in K = 32, dtw_filter.hip build_filter_records_kernel): the SOURCE in two
+//      pieces (rho_a = 2^-22), the TARGET in one (rho_b = 2^-11; two for its first two values, where the product
+//      H2a*H2b is dropped as above: <= 4 u (|a|^2 + |b|^2)), norms of the represented frames in TWO f16 pieces
+//      (<= 2^-22 relative each: 4 u (|a|^2 + |b|^2) + 2^-25 absolute), 32 products in two chained MFMAs
+//      (2 * 32 u * 2 (|a|^2 + |b|^2)): together 140 u (|a|^2 + |b|^2) + 2^-12, inside the same E; the rounding
+//      term of a cell is rho_a |a| + rho_b |b| (dtw_margin.hpp in_round_a / in_round_b).
 //  DP: min is exact; each of the <= L = Fa+Fb-1 additions along a path rounds once and v_sqrt_f32 is
 //      within 1 ulp, and DTW is monotone and 1-Lipschitz in the cell costs along the optimal path
 //      of either side, so for EVERY pair

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""tools/band_abl_timing.py -- the banded filter's time on configs[4] (256 frames x 40 values, r = 32) under whatever
+library SSYM_LIB names: the product library, or one built with -DSSYM_BAND_ABL=1|2|3 (no MFMAs / no LDS operand reads /
+no target loads: wrong values, valid timing) to see what each stream of the kernel costs beside the recurrence."""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from soundsym_amd import Engine, synth
+
+n = m = 4096
+f, d, r = 256, 40, 32
+if len(sys.argv) > 1:
+    f, d, r = (int(x) for x in sys.argv[1:4])
+g = synth.make_grid(n, m, f, d, 0x5EED0003)
+e = Engine(metric="dtw", dtype="f32", band=r)
+off = np.arange(n + 1, dtype=np.uint64) * f
+dd, q = e.dictionary(g.sources.reshape(-1), off, d), e.queries(g.targets.reshape(-1), off, d)
+ms = []
+for it in range(6):
+    try:
+        e.match(dd, q)
+    except Exception as ex:            # (wrong filter values may overflow the candidate list: the timing is still valid)
+        print("match raised:", type(ex).__name__)
+    ms.append(e.timings()["main_ms"])
+print(os.environ.get("SSYM_LIB", "product library"), (f, d, r), "filter main_ms:", [round(x, 2) for x in ms[2:]])
