@@ -181,8 +181,8 @@ def secondary_cpu(out: dict) -> None:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3",
                     help="BASELINE.json config: c3 = configs[2] (default, the metric's), c4 = configs[3], c5 = configs[4]")
     ap.add_argument("--no-secondary", action="store_true",
@@ -472,7 +472,7 @@ def main():
                          "frac_with_mfma_issue": cells_per_s / (1024 * 64 / issue_cycles * 2.4e9),
                          "note_mfma_issue": "the same model plus the 8 vector-issue cycles each MFMA of a tile holds the SIMD "
                                             "for: the floor of the instruction stream as written, still at the nominal 2.4 GHz "
-                                            "(the kernel runs power-limited near 2.1 GHz, profiles/)"},
+                                            "(the kernel runs power-limited at 2.1-2.2 GHz, profiles/)"},
                 "recorded_pmc": recorded,
             },
         }
