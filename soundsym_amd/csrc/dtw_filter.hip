@@ -15,6 +15,7 @@
 // always come from the exact f64 kernel.
 #include "ssym_internal.hpp"
 #include "dtw_filter_kernel.hpp"
+#include "dtw_filter_pk_kernel.hpp"
 #include "dtw_band_kernel.hpp"
 
 #include <algorithm>
@@ -232,6 +233,16 @@ static void launch_one(hipStream_t st, const SegmentSet &src, const SegmentSet &
     const long cellsPerTask = (long)(16 * NT * nPasses) * std::max<uint32_t>(tgt.max_frames, 1);
     int taskChunk = (int)std::max(1L, std::min(8L, 8192 / std::max(1L, cellsPerTask)));
     taskChunk = std::max(1, std::min(taskChunk, nTasks / (grid * kFilterWavesPerBlock * 16)));
+    // SSYM_FILTER_PK=1 (experiment, off in the product: +1...1.5 % measured): 64-row passes without early
+    // abandoning on the two-block kernel whose additions are packed (dtw_filter_pk_kernel.hpp)
+    static const bool pkOn = getenv("SSYM_FILTER_PK") && atoi(getenv("SSYM_FILTER_PK")) != 0;
+    if (NT == 4 && !abandon && pkOn) {
+        dtw_filter_pk_kernel<SQ, KU><<<dim3(grid), 64 * kFilterWavesPerBlock, 0, st>>>(
+            (const _Float16 *)src.rec, (const _Float16 *)tgt.rec, src.len, tgt.len, (int)src.frames_pad, nPasses,
+            (int)tgt.frames_pad, (int)tgt.n_pad, nSrcPairs, nTasks, taskChunk, outScale, handoff, taskCtr, cmat,
+            rowOrigin, spBase);
+        return;
+    }
     if (abandon)
         dtw_filter_kernel<NT, SQ, OCC, true, KU><<<dim3(grid), 64 * kFilterWavesPerBlock, 0, st>>>(
             (const _Float16 *)src.rec, (const _Float16 *)tgt.rec, src.len, tgt.len, (int)src.frames_pad, nPasses,

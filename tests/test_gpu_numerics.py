@@ -9,6 +9,7 @@
   cost, so the per-cell claim of select.hip is checked directly.
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -235,3 +236,40 @@ def test_dtw_alternating_amplitudes_reuse_the_dictionary_records(oracle):
             assert (np.abs(filt - mat) <= 16 * bound + 1e-5 * mat).all()
             q.close()
     e.close()
+
+
+_PK_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from soundsym_amd import Engine
+rng = np.random.default_rng(77)
+dim = 13
+def ragged(n, lo, hi, scale):
+    lens = rng.integers(lo, hi + 1, size=n)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    return (rng.standard_normal((int(off[-1]), dim)) * scale).astype(np.float32).reshape(-1), off
+sf, so = ragged(40, 49, 200, 1.0)        # more than 48 frames: the 64-row passes, one to four of them
+tf, to = ragged(70, 1, 150, 1.0)
+e = Engine(metric="dtw", dtype="f32")
+d, q = e.dictionary(sf, so, dim), e.queries(tf, to, dim)
+idx, cost = e.match(d, q)
+np.savez(sys.argv[2], filt=e.pair_matrix(d, q, exact=False), idx=idx, cost=cost)
+"""
+
+
+def test_dtw_filter_packed_add_experiment_is_bit_identical_to_the_product_kernel(tmp_path):
+    # SSYM_FILTER_PK=1 (csrc/dtw_filter_pk_kernel.hpp, off in the product) performs the same IEEE operations per cell in
+    # another order of cells: its whole filter matrix must equal the product kernel's bit for bit
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for name, env in (("plain", {"SSYM_FILTER_PK": "0"}), ("packed", {"SSYM_FILTER_PK": "1"})):
+        path = str(tmp_path / (name + ".npz"))
+        r = subprocess.run([sys.executable, "-c", _PK_SCRIPT, root, path], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[name] = np.load(path)
+    assert np.isfinite(out["plain"]["filt"]).any()
+    assert np.array_equal(out["plain"]["filt"], out["packed"]["filt"], equal_nan=True)
+    assert np.array_equal(out["plain"]["idx"], out["packed"]["idx"]) and np.array_equal(out["plain"]["cost"], out["packed"]["cost"])
