@@ -773,7 +773,9 @@ int32_t launch_dtw_exact(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet 
     const int up4 = (dimr + 3) / 4 * 4;
     const int ldr = bf32 ? up4 + (up4 % 8 == 4 ? 0 : 4) : ((dimr % 4 == 2) ? dimr : dimr + 2);   // exact_ld<>
     // staged target rows: all of them, or (banded) the widest window a 64-row chunk can reach
-    const uint32_t winRows = ctx->band >= 0 ? std::min<uint32_t>(fbEven, 64 + 2 * (uint32_t)ctx->band + 2) : fbEven;
+    // (a chunk of 64 rows reaches 64 + 2 r columns; an even count keeps the rows 16-byte aligned.  Two rows of slack here
+    // cost configs[4] a workgroup per CU: 6 x 26 KB fit the 160 KB, 5 x 27 KB did)
+    const uint32_t winRows = ctx->band >= 0 ? std::min<uint32_t>(fbEven, (64 + 2 * (uint32_t)ctx->band + 1) & ~1u) : fbEven;
     const size_t regLds = 2 * (size_t)fbEven * sizeof(double) + (size_t)winRows * ldr * (bf32 ? sizeof(float) : sizeof(double));
     uint64_t regLo = 0;
     // sources of 65...512 frames: row chunks pipelined over the waves of a workgroup (dtw_exact_pipe_kernel)
