@@ -295,20 +295,19 @@ __global__ __launch_bounds__(64) void dtw_exact_reg_kernel(
             typedef BT d2 __attribute__((ext_vector_type(VPR)));        // one 128-bit read
             constexpr int PW = DIMR / PARTS;              // values fetched at a time
             constexpr int NV = (PW + VPR - 1) / VPR;      // reads per fetch (a row's padding covers the overhang)
-            d2 bv[NV], bn[PARTS == 1 ? NV : 1];
+            // (PARTS == 1: the frames of this step and of the next one live in two register sets that swap roles from
+            // step to step -- copying the prefetched frame over cost NV x 4 v_mov per step, 18 % of the VALU work at 40 values)
+            d2 bA[NV], bB[PARTS == 1 ? NV : 1];
             if (PARTS == 1) {
                 const int jc = min(max(jlo - lane, wlo), whi) - wlo;
                 const d2 *bp = reinterpret_cast<const d2 *>(ldsB + (size_t)jc * LD);
 #pragma unroll
                 for (int e = 0; e < NV; ++e)
-                    bn[e] = bp[e];
+                    bA[e] = bp[e];
             }
-            for (int tau = jlo; tau < tauEnd; ++tau) {
+            auto step = [&](const int tau, d2 (&bv)[NV], d2 (&bn)[PARTS == 1 ? NV : 1]) {
                 const int j = tau - lane;
                 if (PARTS == 1) {
-#pragma unroll
-                    for (int e = 0; e < NV; ++e)
-                        bv[e] = bn[e];
                     // next step's frame (clamped to a valid row; unused when out of range)
                     const int jc = min(max(j + 1, wlo), whi) - wlo;
                     const d2 *bp = reinterpret_cast<const d2 *>(ldsB + (size_t)jc * LD);
@@ -369,6 +368,26 @@ __global__ __launch_bounds__(64) void dtw_exact_reg_kernel(
                     mine = cur;
                 }
                 diagReg = fromAbove;
+            };
+            if constexpr (PARTS == 1 && DIMR > 16) {
+                int tau = jlo;
+                for (; tau + 1 < tauEnd; tau += 2) {
+                    step(tau, bA, bB);
+                    step(tau + 1, bB, bA);
+                }
+                if (tau < tauEnd)
+                    step(tau, bA, bB);
+            } else if constexpr (PARTS == 1) {
+                // narrow frames: the unrolled pair of steps costs more registers (a wave per SIMD) than the copy costs cycles
+                for (int tau = jlo; tau < tauEnd; ++tau) {
+                    step(tau, bA, bB);
+#pragma unroll
+                    for (int e = 0; e < NV; ++e)
+                        bA[e] = bB[e];
+                }
+            } else {
+                for (int tau = jlo; tau < tauEnd; ++tau)
+                    step(tau, bA, bB);
             }
         }
         if ((Fa - 1) % 64 == lane)
