@@ -269,7 +269,7 @@ static int32_t launch_band_cfg2(ssym_ctx *ctx, const SegmentSet &src, const Segm
     unsigned *taskCtr = (unsigned *)ctx->handoff.ptr;
     SSYM_HIP_CHECK(ctx, hipMemsetAsync(taskCtr, 0, sizeof(unsigned), ctx->stream));
     // operand planes the kernel multiplies: record layout 3 leaves the third one zero
-    const bool two = filter_mfmas(filter_pieces(filter_dim_used((int)src.dim))) == 2;
+    const bool two = filter_mfmas(filter_pieces(filter_dim_used((int)src.dim)), filter_dim_used((int)src.dim)) == 2;
     auto kern = two ? dtw_band_kernel<NTB, WB, OCC, SQ, LASTN, PRUNE, 2> : dtw_band_kernel<NTB, WB, OCC, SQ, LASTN, PRUNE, 3>;
     if (lds > 64 * 1024)
         SSYM_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -431,7 +431,7 @@ int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
     for (int c = 1; c < topTiles; ++c)
         bound[c] = oneLaunch ? 0 : firstAbove(16u * c);
     // operand planes the kernel multiplies: record layout 3 leaves the third one zero
-    const bool two = filter_mfmas(filter_pieces(filter_dim_used((int)src.dim))) == 2;
+    const bool two = filter_mfmas(filter_pieces(filter_dim_used((int)src.dim)), filter_dim_used((int)src.dim)) == 2;
 #define SSYM_LAUNCH1(NT_, SQ_, KU_, PASSES_, ORIGIN_, LO_, HI_, K_)                                               \
     launch_one<NT_, SQ_, KU_>(st, src, tgt, PASSES_, gridBlocks, outScale, hand, taskCtr + (K_) * 8 * kTaskCtrStride, \
                               cmat, abandon, colCtr, candSlot, LO_, (HI_) - (LO_), ORIGIN_)

@@ -39,7 +39,8 @@ inline FilterShape filter_shape(int max_frames)
 //      of the records stays zero).  The default for up to 13 values; SSYM_FILTER_K48=1 keeps layout 2 (measurements).
 int filter_pieces(int dim);
 // MFMAs the unbanded filter issues per 32 x 32 tile for that layout
-inline int filter_mfmas(int pieces) { return pieces == 3 ? 2 : 3; }
+// (layout 1 needs dim + 6 slots: frames of 14...26 values fit two planes as well)
+inline int filter_mfmas(int pieces, int dim) { return (pieces == 3 || (pieces == 1 && dim + 6 <= 32)) ? 2 : 3; }
 // values per frame the filter sees: frames wider than 42 values enter with their first 42 only, which
 // makes the filter's cost a LOWER bound of the pair's cost ("wide frames")
 inline int filter_dim_used(int dim) { return dim <= 42 ? dim : 42; }
