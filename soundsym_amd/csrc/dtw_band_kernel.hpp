@@ -14,6 +14,8 @@
 #pragma once
 #include "dtw_filter_kernel.hpp"
 
+#include <type_traits>
+
 namespace ssym {
 
 constexpr int kBandTgtQuantum = 256;   // targets are padded to this (8 groups of 32)
@@ -28,6 +30,10 @@ constexpr bool kBandDynamicGroups = SSYM_BAND_DYNAMIC_GROUPS != 0;
 #ifndef SSYM_BAND_ABL
 #define SSYM_BAND_ABL 0   // tools only (wrong results, valid timing): 1 = no MFMAs, 2 = no LDS operand reads, 3 = no target loads
 #endif
+#ifndef SSYM_BAND_PHASES
+#define SSYM_BAND_PHASES 1      // 0: tools only, every tile of every column (the round-1 loop)
+#endif
+constexpr bool kBandPhases = SSYM_BAND_PHASES != 0;
 constexpr int kBandImagePad = 8;       // halfs between the two sources' LDS images (16 bytes = 4 banks, see the kernel)
 
 // Records of one source in the banded layout: slot s holds frame s - lead, lead = r.
@@ -144,103 +150,131 @@ __global__ __launch_bounds__(64 * WB, OCC) void dtw_band_kernel(
             B0[m] = half8{0, 0, 0, 0, 0, 0, 0, 0};
         if (nCols > 0)
             load_tgt_rec(bbase, 0, B0);
-        // Software pipeline: while the cells of tile T run on the VALU, the three chained MFMAs of the NEXT
-        // step (next tile; after the last tile, tile 0 of the next column) are issued BETWEEN the cells --
+        // Software pipeline: while the cells of tile T run on the VALU, the chained MFMAs of the NEXT
+        // step (next tile; after the last tile, the first tile of the next column) are issued BETWEEN the cells --
         // issued back to back at the top of a tile each waited for its predecessor and kept the wave off
         // the VALU for ~80 cycles per tile -- and the operands of the step AFTER that are on their way
-        // from LDS (An).  Steps run column-major: (j, 0), ..., (j, NTB-1), (j+1, 0), ...
+        // from LDS (An).  Steps run column-major: (j, TLO), ..., (j, THI), (j+1, TLO), ...
+        //
+        // Tiles TLO..THI of a column: the band's corners lie outside the matrix -- above row 0 in the first columns
+        // (tile 0 while j < r - 15), below the longer source's last row in the last ones (the last tile from
+        // j >= faMax + r - 16 (NTB-1), the one before it 16 columns later) -- r (r + 1) cells per pair, 6 % at r = 32.
+        // They cost nothing to leave out (their diagonals hold +inf either way) as long as no test stands in front of
+        // every tile (that variant lost 4.7 %): the column loop runs in up to four PHASES with the tile range a
+        // compile-time constant each.  A phase starts on an even column (the operand registers swap by parity), at
+        // least one column after its tiles have fallen outside (so that their diagonals already hold the +inf the
+        // full kernel computed there), and re-primes the pipeline.
         f32x16 acc;
         half8 An[KU];
-        {
-            half8 A[KU];
-            load_rec(aLane, A);                        // column 0, tile 0
-            acc = mfma_tile<KU>(A, B0);
-            load_rec(aLane + (size_t)(1 / NTB) * REC + (size_t)(1 % NTB) * 16 * REC, An);     // the step after it
-        }
-
-        for (int j0 = 0; j0 < nCols && !dropped; j0 += 2) {
-            if (PRUNE)
-                colSteps += (unsigned)min(2, nCols - j0);
+        auto run_phase = [&](auto tlo_c, auto thi_c, const int jBegin, const int jEnd) {
+            constexpr int TLO = decltype(tlo_c)::value, THI = decltype(thi_c)::value;
+            constexpr int NTP = THI - TLO + 1;                 // tiles per column in this phase
+            if (jBegin >= jEnd || dropped)
+                return;
+            {
+                half8 A[KU];
+                load_rec(aLane + (size_t)jBegin * REC + (size_t)TLO * 16 * REC, A);      // (jBegin, TLO); jBegin is even: B0
+                acc = mfma_tile<KU>(A, B0);
+                load_rec(aLane + (size_t)(jBegin + 1 / NTP) * REC + (size_t)(TLO + 1 % NTP) * 16 * REC, An);   // the step after it
+            }
+            for (int j0 = jBegin; j0 < jEnd && !dropped; j0 += 2) {
+                if (PRUNE)
+                    colSteps += (unsigned)min(2, jEnd - j0);
 #pragma unroll
-            for (int par = 0; par < 2; ++par) {
-                const int j = j0 + par;
-                if (j < nCols) {                       // wave-uniform
-                    const int jn = min(j + 1, nCols - 1);
+                for (int par = 0; par < 2; ++par) {
+                    const int j = j0 + par;
+                    if (j < jEnd) {                        // wave-uniform
+                        const int jn = min(j + 1, nCols - 1);
 #if SSYM_BAND_ABL != 3
-                    if (par == 0)
-                        load_tgt_rec(bbase, jn, B1);
-                    else
-                        load_tgt_rec(bbase, jn, B0);
+                        if (par == 0)
+                            load_tgt_rec(bbase, jn, B1);
+                        else
+                            load_tgt_rec(bbase, jn, B0);
 #else
-                    (void)jn;
-                    if (par == 0)
-                        for (int m = 0; m < KU; ++m) B1[m] = B0[m];
+                        (void)jn;
+                        if (par == 0)
+                            for (int m = 0; m < KU; ++m) B1[m] = B0[m];
 #endif
-                    // tile T of column j needs source frames j - r + 16T + local = slots j + 16T + local
-                    const _Float16 *aCol = aLane + (size_t)j * REC;
-                    float up = INF;
+                        // tile T of column j needs source frames j - r + 16T + local = slots j + 16T + local
+                        const _Float16 *aCol = aLane + (size_t)j * REC;
+                        float up = INF;
 #pragma unroll
-                    for (int T = 0; T < NTB; ++T) {
-                        // this step's MFMA operands (loaded during the previous tile) ...
-                        half8 Ac[KU];
-#pragma unroll
-                        for (int m = 0; m < KU; ++m)
-                            Ac[m] = An[m];
-                        // ... and the next one's (slots stay inside the staged window)
-#if SSYM_BAND_ABL != 2
-                        load_rec(aCol + (size_t)((T + 2) / NTB) * REC + (size_t)((T + 2) % NTB) * 16 * REC, An);
-#else
-                        for (int m = 0; m < KU; ++m)
-                            asm volatile("" : "+v"(An[m]));                               // opaque: no MFMA is merged
-#endif
-                        const bool sameCol = T + 1 < NTB;      // the step being issued belongs to column j
-                        f32x16 accn = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                        const int nCells = (T == NTB - 1) ? LASTN : 16;
-#pragma unroll
-                        for (int r = 0; r < (T == NTB - 1 ? LASTN : 16); ++r) {
-                            // one MFMA of the chain every few cells (all at once when the tile has one cell)
+                        for (int T = TLO; T <= THI; ++T) {
+                            // this step's MFMA operands (loaded during the previous tile) ...
+                            half8 Ac[KU];
 #pragma unroll
                             for (int m = 0; m < KU; ++m)
-                                if (r == (nCells >= 11 ? 5 * m : 0)) {
-                                    const half8 &b = ((par == 0) == sameCol) ? B0[m] : B1[m];
-#if SSYM_BAND_ABL == 1
-                                    asm volatile("" : "+v"(accn) : "v"(Ac[m]), "v"(b));   // opaque: nothing folds
+                                Ac[m] = An[m];
+                            // ... and the next one's (slots stay inside the staged window)
+#if SSYM_BAND_ABL != 2
+                            load_rec(aCol + (size_t)((T - TLO + 2) / NTP) * REC + (size_t)(TLO + (T - TLO + 2) % NTP) * 16 * REC, An);
 #else
-                                    accn = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ac[m], b, accn, 0, 0, 0);
+                            for (int m = 0; m < KU; ++m)
+                                asm volatile("" : "+v"(An[m]));                               // opaque: no MFMA is merged
 #endif
-                                }
-                            const int k = T * 16 + r;
-                            const float x = acc[r];
-                            float c = SQ ? __builtin_fabsf(x) : __builtin_amdgcn_sqrtf(__builtin_fabsf(x));
-                            if (T == NTB - 1 && LASTN > 1)
-                                c = (k <= twoR) ? c : INF;       // diagonals beyond the band (wave-uniform)
-                            const float m3 = __builtin_fminf(__builtin_fminf(up, L[k]), L[k + 1]);
-                            const float cur = c + m3;
-                            L[k] = cur;
-                            up = cur;
+                            const bool sameCol = T < THI;          // the step being issued belongs to column j
+                            f32x16 accn = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                            const int nCells = (T == NTB - 1) ? LASTN : 16;
+#pragma unroll
+                            for (int r = 0; r < (T == NTB - 1 ? LASTN : 16); ++r) {
+                                // one MFMA of the chain every few cells (all at once when the tile has one cell)
+#pragma unroll
+                                for (int m = 0; m < KU; ++m)
+                                    if (r == (nCells >= 11 ? 5 * m : 0)) {
+                                        const half8 &b = ((par == 0) == sameCol) ? B0[m] : B1[m];
+#if SSYM_BAND_ABL == 1
+                                        asm volatile("" : "+v"(accn) : "v"(Ac[m]), "v"(b));   // opaque: nothing folds
+#else
+                                        accn = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ac[m], b, accn, 0, 0, 0);
+#endif
+                                    }
+                                const int k = T * 16 + r;
+                                const float x = acc[r];
+                                float c = SQ ? __builtin_fabsf(x) : __builtin_amdgcn_sqrtf(__builtin_fabsf(x));
+                                if (T == NTB - 1 && LASTN > 1)
+                                    c = (k <= twoR) ? c : INF;       // diagonals beyond the band (wave-uniform)
+                                const float m3 = __builtin_fminf(__builtin_fminf(up, L[k]), L[k + 1]);
+                                const float cur = c + m3;
+                                L[k] = cur;
+                                up = cur;
+                            }
+                            acc = accn;
+                            // keep the scheduler from hoisting every tile's LDS reads and MFMA chains to
+                            // the top of the column (5 accumulators + 15 operand quads live = spills)
+                            __builtin_amdgcn_sched_barrier(0);
                         }
-                        acc = accn;
-                        // keep the scheduler from hoisting every tile's LDS reads and MFMA chains to
-                        // the top of the column (5 accumulators + 15 operand quads live = spills)
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    if (__any(j == fb_m1)) {           // the end cell of some lane's pair is in this column
-                        const bool mine = (j == fb_m1);
+                        if (__any(j == fb_m1)) {           // the end cell of some lane's pair is in this column
+                            const bool mine = (j == fb_m1);
 #pragma unroll
-                        for (int k = 0; k < KB; ++k)
-                            res = (mine && k == kstar) ? L[k] : res;
-                    }
-                    if (PRUNE && par == 1 && (j & (kPruneEvery - 1)) == kPruneEvery - 1) {
-                        float lb = L[0];
+                            for (int k = 0; k < KB; ++k)
+                                res = (mine && k == kstar) ? L[k] : res;
+                        }
+                        if (PRUNE && par == 1 && (j & (kPruneEvery - 1)) == kPruneEvery - 1) {
+                            float lb = L[0];
 #pragma unroll
-                        for (int k = 1; k + 1 < KB; k += 2)
-                            lb = __builtin_fminf(__builtin_fminf(lb, L[k]), L[k + 1]);
-                        if ((KB & 1) == 0)
-                            lb = __builtin_fminf(lb, L[KB - 1]);
-                        dropped = __all(!(lb <= thr) || j >= fb_m1 || dead);
+                            for (int k = 1; k + 1 < KB; k += 2)
+                                lb = __builtin_fminf(__builtin_fminf(lb, L[k]), L[k + 1]);
+                            if ((KB & 1) == 0)
+                                lb = __builtin_fminf(lb, L[KB - 1]);
+                            dropped = __all(!(lb <= thr) || j >= fb_m1 || dead);
+                        }
                     }
                 }
             }
+        };
+        if (kBandPhases && NTB >= 4) {
+            // (wave-uniform bounds; every phase boundary is even and inside [0, nCols])
+            const int faMax = max(__shfl(fa, 0), __shfl(fa, 32));
+            const int head = min(max(radius - 15, 0) & ~1, nCols & ~1);
+            const int out1 = faMax + radius - 16 * (NTB - 1), out2 = out1 + 16;     // first columns with the last tile(s) outside
+            const int tail1 = min(max((max(out1, 0) + 2) & ~1, head), (nCols + 1) & ~1);
+            const int tail2 = min(max((max(out2, 0) + 2) & ~1, tail1), (nCols + 1) & ~1);
+            run_phase(std::integral_constant<int, 1>{}, std::integral_constant<int, NTB - 1>{}, 0, min(head, nCols));
+            run_phase(std::integral_constant<int, 0>{}, std::integral_constant<int, NTB - 1>{}, head, min(tail1, nCols));
+            run_phase(std::integral_constant<int, 0>{}, std::integral_constant<int, (NTB >= 4 ? NTB - 2 : 0)>{}, tail1, min(tail2, nCols));
+            run_phase(std::integral_constant<int, 0>{}, std::integral_constant<int, (NTB >= 4 ? NTB - 3 : 0)>{}, tail2, nCols);
+        } else {
+            run_phase(std::integral_constant<int, 0>{}, std::integral_constant<int, NTB - 1>{}, 0, nCols);
         }
         cmat[(size_t)(2 * sp + half) * mPad + 32 * tg + col] = res * outScale;
       }
