@@ -262,7 +262,7 @@ __global__ __launch_bounds__(64 * WB, OCC) void dtw_band_kernel(
                 }
             }
         };
-        if (kBandPhases && NTB >= 4) {
+        if constexpr (kBandPhases && NTB >= 4 && !PRUNE) {     // (pruned tasks rarely reach their last columns; half the compile time)
             // (wave-uniform bounds; every phase boundary is even and inside [0, nCols])
             const int faMax = max(__shfl(fa, 0), __shfl(fa, 32));
             const int head = min(max(radius - 15, 0) & ~1, nCols & ~1);
@@ -271,8 +271,8 @@ __global__ __launch_bounds__(64 * WB, OCC) void dtw_band_kernel(
             const int tail2 = min(max((max(out2, 0) + 2) & ~1, tail1), (nCols + 1) & ~1);
             run_phase(std::integral_constant<int, 1>{}, std::integral_constant<int, NTB - 1>{}, 0, min(head, nCols));
             run_phase(std::integral_constant<int, 0>{}, std::integral_constant<int, NTB - 1>{}, head, min(tail1, nCols));
-            run_phase(std::integral_constant<int, 0>{}, std::integral_constant<int, (NTB >= 4 ? NTB - 2 : 0)>{}, tail1, min(tail2, nCols));
-            run_phase(std::integral_constant<int, 0>{}, std::integral_constant<int, (NTB >= 4 ? NTB - 3 : 0)>{}, tail2, nCols);
+            run_phase(std::integral_constant<int, 0>{}, std::integral_constant<int, NTB - 2>{}, tail1, min(tail2, nCols));
+            run_phase(std::integral_constant<int, 0>{}, std::integral_constant<int, NTB - 3>{}, tail2, nCols);
         } else {
             run_phase(std::integral_constant<int, 0>{}, std::integral_constant<int, NTB - 1>{}, 0, nCols);
         }
