@@ -269,7 +269,22 @@ def main():
     sharded = world > 1 or force_dist
     comm = None
     if sharded and backend == "nccl":
-        comm = sharding.init_comm(eng, rank, world)       # RCCL communicator behind the C ABI (collective)
+        # RCCL communicator behind the C ABI (collective).  Every rank first says whether it can bind RCCL at all: a rank
+        # that could not would leave the others waiting inside ncclCommInitRank.  If any cannot, ALL ranks run the same
+        # exchange as torch.distributed collectives around the two-phase C-ABI calls (match_sharded_torch) and say so.
+        from soundsym_amd import _native
+        ok = 1
+        try:
+            _native.load_rccl()
+        except Exception as ex:                            # noqa: BLE001 -- reported, and the run continues on the other path
+            ok = 0
+            print(f"rank {rank}: RCCL not bound by the library ({ex}); torch.distributed collectives instead", file=sys.stderr)
+        if world > 1:
+            t = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            ok = int(t.item())
+        if ok:
+            comm = sharding.init_comm(eng, rank, world)
 
     def run_step(oi, oc, prune=False, queries=None):
         qq = q if queries is None else queries
@@ -431,7 +446,8 @@ def main():
                 "sources_per_gpu": hi - lo,
                 "parallelism": (f"source-shard x{n_gpus}, RCCL all-reduce(MIN) of bounds + all-gather of (cost, index) "
                                 f"inside the library" if comm is not None and n_gpus > 1 else
-                                (f"source-shard x{n_gpus} ({backend} rehearsal)" if sharded else "single GPU")),
+                                (f"source-shard x{n_gpus}, {backend} collectives of torch.distributed around the two-phase "
+                                 f"C-ABI calls" if sharded else "single GPU")),
                 "indices_equal_planted": planted_ok,
                 "pairs_refined_f64": int(last.get("n_refined", 0)),
                 "phase_ms": {k: round(float(np.mean(v)), 3) for k, v in stats.items()},
