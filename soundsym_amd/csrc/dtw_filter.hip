@@ -291,20 +291,20 @@ static int32_t launch_band_cfg(ssym_ctx *ctx, const SegmentSet &src, const Segme
 
 // Up to 5 tiles of diagonals (r <= 39) run two waves per SIMD (8-wave workgroups); at 4 and 5 tiles
 // that costs a few register spills but measured 10 % faster than one wave per SIMD at r = 32.
-// 6 tiles run one wave per SIMD (4-wave workgroups) with the whole register file.
-// SSYM_BAND_OCC1=1 forces the one-wave variant for tuning experiments.
+// 6 tiles run one wave per SIMD (4-wave workgroups) with the whole register file.  (Only the variant a tile count
+// uses is instantiated: the other half of the kernels doubled the compile time for a tuning knob.)
 template <int NTB, bool SQ>
 static int32_t launch_band(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, uint32_t slots,
                            size_t lds, float outScale, float *cmat, const float *abandon, unsigned long long *colCtr, const uint32_t *candSlot)
 {
-    static const bool forceOcc1 = getenv("SSYM_BAND_OCC1") != nullptr;
     // radii that are multiples of 8 end exactly one diagonal into their last tile
     const bool last1 = 2 * ctx->band + 1 == 16 * (NTB - 1) + 1;
-    if (NTB <= 5 && !forceOcc1)
+    if constexpr (NTB <= 5)
         return last1 ? launch_band_cfg<NTB, 8, 2, SQ, 1>(ctx, src, tgt, slots, lds, outScale, cmat, abandon, colCtr, candSlot)
                      : launch_band_cfg<NTB, 8, 2, SQ, 16>(ctx, src, tgt, slots, lds, outScale, cmat, abandon, colCtr, candSlot);
-    return last1 ? launch_band_cfg<NTB, 4, 1, SQ, 1>(ctx, src, tgt, slots, lds, outScale, cmat, abandon, colCtr, candSlot)
-                 : launch_band_cfg<NTB, 4, 1, SQ, 16>(ctx, src, tgt, slots, lds, outScale, cmat, abandon, colCtr, candSlot);
+    else
+        return last1 ? launch_band_cfg<NTB, 4, 1, SQ, 1>(ctx, src, tgt, slots, lds, outScale, cmat, abandon, colCtr, candSlot)
+                     : launch_band_cfg<NTB, 4, 1, SQ, 16>(ctx, src, tgt, slots, lds, outScale, cmat, abandon, colCtr, candSlot);
 }
 
 static int32_t launch_dtw_filter_banded(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, float *cmat,
