@@ -22,6 +22,8 @@ import argparse
 import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,7 +38,9 @@ WORKLOADS = {
     "c4": dict(n_src=16384, n_tgt=4096, frames=128, dim=13, band=-1, config="configs[3]"),
     "c5": dict(n_src=4096, n_tgt=4096, frames=256, dim=40, band=32, config="configs[4]"),
 }
-SEED = 0x5EED0003
+# seed 0x5EED0000 + config number (configs[i] is config i + 1); tests/test_gpu_fullsize.py draws the
+# same grids from the same generator
+SEEDS = {"c2": 0x5EED0002, "c3": 0x5EED0003, "c4": 0x5EED0004, "c5": 0x5EED0005}
 PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16/f16 MFMA peak (the cost block runs on the f16 pipe)
 PEAK_HBM_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
@@ -206,6 +210,23 @@ def main():
         wl["band"] = args.band
         custom.append("band")
 
+    SEED = SEEDS[args.workload]
+    # `python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks here, one process per GPU, with
+    # the launcher the driver would have used.  This parent has made no GPU call (nothing above imports torch or the
+    # library), it only waits: rank 0's record reaches stdout through the inherited descriptor, and the exit code is
+    # the launcher's (non-zero when any rank failed).
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and os.environ.get("SSYM_BENCH_FORCE_DIST") != "1":
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "1")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        print("bench.py: launching %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+        sys.exit(subprocess.call(cmd, env=env))
+
     # stdout carries ONE line, the JSON record of rank 0: libraries write there too (RCCL prints a five-line version
     # banner on the first communicator of a process), so file descriptor 1 is pointed at stderr for the run and the
     # record goes to the saved descriptor at the end
@@ -227,9 +248,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if args.gpus > 1 and world == 1:
-        sys.exit("bench.py --gpus N > 1 must be launched with `python -m torch.distributed.run "
-                 "--nproc-per-node N ... bench.py --gpus N` (one rank per GPU)")
+    if os.environ.get("SSYM_BENCH_FAIL_RANK") == str(rank) and world > 1:
+        sys.exit(f"rank {rank}: SSYM_BENCH_FAIL_RANK (tests/test_gpu_bench.py: a dying rank must fail the whole run)")
+    if args.gpus != world and not force_dist:
+        sys.exit(f"bench.py --gpus {args.gpus} inside a launcher with WORLD_SIZE={world}: the two must agree")
     # SSYM_BENCH_BACKEND=gloo rehearses the N > 1 code path on a box with fewer GPUs than ranks: the exchange
     # then runs as torch.distributed collectives over gloo around the two-phase C-ABI calls (RCCL cannot put
     # two ranks on one device); the judged path is the default, RCCL inside the library
@@ -272,13 +294,11 @@ def main():
         # RCCL communicator behind the C ABI (collective).  Every rank first says whether it can bind RCCL at all: a rank
         # that could not would leave the others waiting inside ncclCommInitRank.  If any cannot, ALL ranks run the same
         # exchange as torch.distributed collectives around the two-phase C-ABI calls (match_sharded_torch) and say so.
-        from soundsym_amd import _native
-        ok = 1
-        try:
-            _native.load_rccl()
-        except Exception as ex:                            # noqa: BLE001 -- reported, and the run continues on the other path
-            ok = 0
-            print(f"rank {rank}: RCCL not bound by the library ({ex}); torch.distributed collectives instead", file=sys.stderr)
+        # The probe is the library's own (ssym_comm_available: every RCCL symbol comm.hip calls was bound), not Python's.
+        from soundsym_amd.engine import comm_available
+        ok = 1 if comm_available() else 0
+        if not ok:
+            print(f"rank {rank}: RCCL not bound by the library; torch.distributed collectives instead", file=sys.stderr)
         if world > 1:
             t = torch.tensor([ok], dtype=torch.int32, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
@@ -385,7 +405,27 @@ def main():
 
     secondary = None
     if rank == 0 and n_gpus == 1 and not args.no_secondary:
+        # SURVEY.md 8(d) "H2D of inputs reported separately": the same step through ssym_match_batch, the targets in
+        # (pageable) HOST memory -- upload, packing, records, match, results back, release: what a drop-in
+        # clone_from_dictionary pays per batch.  Never `value`.
+        tflat = np.ascontiguousarray(grid.targets).reshape(-1)
+        for _ in range(2):
+            eng.match_batch(d, tflat, to)
+        hb_n = 5
+        t0 = time.perf_counter()
+        packs = []
+        for _ in range(hb_n):
+            hb_idx, _ = eng.match_batch(d, tflat, to)
+            packs.append(eng.timings()["pack_ms"])
+        hb_dt = (time.perf_counter() - t0) / hb_n
+        host_batch = {"value": pairs_per_step / hb_dt, "unit": "segment-pairs/s", "ms_per_call": hb_dt * 1e3,
+                      "pack_ms": float(np.mean(packs)), "target_bytes": int(tflat.nbytes),
+                      "indices_equal_planted": bool(np.array_equal(hb_idx.astype(np.int64) + 0, grid.planted)),
+                      "resident_ms_per_step": elapsed / args.steps * 1e3,
+                      "note": "ssym_match_batch: targets handed over as host memory every call (PCIe upload + packing = "
+                              "pack_ms, device time), against the same step on resident targets"}
         secondary = secondary_metrics(local_rank)
+        secondary["host_batch"] = host_batch
 
     if rank == 0:
         # Roofline of the dominant kernel (dtw_filter_kernel / dtw_band_kernel).  Its duration is measured live
@@ -422,7 +462,7 @@ def main():
         planes = 2 if ((dd <= 13 and not os.environ.get("SSYM_FILTER_K48")) or 14 <= dd <= 26) else 3
         tiles_per_cell = 1.0 / 16 if r < 0 else float((2 * r + 1 + 15) // 16) / (2 * r + 1)
         issue_cycles = 16.0 + 8.0 * planes * tiles_per_cell
-        scaling = "weak" if (weak or n_gpus == 1) else "strong"
+        scaling = "n/a" if n_gpus == 1 else ("weak" if weak else "strong")
         names = ("main_ms", "select_ms", "refine_ms", "collective_ms", "total_ms", "n_refined", "attempts")
         line = {
             "metric": "segment-pairs/sec (DTW cost+argmin)",

@@ -13,7 +13,7 @@ use std::os::raw::{c_char, c_void};
 #[repr(C)] pub struct SsymComm { _p: [u8; 0] }
 #[repr(C)] pub struct SsymLocalGroup { _p: [u8; 0] }
 
-pub const SSYM_ABI_VERSION: i32 = 2;
+pub const SSYM_ABI_VERSION: i32 = 3;
 
 pub const SSYM_OK: i32 = 0;
 pub const SSYM_E_INVALID: i32 = -1;
@@ -22,6 +22,8 @@ pub const SSYM_E_NO_DEVICE: i32 = -3;
 pub const SSYM_E_HIP: i32 = -4;
 pub const SSYM_E_NOMEM: i32 = -5;
 pub const SSYM_E_UNSUPPORTED: i32 = -6;
+pub const SSYM_E_TIMEOUT: i32 = -7;      // a rank of the sharded match did not arrive; the communicator is aborted
+pub const SSYM_E_COMM: i32 = -8;         // the communicator is dead: destroy it
 
 pub const SSYM_METRIC_REFCOS: i32 = 0;   // the crate's own cosine_sim / at_distance, bit for bit
 pub const SSYM_METRIC_DTW: i32 = 1;
@@ -133,6 +135,10 @@ extern "C" {
 
     // the ranks of ONE process (a thread per rank) without RCCL: host barriers around device copies -- what the
     // one-GPU tests use to run more than one rank (RCCL refuses two ranks on one device)
+    pub fn ssym_comm_available() -> i32;
+    pub fn ssym_comm_set_timeout(comm: *mut SsymComm, milliseconds: i64) -> i32;
+    pub fn ssym_comm_is_dead(comm: *const SsymComm) -> i32;
+    pub fn ssym_comm_inject_fault(comm: *mut SsymComm, phase: i32, kind: i32) -> i32;
     pub fn ssym_local_group_create(world: i32, out: *mut *mut SsymLocalGroup) -> i32;
     pub fn ssym_local_group_destroy(group: *mut SsymLocalGroup) -> i32;
     pub fn ssym_comm_create_local(ctx: *mut SsymCtx, group: *mut SsymLocalGroup, rank: i32, out: *mut *mut SsymComm) -> i32;

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define SSYM_ABI_VERSION 2
+#define SSYM_ABI_VERSION 3
 
 #if defined(__GNUC__)
 #define SSYM_API __attribute__((visibility("default")))
@@ -64,7 +64,12 @@ enum {
     SSYM_E_NO_DEVICE = -3,   /* no usable gfx950 device / HIP runtime -- there is no CPU path    */
     SSYM_E_HIP = -4,         /* a HIP call failed; see ssym_last_error                           */
     SSYM_E_NOMEM = -5,
-    SSYM_E_UNSUPPORTED = -6  /* shape outside what the kernels handle (see DESIGN.md limits)     */
+    SSYM_E_UNSUPPORTED = -6, /* shape outside what the kernels handle (see DESIGN.md limits)     */
+    SSYM_E_TIMEOUT = -7,     /* ssym_match_sharded: a rank did not arrive within the communicator's
+                                deadline; the communicator has been ABORTED (ncclCommAbort) and can
+                                only be destroyed                                                */
+    SSYM_E_COMM = -8         /* the communicator is dead (aborted by an earlier failure on this or
+                                another rank, or RCCL reported an asynchronous error)            */
 };
 
 enum { SSYM_METRIC_REFCOS = 0, SSYM_METRIC_DTW = 1 };
@@ -297,6 +302,18 @@ SSYM_API int32_t ssym_merge_shards_at(ssym_ctx *ctx, uint32_t n_shards, uint32_t
  *                        reports the fold start; a dictionary that is empty on EVERY rank is the caller's to
  *                        reject (the reference panics, src/sound.rs:369).
  *                        out_idx / out_cost / flags as for ssym_match_queries (SSYM_OUT_DEVICE honoured).
+ * FAILURE on one rank is part of the protocol (the reference fails on its one thread, src/sound.rs:369,440-449; a
+ * sharded replacement has to fail on ALL ranks, and may never leave a rank waiting):
+ *   - a rank whose LOCAL work fails (out of memory, a HIP error, a shape the kernels reject, a C++ exception) still
+ *     takes part in every collective of the step with neutral blocks and puts its status code into the block the
+ *     all-gather carries anyway; after the step's one synchronisation EVERY rank returns that same code (the lowest
+ *     failing rank's), ssym_last_error names the rank and the phase, and the communicator stays usable;
+ *   - a rank that cannot take part at all (it cannot allocate its exchange buffers, a collective cannot be enqueued,
+ *     its caller never makes the call) leaves its peers waiting: they wait under a DEADLINE (ssym_comm_set_timeout,
+ *     default 60 s, $SSYM_COMM_TIMEOUT_MS), then abort their communicator (ncclCommAbort) and return
+ *     SSYM_E_TIMEOUT; the rank that could not take part aborts its own and returns its error.  An aborted communicator
+ *     answers every further call with SSYM_E_COMM and can only be destroyed; RCCL's asynchronous errors
+ *     (ncclCommGetAsyncError) end the wait the same way.
  * RCCL is looked up at run time (symbols already in the process, else librccl.so.1 / $SSYM_RCCL_LIB), so a
  * single-GPU user needs no RCCL at all; without it the three calls fail with SSYM_E_UNSUPPORTED. */
 #define SSYM_COMM_ID_BYTES 128
@@ -306,6 +323,18 @@ SSYM_API int32_t ssym_comm_destroy(ssym_ctx *ctx, ssym_comm *comm);
 SSYM_API int32_t ssym_match_sharded(ssym_ctx *ctx, ssym_comm *comm, const ssym_dict *dict, const ssym_queries *q,
                                     const double *distance, uint32_t index_base, uint32_t *out_idx,
                                     double *out_cost, uint32_t flags);
+/* 1 when this library could bind RCCL (every symbol it calls), 0 otherwise: what the ranks of a job agree on BEFORE
+ * any of them enters ssym_comm_create (a rank without RCCL would leave the others inside ncclCommInitRank). */
+SSYM_API int32_t ssym_comm_available(void);
+/* Deadline of one ssym_match_sharded step in milliseconds (> 0); see the failure rules above. */
+SSYM_API int32_t ssym_comm_set_timeout(ssym_comm *comm, int64_t milliseconds);
+/* 1 = the communicator was aborted (every call on it fails with SSYM_E_COMM), 0 = usable. */
+SSYM_API int32_t ssym_comm_is_dead(const ssym_comm *comm);
+/* Fault injection for the containment tests (tests/test_gpu_comm.py), one shot: the NEXT ssym_match_sharded on this
+ * communicator fails in `phase` (1 = the filter phase before the bound exchange, 2 = selection / re-scoring before the
+ * gather).  kind 0: the local work reports SSYM_E_NOMEM (the rank takes part, every rank returns SSYM_E_NOMEM);
+ * kind 1: the rank leaves the step there without its collectives (its peers meet the deadline). */
+SSYM_API int32_t ssym_comm_inject_fault(ssym_comm *comm, int32_t phase, int32_t kind);
 
 /* The ranks of ONE process (a thread per rank, every rank its own context, on one GPU or several) without RCCL:
  * the same ssym_match_sharded, its two exchanges done with host barriers around device copies instead of

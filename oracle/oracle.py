@@ -14,7 +14,23 @@ from typing import Optional, Sequence, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "libssym_oracle.so")
+# SSYM_ORACLE_LIB: a differently built oracle (tools/rulinalg_variants.sh: the other association of rulinalg's dot)
+_LIB = os.environ.get("SSYM_ORACLE_LIB") or os.path.join(_HERE, "libssym_oracle.so")
+
+
+def _rulinalg_combine() -> int:
+    """SSYM_RULINALG_COMBINE: the association of rulinalg's combine step, from include/ssym_rulinalg.h (the constant
+    the C oracle and the product are compiled with); the environment variable of the same name selects the other
+    one for the variant run, in step with -DSSYM_RULINALG_COMBINE on the two native builds."""
+    env = os.environ.get("SSYM_RULINALG_COMBINE")
+    if env is not None:
+        return int(env)
+    import re
+    text = open(os.path.join(os.path.dirname(_HERE), "include", "ssym_rulinalg.h")).read()
+    return int(re.search(r"#ifndef SSYM_RULINALG_COMBINE\s*#define SSYM_RULINALG_COMBINE (\d)", text).group(1))
+
+
+RULINALG_COMBINE = _rulinalg_combine()
 
 _f64p = ctypes.POINTER(ctypes.c_double)
 _u64p = ctypes.POINTER(ctypes.c_uint64)
@@ -24,7 +40,10 @@ _i64p = ctypes.POINTER(ctypes.c_int64)
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (oracle/Makefile).  Returns the library path."""
     src = os.path.join(_HERE, "ssym_oracle.c")
-    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+    hdr = os.path.join(os.path.dirname(_HERE), "include", "ssym_rulinalg.h")
+    if os.environ.get("SSYM_ORACLE_LIB"):
+        return _LIB                                   # a variant built by its own recipe
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s", "libssym_oracle.so"],
                               stdout=subprocess.DEVNULL)
     return _LIB
@@ -55,6 +74,10 @@ class Oracle:
         L = self.lib
         L.ssym_oracle_norm.restype = ctypes.c_double
         L.ssym_oracle_norm.argtypes = [_f64p, ctypes.c_size_t]
+        L.ssym_oracle_rulinalg_combine.restype = ctypes.c_int
+        if L.ssym_oracle_rulinalg_combine() != RULINALG_COMBINE:
+            raise RuntimeError("libssym_oracle.so was built with SSYM_RULINALG_COMBINE=%d, the Python restatement uses %d"
+                               % (L.ssym_oracle_rulinalg_combine(), RULINALG_COMBINE))
         L.ssym_oracle_dot.restype = ctypes.c_double
         L.ssym_oracle_dot.argtypes = [_f64p, _f64p, ctypes.c_size_t]
         L.ssym_oracle_cosine_sim.restype = ctypes.c_double
@@ -284,10 +307,8 @@ def _np_dot(xs, ys, n) -> float:                # rulinalg 0.4.2 utils::dot (see
             p[k] = p[k] + float(xs[i + k]) * float(ys[i + k])
         i += 8
     s = 0.0
-    s = s + (p[0] + p[4])
-    s = s + (p[1] + p[5])
-    s = s + (p[2] + p[6])
-    s = s + (p[3] + p[7])
+    for a, b in ((0, 4), (1, 5), (2, 6), (3, 7)):
+        s = s + (p[a] + p[b]) if RULINALG_COMBINE == 0 else (s + p[a]) + p[b]      # include/ssym_rulinalg.h
     while i < n:
         s = s + float(xs[i]) * float(ys[i])
         i += 1

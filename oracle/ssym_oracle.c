@@ -35,6 +35,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "ssym_rulinalg.h"   /* ../include: the one constant shared with the product (the dot's association) */
+
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -58,9 +60,13 @@ SSYM_ORACLE_API double ssym_oracle_norm(const double *me, size_t n)
 
 /* rulinalg 0.4.2 `utils::dot` (called at src/sound.rs:31), restated from the published crate:
  * eight independent accumulators over blocks of eight, combined as
- *   s += p0+p4; s += p1+p5; s += p2+p6; s += p3+p7;
+ *   s = s + (p0+p4); s = s + (p1+p5); s = s + (p2+p6); s = s + (p3+p7);       (SSYM_RULINALG_COMBINE 0, the default)
+ * or left-associated, s = s + p0 + p4; ...                                    (SSYM_RULINALG_COMBINE 1)
+ * -- which of the two the crate uses could not be checked in this image (its source is not under /root/reference);
+ * the choice is ONE constant shared with the product, include/ssym_rulinalg.h --,
  * then the (len mod 8) tail is added to s one product at a time.  Products and sums are
  * separately rounded (no fused multiply-add under default rustc codegen). */
+#define SSYM_ORACLE_ADD(x, y) ((x) + (y))     /* one rounded f64 addition (-ffp-contract=off) */
 SSYM_ORACLE_API double ssym_oracle_dot(const double *xs, const double *ys, size_t len)
 {
     double s = 0.0;
@@ -76,14 +82,17 @@ SSYM_ORACLE_API double ssym_oracle_dot(const double *xs, const double *ys, size_
         p6 = p6 + xs[i + 6] * ys[i + 6];
         p7 = p7 + xs[i + 7] * ys[i + 7];
     }
-    s = s + (p0 + p4);
-    s = s + (p1 + p5);
-    s = s + (p2 + p6);
-    s = s + (p3 + p7);
+    s = SSYM_RULINALG_STEP(SSYM_ORACLE_ADD, s, p0, p4);     /* association: include/ssym_rulinalg.h */
+    s = SSYM_RULINALG_STEP(SSYM_ORACLE_ADD, s, p1, p5);
+    s = SSYM_RULINALG_STEP(SSYM_ORACLE_ADD, s, p2, p6);
+    s = SSYM_RULINALG_STEP(SSYM_ORACLE_ADD, s, p3, p7);
     for (; i < len; ++i)
         s = s + xs[i] * ys[i];
     return s;
 }
+
+/* which association this build of the oracle uses (tests print it; tools/rulinalg_variants.sh checks it) */
+SSYM_ORACLE_API int ssym_oracle_rulinalg_combine(void) { return SSYM_RULINALG_COMBINE; }
 
 /* src/sound.rs:22-33 */
 SSYM_ORACLE_API double ssym_oracle_cosine_sim(const double *me, size_t nme,

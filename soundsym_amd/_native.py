@@ -22,6 +22,8 @@ SSYM_E_NO_DEVICE = -3
 SSYM_E_HIP = -4
 SSYM_E_NOMEM = -5
 SSYM_E_UNSUPPORTED = -6
+SSYM_E_TIMEOUT = -7
+SSYM_E_COMM = -8
 
 METRIC_REFCOS = 0
 METRIC_DTW = 1
@@ -45,6 +47,7 @@ ABI_SYMBOLS = [
     "ssym_samples_destroy", "ssym_reconstruct", "ssym_mfcc_num_frames", "ssym_mfcc",
     "ssym_comm_unique_id", "ssym_comm_create", "ssym_comm_destroy", "ssym_match_sharded",
     "ssym_local_group_create", "ssym_local_group_destroy", "ssym_comm_create_local",
+    "ssym_comm_available", "ssym_comm_set_timeout", "ssym_comm_is_dead", "ssym_comm_inject_fault",
 ]
 COMM_ID_BYTES = 128        # SSYM_COMM_ID_BYTES
 
@@ -249,6 +252,14 @@ def lib() -> ctypes.CDLL:
     L.ssym_local_group_destroy.argtypes = [vp]
     L.ssym_comm_create_local.restype = i32
     L.ssym_comm_create_local.argtypes = [vp, vp, i32, pvp]
+    L.ssym_comm_available.restype = i32
+    L.ssym_comm_available.argtypes = []
+    L.ssym_comm_set_timeout.restype = i32
+    L.ssym_comm_set_timeout.argtypes = [vp, ctypes.c_int64]
+    L.ssym_comm_is_dead.restype = i32
+    L.ssym_comm_is_dead.argtypes = [vp]
+    L.ssym_comm_inject_fault.restype = i32
+    L.ssym_comm_inject_fault.argtypes = [vp, i32, i32]
     _lib = L
     return L
 

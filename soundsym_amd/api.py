@@ -56,6 +56,41 @@ def _round_half_away(x: float) -> int:
     return int(math.floor(x + 0.5)) if x >= 0 else -int(math.floor(-x + 0.5))
 
 
+def _round_as_usize(x: float) -> int:
+    """`x.round() as usize` (src/sound.rs:422-423): f64::round, then Rust's SATURATING float-to-integer cast -- a
+    negative value or NaN becomes 0, +inf (and anything beyond) usize::MAX."""
+    import math
+    if x != x or x <= 0:
+        return 0
+    if math.isinf(x) or x >= 2.0 ** 64:
+        return 2 ** 64 - 1
+    return _round_half_away(x)
+
+
+class _SoundList(list):
+    """`pub sounds: Vec<Arc<Sound>>` as a list that counts its own mutations: the dictionary's GPU copies are rebuilt
+    when `version` has moved, which costs O(1) per query instead of an identity scan of the whole list."""
+
+    def __init__(self, *a):
+        super().__init__(*a)
+        self.version = 0
+
+
+def _bumping(name):
+    base = getattr(list, name)
+
+    def method(self, *a, **k):
+        self.version += 1
+        return base(self, *a, **k)
+    method.__name__ = name
+    return method
+
+
+for _m in ("append", "extend", "insert", "pop", "remove", "clear", "reverse", "sort", "__setitem__", "__delitem__",
+           "__iadd__", "__imul__"):
+    setattr(_SoundList, _m, _bumping(_m))
+
+
 class Sound:
     """Samples + flat frame-major features of one sound (src/sound.rs:73-82)."""
 
@@ -132,7 +167,7 @@ class SoundDictionary:
     """Cache of Sounds searched by similarity (src/sound.rs:290-371)."""
 
     def __init__(self, engine: Optional[Engine] = None):
-        self.sounds: List[Sound] = []         # `pub sounds: Vec<Arc<Sound>>`
+        self._sounds = _SoundList()           # `pub sounds: Vec<Arc<Sound>>` (the `sounds` property below)
         self._engine = engine
         self._resident = None
         self._resident_key = None
@@ -188,16 +223,25 @@ class SoundDictionary:
     def _dim(self) -> int:
         return self.sounds[0].ncoeffs
 
+    @property
+    def sounds(self) -> List[Sound]:
+        return self._sounds
+
+    @sounds.setter
+    def sounds(self, value) -> None:
+        self._sounds = _SoundList(value)      # a fresh list object: its identity is part of the key below
+
     def _content_key(self):
-        """What `sounds` holds now.  `sounds` is the public, mutable list (`pub sounds`): entries may have been
-        replaced, reordered, or popped and pushed since the last pack, so the length alone does not say.  A Sound's
-        arrays are fixed at construction, hence the OBJECTS are the content; the key keeps them alive, so an
-        identity cannot be reused by a new Sound while the key is held."""
-        return list(self.sounds)
+        """What `sounds` holds now, in O(1).  `sounds` is the public, mutable list (`pub sounds`): entries may have
+        been replaced, reordered, or popped and pushed since the last pack, so the length alone does not say.  The
+        list counts its own mutations (_SoundList.version) and assigning a new list makes a new object, so (the list
+        object, its version) changes whenever the content can have; a Sound's arrays are fixed at construction.  The
+        key holds the list, so its identity cannot be reused while the key is kept."""
+        return (self._sounds, self._sounds.version)
 
     @staticmethod
     def _same(key, now) -> bool:
-        return key is not None and len(key) == len(now) and all(a is b for a, b in zip(key, now))
+        return key is not None and key[0] is now[0] and key[1] == now[1]
 
     def invalidate(self) -> None:
         """Drop the GPU copies (they are rebuilt on the next query)."""
@@ -292,12 +336,14 @@ class SoundSequence:
     @staticmethod
     def from_timestamps(sound: Sound, timestamps, engine: Optional[Engine] = None) -> "SoundSequence":
         """SoundSequence::from_timestamps (src/sound.rs:419-430): one Sound per (start s, end s, label),
-        samples [round(start * rate), round(end * rate)] INCLUSIVE (:422-424), features analysed."""
+        samples [round(start * rate), round(end * rate)] INCLUSIVE (:422-424), features analysed.  The cast is Rust's
+        saturating one: a negative or NaN time reads as sample 0 and the call proceeds; only an end beyond the sound
+        (or a start beyond the end) fails, where the reference's slice panics."""
         out = []
         smp, rate = sound.samples(), sound.sample_rate()
         for start, end, label in timestamps:
-            a, b = _round_half_away(start * rate), _round_half_away(end * rate)      # f64::round, :422-423
-            if a < 0 or b + 1 > smp.size or a > b + 1:
+            a, b = _round_as_usize(start * rate), _round_as_usize(end * rate)        # `.round() as usize`, :422-423
+            if b + 1 > smp.size or a > b + 1:
                 # the reference slices `samples[start_sample..end_sample + 1]` (:424) and panics out of range
                 raise IndexError(f"timestamp ({start}, {end}) -> samples [{a}, {b}] outside the sound's {smp.size} samples")
             out.append(Sound.from_samples(smp[a:b + 1].copy(), rate, None, label, sound.ncoeffs, engine=engine))

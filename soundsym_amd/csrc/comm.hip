@@ -16,12 +16,15 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <thread>
 
 using namespace ssym;
 
@@ -31,6 +34,8 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t *) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
@@ -70,6 +75,8 @@ Rccl load_rccl()
     SSYM_BIND(GetUniqueId, "ncclGetUniqueId")
     SSYM_BIND(CommInitRank, "ncclCommInitRank")
     SSYM_BIND(CommDestroy, "ncclCommDestroy")
+    SSYM_BIND(CommAbort, "ncclCommAbort")
+    SSYM_BIND(CommGetAsyncError, "ncclCommGetAsyncError")
     SSYM_BIND(AllReduce, "ncclAllReduce")
     SSYM_BIND(AllGather, "ncclAllGather")
     SSYM_BIND(GetErrorString, "ncclGetErrorString")
@@ -97,20 +104,39 @@ struct ssym_local_group {
     std::condition_variable cv;
     int arrived = 0;
     unsigned long long gen = 0;
+    bool aborted = false;               // a rank gave up: every barrier, now and later, returns false at once
     std::vector<const void *> slot;     // per rank: the buffer it offers in the current collective
-    void barrier()
+    // false: the group was aborted, or a rank did not arrive within the deadline (which aborts it)
+    bool barrier(int64_t timeout_ms)
     {
         std::unique_lock<std::mutex> lk(m);
+        if (aborted)
+            return false;
         const unsigned long long g = gen;
         if (++arrived == world) {
             arrived = 0;
             ++gen;
             cv.notify_all();
-        } else {
-            cv.wait(lk, [&] { return gen != g; });
+            return true;
         }
+        const bool ok = cv.wait_for(lk, std::chrono::milliseconds(timeout_ms), [&] { return gen != g || aborted; });
+        if (ok && gen != g)
+            return true;            // (a barrier that completed counts even if somebody aborted right after it)
+        aborted = true;
+        cv.notify_all();
+        return false;
+    }
+    void abort()
+    {
+        std::lock_guard<std::mutex> lk(m);
+        aborted = true;
+        cv.notify_all();
     }
 };
+
+// words of list status every rank's gathered block ends with: entries list 1 wanted, "it did not fit", the rank's
+// status code (0 = fine, else -SSYM_E_*) and the phase its local work failed in
+constexpr int kStatusWords = 4;
 
 struct ssym_comm {
     ncclComm_t nccl = nullptr;
@@ -120,7 +146,10 @@ struct ssym_comm {
     DeviceBuf bounds;      // M f64: per-target bounds (and, before them, the candidates' costs of a pruned step)
     DeviceBuf cand;        // M f64: candidates' costs
     DeviceBuf send, recv;  // one block per rank: [M f64 cost][Mpad u32 index][u32 wanted, u32 overflow]
-    uint32_t *status_host = nullptr;    // pinned: world x {wanted, overflow} + {list-2 count, 0}
+    uint32_t *status_host = nullptr;    // pinned: world x kStatusWords + {list-2 count, 0} + the 8 give-up counters of the exact kernel
+    bool dead = false;                  // aborted: every further call answers SSYM_E_COMM
+    int64_t timeout_ms = 60000;         // deadline of one step (ssym_comm_set_timeout, $SSYM_COMM_TIMEOUT_MS)
+    int fault_phase = 0, fault_kind = 0;   // ssym_comm_inject_fault, one shot
     hipEvent_t ev[8]{};    // 0-1 all-reduce of the candidates' costs, 2-3 of the bounds, 4 step start, 5-6 all-gather, 7 step end
 };
 
@@ -133,7 +162,8 @@ struct ssym_comm {
         }                                                                                 \
     } while (0)
 
-__global__ void comm_fill_block_kernel(double *cost, uint32_t *idx, uint32_t *status, double v, uint32_t base, uint32_t n)
+__global__ void comm_fill_block_kernel(double *cost, uint32_t *idx, uint32_t *status, double v, uint32_t base, uint32_t n,
+                                       uint32_t code, uint32_t phase)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
@@ -143,13 +173,24 @@ __global__ void comm_fill_block_kernel(double *cost, uint32_t *idx, uint32_t *st
     if (i == 0) {
         status[0] = 0;
         status[1] = 0;
+        status[2] = code;
+        status[3] = phase;
     }
+}
+
+__global__ void comm_fill_f64_kernel(double *p, double v, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        p[i] = v;
 }
 
 __global__ void comm_status_kernel(const uint32_t *__restrict__ hdr1, uint32_t *__restrict__ status)
 {
     status[0] = hdr1 ? hdr1[0] : 0u;     // entries list 1 wanted
     status[1] = hdr1 ? hdr1[1] : 0u;     // it did not fit
+    status[2] = 0u;                      // this rank's local work went through
+    status[3] = 0u;
 }
 
 static float ev_ms2(hipEvent_t a, hipEvent_t b)
@@ -169,6 +210,28 @@ __global__ void comm_min_rows_kernel(const double *__restrict__ rows, int nRows,
     out[i] = m;
 }
 
+// Give the communicator up: RCCL's kernels of this rank leave their loops (ncclCommAbort), the ranks of an in-process
+// group see the flag at their next barrier.  Peers over RCCL notice nothing by themselves -- they meet their deadline.
+static void comm_abort(ssym_comm *c)
+{
+    if (c->dead)
+        return;
+    c->dead = true;
+    if (c->local)
+        c->local->abort();
+    else if (c->nccl && rccl().ok) {
+        (void)rccl().CommAbort(c->nccl);     // frees the communicator as ncclCommDestroy would
+        c->nccl = nullptr;
+    }
+}
+
+static int32_t local_timeout(ssym_ctx *ctx)
+{
+    ctx->err = "ssym_match_sharded: a rank of the in-process group did not arrive within the deadline (or gave the "
+               "group up); the communicator is aborted";
+    return SSYM_E_TIMEOUT;
+}
+
 // in-process all-gather: every rank copies every rank's block into its own receive buffer
 static int32_t local_all_gather(ssym_ctx *ctx, ssym_comm *c, const void *send, void *recv, size_t bytes)
 {
@@ -178,12 +241,14 @@ static int32_t local_all_gather(ssym_ctx *ctx, ssym_comm *c, const void *send, v
         std::lock_guard<std::mutex> lk(g->m);
         g->slot[c->rank] = send;
     }
-    g->barrier();                                                     // everybody's block is complete and published
+    if (!g->barrier(c->timeout_ms))                                  // everybody's block is complete and published
+        return local_timeout(ctx);
     for (int r = 0; r < c->world; ++r)
         SSYM_HIP_CHECK(ctx, hipMemcpyAsync((char *)recv + (size_t)r * bytes, g->slot[r], bytes, hipMemcpyDeviceToDevice,
                                            ctx->stream));
     SSYM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    g->barrier();                                                     // everybody has read: the blocks may change again
+    if (!g->barrier(c->timeout_ms))                                  // everybody has read: the blocks may change again
+        return local_timeout(ctx);
     return SSYM_OK;
 }
 
@@ -211,12 +276,100 @@ static int32_t comm_all_reduce_min(ssym_ctx *ctx, ssym_comm *c, double *buf, uin
     return SSYM_OK;
 }
 
+// The step's one synchronisation, under the communicator's deadline.  With RCCL the stream holds collectives that only
+// finish when every rank has enqueued its part, so a peer that never arrives would keep hipStreamSynchronize forever:
+// the end-of-step event is polled instead, RCCL's asynchronous error state with it; on expiry the communicator is
+// aborted (its kernels then leave the stream) and the call fails with SSYM_E_TIMEOUT.  The in-process transport has
+// nothing but local work on the stream at this point (its barriers carry the deadline).
+static int32_t comm_wait_step(ssym_ctx *ctx, ssym_comm *c, hipEvent_t done)
+{
+    if (c->local) {
+        SSYM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        return SSYM_OK;
+    }
+    using clock = std::chrono::steady_clock;
+    const clock::time_point t0 = clock::now();
+    const clock::duration limit = std::chrono::milliseconds(c->timeout_ms);
+    for (unsigned spin = 1;; ++spin) {
+        const hipError_t e = hipEventQuery(done);
+        if (e == hipSuccess)
+            return SSYM_OK;
+        if (e != hipErrorNotReady) {
+            ctx->err = std::string("ssym_match_sharded: hipEventQuery: ") + hipGetErrorString(e);
+            return SSYM_E_HIP;
+        }
+        if ((spin & 63u) != 0)
+            continue;
+        const clock::duration waited = clock::now() - t0;
+        ncclResult_t async = ncclSuccess;
+        if (rccl().CommGetAsyncError(c->nccl, &async) == ncclSuccess && async != ncclSuccess && async != ncclInProgress) {
+            ctx->err = std::string("ssym_match_sharded: RCCL reported an asynchronous error: ") + rccl().GetErrorString(async) +
+                       "; the communicator is aborted";
+            comm_abort(c);
+            (void)hipStreamSynchronize(ctx->stream);
+            return SSYM_E_COMM;
+        }
+        if (waited > limit) {
+            ctx->err = "ssym_match_sharded: the step did not complete within " + std::to_string(c->timeout_ms) +
+                       " ms (a rank failed to take part); the communicator is aborted";
+            comm_abort(c);
+            (void)hipStreamSynchronize(ctx->stream);      // the aborted collectives leave the stream
+            return SSYM_E_TIMEOUT;
+        }
+        if (waited > std::chrono::milliseconds(2))
+            std::this_thread::yield();                    // a healthy step is over long before; stop burning the core
+    }
+}
+
+static const char *status_name(int32_t rc)
+{
+    switch (rc) {
+    case SSYM_E_INVALID: return "SSYM_E_INVALID";
+    case SSYM_E_EMPTY_DICT: return "SSYM_E_EMPTY_DICT";
+    case SSYM_E_NO_DEVICE: return "SSYM_E_NO_DEVICE";
+    case SSYM_E_HIP: return "SSYM_E_HIP";
+    case SSYM_E_NOMEM: return "SSYM_E_NOMEM";
+    case SSYM_E_UNSUPPORTED: return "SSYM_E_UNSUPPORTED";
+    case SSYM_E_TIMEOUT: return "SSYM_E_TIMEOUT";
+    case SSYM_E_COMM: return "SSYM_E_COMM";
+    default: return "an unknown status";
+    }
+}
+
+static int64_t default_timeout_ms()
+{
+    const char *e = getenv("SSYM_COMM_TIMEOUT_MS");
+    const long long v = e ? atoll(e) : 0;
+    return v > 0 ? v : 60000;
+}
+
+static int32_t comm_alloc_host(ssym_ctx *ctx, ssym_comm *c, const char *who)
+{
+    c->timeout_ms = default_timeout_ms();
+    hipError_t e = hipHostMalloc((void **)&c->status_host, sizeof(uint32_t) * (kStatusWords * (size_t)c->world + 2 + 8),
+                                 hipHostMallocDefault);
+    for (auto &ev : c->ev)
+        if (e == hipSuccess)
+            e = hipEventCreate(&ev);
+    if (e != hipSuccess) {
+        ctx->err = std::string(who) + ": " + hipGetErrorString(e);
+        return SSYM_E_HIP;
+    }
+    return SSYM_OK;
+}
+
 extern "C" {
+
+int32_t ssym_comm_available(void)
+{
+    return guarded(nullptr, [&]() -> int32_t { return rccl().ok ? 1 : 0; });
+}
 
 int32_t ssym_comm_unique_id(void *out_id)
 {
     if (!out_id)
         return SSYM_E_INVALID;
+    return guarded(nullptr, [&]() -> int32_t {
     if (!rccl().ok)
         return SSYM_E_UNSUPPORTED;
     ncclUniqueId id;
@@ -225,6 +378,7 @@ int32_t ssym_comm_unique_id(void *out_id)
     static_assert(sizeof(id) == SSYM_COMM_ID_BYTES, "RCCL unique id size");
     memcpy(out_id, &id, sizeof(id));
     return SSYM_OK;
+    });
 }
 
 int32_t ssym_comm_create(ssym_ctx *ctx, const void *id, int32_t rank, int32_t world, ssym_comm **out)
@@ -255,14 +409,12 @@ int32_t ssym_comm_create(ssym_ctx *ctx, const void *id, int32_t rank, int32_t wo
         delete c;
         return SSYM_E_HIP;
     }
-    hipError_t e = hipHostMalloc((void **)&c->status_host, sizeof(uint32_t) * 2 * ((size_t)world + 1), hipHostMallocDefault);
-    for (auto &ev : c->ev)
-        if (e == hipSuccess)
-            e = hipEventCreate(&ev);
-    if (e != hipSuccess) {
-        ctx->err = std::string("ssym_comm_create: ") + hipGetErrorString(e);
+    const int32_t rc = comm_alloc_host(ctx, c, "ssym_comm_create");
+    if (rc != SSYM_OK) {
+        const std::string keep = ctx->err;
         ssym_comm_destroy(ctx, c);
-        return SSYM_E_HIP;
+        ctx->err = keep;
+        return rc;
     }
     *out = c;
     return SSYM_OK;
@@ -279,7 +431,7 @@ int32_t ssym_comm_destroy(ssym_ctx *ctx, ssym_comm *c)
         (void)hipStreamSynchronize(ctx->stream);
     }
     if (c->nccl && rccl().ok)
-        (void)rccl().CommDestroy(c->nccl);
+        (void)rccl().CommDestroy(c->nccl);       // (an aborted communicator is gone already: nccl == NULL)
     for (DeviceBuf *b : {&c->bounds, &c->cand, &c->send, &c->recv, &c->local_tmp})
         if (b->ptr)
             (void)hipFree(b->ptr);
@@ -291,6 +443,28 @@ int32_t ssym_comm_destroy(ssym_ctx *ctx, ssym_comm *c)
     delete c;
     return SSYM_OK;
     });
+}
+
+int32_t ssym_comm_set_timeout(ssym_comm *comm, int64_t milliseconds)
+{
+    if (!comm || milliseconds <= 0)
+        return SSYM_E_INVALID;
+    comm->timeout_ms = milliseconds;
+    return SSYM_OK;
+}
+
+int32_t ssym_comm_is_dead(const ssym_comm *comm)
+{
+    return comm ? (comm->dead ? 1 : 0) : SSYM_E_INVALID;
+}
+
+int32_t ssym_comm_inject_fault(ssym_comm *comm, int32_t phase, int32_t kind)
+{
+    if (!comm || phase < 0 || phase > 2 || kind < 0 || kind > 1)
+        return SSYM_E_INVALID;
+    comm->fault_phase = phase;
+    comm->fault_kind = kind;
+    return SSYM_OK;
 }
 
 int32_t ssym_local_group_create(int32_t world, ssym_local_group **out)
@@ -328,14 +502,12 @@ int32_t ssym_comm_create_local(ssym_ctx *ctx, ssym_local_group *group, int32_t r
     c->local = group;
     c->rank = rank;
     c->world = group->world;
-    hipError_t e = hipHostMalloc((void **)&c->status_host, sizeof(uint32_t) * 2 * ((size_t)c->world + 1), hipHostMallocDefault);
-    for (auto &ev : c->ev)
-        if (e == hipSuccess)
-            e = hipEventCreate(&ev);
-    if (e != hipSuccess) {
-        ctx->err = std::string("ssym_comm_create_local: ") + hipGetErrorString(e);
+    const int32_t rc = comm_alloc_host(ctx, c, "ssym_comm_create_local");
+    if (rc != SSYM_OK) {
+        const std::string keep = ctx->err;
         ssym_comm_destroy(ctx, c);
-        return SSYM_E_HIP;
+        ctx->err = keep;
+        return rc;
     }
     *out = c;
     return SSYM_OK;
@@ -352,16 +524,15 @@ struct StreamOnly {      // the phases below only enqueue; restored on every way
     ~StreamOnly() { c->stream_only = false; c->so_cap = 0; }
 };
 
-int32_t match_sharded_impl(ssym_ctx *ctx, ssym_comm *comm, const ssym_dict *dict, const ssym_queries *q,
+// One step.  *agreed = true on return means every rank of the communicator leaves the step with this same status
+// (success, or the failure one of them reported through the gathered block) and the communicator is still in step;
+// any other way out (*agreed false and a status != SSYM_OK) makes the caller abort the communicator.
+int32_t match_sharded_step(ssym_ctx *ctx, ssym_comm *comm, const ssym_dict *dict, const ssym_queries *q,
                            const double *distance, uint32_t index_base, uint32_t *out_idx, double *out_cost,
-                           uint32_t flags)
+                           uint32_t flags, bool *agreed)
 {
-    if (!comm || !dict || !q || !out_idx) {
+    if (!dict || !q || !out_idx) {
         ctx->err = "ssym_match_sharded: NULL argument";
-        return SSYM_E_INVALID;
-    }
-    if (dict->set.n && dict->set.dim != q->set.dim) {
-        ctx->err = "dim mismatch between dictionary and targets";
         return SSYM_E_INVALID;
     }
     const uint32_t M = q->set.n;
@@ -369,6 +540,7 @@ int32_t match_sharded_impl(ssym_ctx *ctx, ssym_comm *comm, const ssym_dict *dict
     tm.n_pairs = (uint64_t)dict->set.n * M;
     if (M == 0) {               // (the targets are the same on every rank: everybody returns here)
         ctx->timings = tm;
+        *agreed = true;
         return SSYM_OK;
     }
     SSYM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -378,10 +550,12 @@ int32_t match_sharded_impl(ssym_ctx *ctx, ssym_comm *comm, const ssym_dict *dict
     const bool refcos = ctx->metric == SSYM_METRIC_REFCOS;
     const bool emptyShard = dict->set.n == 0;
     const double foldStart = refcos ? 2.0 : (double)INFINITY;
+    const int faultPhase = comm->fault_phase, faultKind = comm->fault_kind;
+    comm->fault_phase = comm->fault_kind = 0;       // one shot
 
     // one block per rank: costs, indices (padded to an even count so that blocks stay 8-byte aligned), list status
     const size_t mPad = ((size_t)M + 1) & ~(size_t)1;
-    const size_t blk = sizeof(double) * M + sizeof(uint32_t) * mPad + 2 * sizeof(uint32_t);
+    const size_t blk = sizeof(double) * M + sizeof(uint32_t) * mPad + kStatusWords * sizeof(uint32_t);
     int32_t rc = ensure(ctx, comm->bounds, sizeof(double) * M);
     if (rc == SSYM_OK)
         rc = ensure(ctx, comm->cand, sizeof(double) * M);
@@ -390,7 +564,7 @@ int32_t match_sharded_impl(ssym_ctx *ctx, ssym_comm *comm, const ssym_dict *dict
     if (rc == SSYM_OK)
         rc = ensure(ctx, comm->recv, blk * G);
     if (rc != SSYM_OK)
-        return rc;
+        return rc;               // (without its exchange buffers a rank cannot take part: the caller aborts)
     double *bounds = (double *)comm->bounds.ptr;
     double *sendCost = (double *)comm->send.ptr;
     uint32_t *sendIdx = (uint32_t *)((char *)comm->send.ptr + sizeof(double) * M);
@@ -413,18 +587,61 @@ int32_t match_sharded_impl(ssym_ctx *ctx, ssym_comm *comm, const ssym_dict *dict
     float coll_ms = 0.f;
     const bool wantPrune = ((flags & SSYM_DTW_PRUNE) || ctx->prune_default) && !distance && !refcos;
 
+    // This rank's LOCAL work runs through here.  The first failure is remembered -- status, phase, message --, every
+    // later piece of local work is skipped, and the collectives go on with neutral blocks: the status travels in the
+    // gathered block and every rank returns it after the step's one synchronisation.
+    int32_t failed = SSYM_OK;
+    int failedPhase = 0;
+    std::string failedMsg;
+    auto local = [&](int phase, auto &&work) {
+        if (failed != SSYM_OK)
+            return;
+        int32_t r;
+        try {
+            if (faultPhase == phase && faultKind == 0) {
+                ctx->err = "injected failure (ssym_comm_inject_fault)";
+                r = SSYM_E_NOMEM;
+            } else {
+                r = work();
+            }
+        } catch (const std::bad_alloc &) {
+            ctx->err = "out of host memory";
+            r = SSYM_E_NOMEM;
+        } catch (...) {
+            ctx->err = "unexpected C++ exception inside the library";
+            r = SSYM_E_HIP;
+        }
+        if (r != SSYM_OK) {
+            failed = r;
+            failedPhase = phase;
+            failedMsg = ctx->err;
+        }
+    };
+    auto left_the_step = [&](int phase) {          // ssym_comm_inject_fault, kind 1
+        if (faultPhase != phase || faultKind != 1)
+            return false;
+        ctx->err = "injected failure (ssym_comm_inject_fault): the rank leaves the step without its collectives";
+        return true;
+    };
+    const uint32_t fillGrid = (M + 255) / 256;
+
     // ---- phase 1: candidates (pruned steps), filter, per-target bounds ------------------------------------
+    if (dict->set.n && dict->set.dim != q->set.dim)
+        local(1, [&]() -> int32_t {
+            ctx->err = "dim mismatch between dictionary and targets";
+            return SSYM_E_INVALID;
+        });
     SSYM_HIP_CHECK(ctx, hipEventRecord(cev[4], st));
+    if (left_the_step(1))
+        return SSYM_E_HIP;
     bool pruned = false;
     if (wantPrune) {
         double *cand = (double *)comm->cand.ptr;
-        if (emptyShard) {
-            comm_fill_block_kernel<<<(M + 255) / 256, 256, 0, st>>>(cand, sendIdx, sendStatus, (double)INFINITY, index_base, M);
+        if (!emptyShard)
+            local(1, [&] { return match_candidates_impl(ctx, dict, q, cand); });
+        if (emptyShard || failed != SSYM_OK) {
+            comm_fill_f64_kernel<<<fillGrid, 256, 0, st>>>(cand, (double)INFINITY, M);
             SSYM_HIP_CHECK(ctx, hipGetLastError());
-        } else {
-            rc = match_candidates_impl(ctx, dict, q, cand);
-            if (rc != SSYM_OK)
-                return rc;
         }
         SSYM_HIP_CHECK(ctx, hipEventRecord(cev[0], st));
         rc = comm_all_reduce_min(ctx, comm, cand, M);
@@ -433,15 +650,15 @@ int32_t match_sharded_impl(ssym_ctx *ctx, ssym_comm *comm, const ssym_dict *dict
         SSYM_HIP_CHECK(ctx, hipEventRecord(cev[1], st));
         pruned = true;
     }
-    if (emptyShard) {
-        comm_fill_block_kernel<<<(M + 255) / 256, 256, 0, st>>>(bounds, sendIdx, sendStatus, (double)INFINITY, index_base, M);
+    if (!emptyShard)
+        local(1, [&] {
+            return match_begin_impl(ctx, dict, q, distance, index_base, bounds, pruned ? (const double *)comm->cand.ptr : nullptr);
+        });
+    if (emptyShard || failed != SSYM_OK) {
+        comm_fill_f64_kernel<<<fillGrid, 256, 0, st>>>(bounds, (double)INFINITY, M);
         SSYM_HIP_CHECK(ctx, hipGetLastError());
-    } else {
-        rc = match_begin_impl(ctx, dict, q, distance, index_base, bounds, pruned ? (const double *)comm->cand.ptr : nullptr);
-        if (rc != SSYM_OK)
-            return rc;
     }
-    const bool filterPath = !emptyShard && ctx->pending.filter;
+    const bool filterPath = !emptyShard && failed == SSYM_OK && ctx->pending.filter;
     tm.used_filter = filterPath ? 1 : 0;
     tm.pruned = filterPath && ctx->pending.pruned ? 1 : 0;
     SSYM_HIP_CHECK(ctx, hipEventRecord(cev[2], st));
@@ -452,11 +669,13 @@ int32_t match_sharded_impl(ssym_ctx *ctx, ssym_comm *comm, const ssym_dict *dict
 
     // ---- phase 2 + exchange; repeated once by EVERY rank when any rank's candidate list overflowed -----------
     uint32_t *status = comm->status_host;
+    uint32_t *ownCount = status + kStatusWords * G;          // {list-2 count, 0}
+    uint32_t *gaveUp = ownCount + 2;                         // the exact kernel's 8 give-up counters
     // (the merge compares |cost - distance| for dtw; refcos shards report the key |sim - distance| itself, which the
     //  merge must compare as it is)
     const double *distDev = nullptr;
     if (distance && !refcos) {
-        if (emptyShard) {                           // (otherwise phase 1 has uploaded them)
+        if (emptyShard || failed != SSYM_OK) {      // (otherwise phase 1 has uploaded them)
             rc = ensure(ctx, ctx->dist, sizeof(double) * M);
             if (rc == SSYM_OK)
                 rc = stage_h2d(ctx, ctx->dist.ptr, distance, sizeof(double) * M);
@@ -469,19 +688,25 @@ int32_t match_sharded_impl(ssym_ctx *ctx, ssym_comm *comm, const ssym_dict *dict
     ssym_ctx::Pending keep = ctx->pending;          // (finish consumes it; a second attempt needs it again)
     for (int attempt = 0; attempt < 2; ++attempt) {
         tm.attempts = attempt + 1;
-        if (emptyShard) {
-            comm_fill_block_kernel<<<(M + 255) / 256, 256, 0, st>>>(sendCost, sendIdx, sendStatus, foldStart, index_base, M);
-            SSYM_HIP_CHECK(ctx, hipGetLastError());
-        } else {
-            ctx->pending = keep;
-            ctx->so_hdr1 = ctx->so_hdr2 = nullptr;
-            ctx->so_filter = false;
-            rc = match_finish_impl(ctx, bounds, sendIdx, sendCost, SSYM_OUT_DEVICE | (flags & SSYM_DTW_FORCE_EXACT));
-            if (rc != SSYM_OK)
-                return rc;
+        if (left_the_step(2))
+            return SSYM_E_HIP;
+        bool finished = false;
+        if (!emptyShard)
+            local(2, [&]() -> int32_t {
+                ctx->pending = keep;
+                ctx->so_hdr1 = ctx->so_hdr2 = nullptr;
+                ctx->so_filter = false;
+                const int32_t r = match_finish_impl(ctx, bounds, sendIdx, sendCost, SSYM_OUT_DEVICE | (flags & SSYM_DTW_FORCE_EXACT));
+                finished = r == SSYM_OK;
+                return r;
+            });
+        if (finished) {
             comm_status_kernel<<<1, 1, 0, st>>>(ctx->so_filter ? ctx->so_hdr1 : nullptr, sendStatus);
-            SSYM_HIP_CHECK(ctx, hipGetLastError());
+        } else {          // an empty shard reports the fold start; so does a rank whose local work failed, with its status
+            comm_fill_block_kernel<<<fillGrid, 256, 0, st>>>(sendCost, sendIdx, sendStatus, foldStart, index_base, M,
+                                                             (uint32_t)(-failed), (uint32_t)failedPhase);
         }
+        SSYM_HIP_CHECK(ctx, hipGetLastError());
         SSYM_HIP_CHECK(ctx, hipEventRecord(cev[5], st));
         rc = comm_all_gather(ctx, comm, comm->send.ptr, comm->recv.ptr, blk);
         if (rc != SSYM_OK)
@@ -492,13 +717,17 @@ int32_t match_sharded_impl(ssym_ctx *ctx, ssym_comm *comm, const ssym_dict *dict
                                  userCost, blk / sizeof(double), blk / sizeof(uint32_t));
         if (rc != SSYM_OK)
             return rc;
-        // every rank's list status, and this rank's own list-2 count
-        SSYM_HIP_CHECK(ctx, hipMemcpy2DAsync(status, 2 * sizeof(uint32_t),
-                                             (const char *)comm->recv.ptr + blk - 2 * sizeof(uint32_t), blk,
-                                             2 * sizeof(uint32_t), (size_t)G, hipMemcpyDeviceToHost, st));
-        status[2 * G] = status[2 * G + 1] = 0;
-        if (ctx->so_filter && ctx->so_hdr2)
-            SSYM_HIP_CHECK(ctx, hipMemcpyAsync(status + 2 * G, ctx->so_hdr2, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        // every rank's status words, this rank's own list-2 count and the exact kernel's give-up counters
+        SSYM_HIP_CHECK(ctx, hipMemcpy2DAsync(status, kStatusWords * sizeof(uint32_t),
+                                             (const char *)comm->recv.ptr + blk - kStatusWords * sizeof(uint32_t), blk,
+                                             kStatusWords * sizeof(uint32_t), (size_t)G, hipMemcpyDeviceToHost, st));
+        ownCount[0] = ownCount[1] = 0;
+        const bool ownLists = finished && ctx->so_filter && ctx->so_hdr2;
+        if (ownLists)
+            SSYM_HIP_CHECK(ctx, hipMemcpyAsync(ownCount, ctx->so_hdr2, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        const unsigned pipeMask = ctx->pipe_mask;
+        if (pipeMask && ctx->pipe_flag.ptr)
+            SSYM_HIP_CHECK(ctx, hipMemcpyAsync(gaveUp, ctx->pipe_flag.ptr, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         if (!outDev) {
             rc = stage_d2h(ctx, out_idx, userIdx, sizeof(uint32_t) * M);
             if (rc == SSYM_OK && out_cost)
@@ -507,34 +736,62 @@ int32_t match_sharded_impl(ssym_ctx *ctx, ssym_comm *comm, const ssym_dict *dict
                 return rc;
         }
         SSYM_HIP_CHECK(ctx, hipEventRecord(cev[7], st));
-        SSYM_HIP_CHECK(ctx, hipStreamSynchronize(st));          // the step's one synchronisation
+        rc = comm_wait_step(ctx, comm, cev[7]);             // the step's one synchronisation, under the deadline
+        if (rc != SSYM_OK)
+            return rc;
+        // ---- from here on every rank looks at the same gathered words and takes the same way ----
+        for (int g = 0; g < G; ++g)
+            if (status[kStatusWords * g + 2]) {
+                const int32_t code = -(int32_t)status[kStatusWords * g + 2];
+                const std::string where = "rank " + std::to_string(g) + " of " + std::to_string(G) + ", phase " +
+                                          std::to_string(status[kStatusWords * g + 3]);
+                if (g == comm->rank)
+                    ctx->err = "ssym_match_sharded failed on this rank (" + where + "): " + failedMsg +
+                               "; every rank returns " + status_name(code);
+                else
+                    ctx->err = "ssym_match_sharded failed on " + where + " with " + status_name(code) +
+                               " (ssym_last_error there has the cause); every rank returns it, this rank's results are void";
+                ctx->pending_d2h.clear();
+                ctx->pending.valid = false;
+                *agreed = true;
+                return code;
+            }
+        if (pipeMask) {
+            for (int i = 0; i < 8; ++i)
+                if ((pipeMask >> i & 1u) && gaveUp[i])
+                    ++tm.exact_redone;
+            ctx->pipe_mask = 0;
+        }
         if (attempt == 0)
             coll_ms += ev_ms2(cev[2], cev[3]) + (pruned ? ev_ms2(cev[0], cev[1]) : 0.f);
         coll_ms += ev_ms2(cev[5], cev[6]);
-        if (ctx->so_filter) {
+        if (finished && ctx->so_filter) {
             hipEvent_t *ev = ctx->ev;
             sel_ms += ev_ms2(ev[0], ev[3]);
             ref_ms += ev_ms2(ev[3], ev[4]);
             red_ms += ev_ms2(ev[4], ev[5]);
-            tm.n_refined = status[2 * G];
+            tm.n_refined = ownCount[0];
         }
         bool anyOverflow = false;
         for (int g = 0; g < G; ++g)
-            anyOverflow |= status[2 * g + 1] != 0;
+            anyOverflow |= status[kStatusWords * g + 1] != 0;
         if (!anyOverflow)
             break;
+        *agreed = true;                 // (the two ways out below are taken by every rank alike)
         if (attempt == 1) {
             ctx->err = "dtw: candidate list overflow on a rank of the sharded match";
             return SSYM_E_NOMEM;
         }
         for (int g = 0; g < G; ++g)
-            if (status[2 * g + 1] && status[2 * g] >= 0xffffffffu) {           // (every rank sees it and stops here)
+            if (status[kStatusWords * g + 1] && status[kStatusWords * g] >= 0xffffffffu) {
                 ctx->err = "dtw: too many near-tied candidates for one batch on a rank of the sharded match";
                 return SSYM_E_UNSUPPORTED;
             }
-        if (status[2 * comm->rank + 1])
-            ctx->so_cap = status[2 * comm->rank];               // this rank's list wanted that much
+        *agreed = false;
+        if (status[kStatusWords * comm->rank + 1])
+            ctx->so_cap = status[kStatusWords * comm->rank];    // this rank's list wanted that much
     }
+    *agreed = true;
     stage_finish(ctx);
     if (filterPath) {
         tm.main_launches = 1;
@@ -559,6 +816,44 @@ int32_t match_sharded_impl(ssym_ctx *ctx, ssym_comm *comm, const ssym_dict *dict
         tm.prune_ms = ev_ms2(cev[4], cev[0]);
     ctx->timings = tm;
     return SSYM_OK;
+}
+
+int32_t match_sharded_impl(ssym_ctx *ctx, ssym_comm *comm, const ssym_dict *dict, const ssym_queries *q,
+                           const double *distance, uint32_t index_base, uint32_t *out_idx, double *out_cost,
+                           uint32_t flags)
+{
+    if (!comm) {
+        ctx->err = "ssym_match_sharded: NULL argument";
+        return SSYM_E_INVALID;
+    }
+    if (comm->dead) {
+        ctx->err = "ssym_match_sharded: the communicator was aborted by an earlier failure; destroy it and create a new one";
+        return SSYM_E_COMM;
+    }
+    bool agreed = false;
+    int32_t rc;
+    try {
+        rc = match_sharded_step(ctx, comm, dict, q, distance, index_base, out_idx, out_cost, flags, &agreed);
+    } catch (const std::bad_alloc &) {
+        ctx->err = "out of host memory";
+        rc = SSYM_E_NOMEM;
+    } catch (...) {
+        ctx->err = "unexpected C++ exception inside the library";
+        rc = SSYM_E_HIP;
+    }
+    if (rc != SSYM_OK && !agreed) {
+        // this rank left the step on a way its peers do not know of: whatever it has enqueued may never complete, and
+        // whatever they have enqueued waits for it.  Give the communicator up (RCCL: this rank's collectives leave the
+        // stream; the peers meet their deadline and abort theirs) and drain the stream.
+        const std::string keep = ctx->err;
+        comm_abort(comm);
+        ctx->stream_only = false;
+        (void)hipStreamSynchronize(ctx->stream);
+        ctx->pending_d2h.clear();
+        ctx->pending.valid = false;
+        ctx->err = keep + " [this rank left the sharded step: its communicator is aborted]";
+    }
+    return rc;
 }
 
 }  // namespace

@@ -10,8 +10,9 @@
 // Arithmetic order is the reference's, so results equal the CPU oracle's bit for bit:
 //   * norm: sequential fold per segment, computed once in pack.hip (recomputing it per pair, as the
 //     reference does, yields the same bits);
-//   * dot: rulinalg's eight running sums p0..p7 over blocks of eight elements, combined as
-//     ((((0+(p0+p4))+(p1+p5))+(p2+p6))+(p3+p7)), then the len%8 tail added one product at a time;
+//   * dot: rulinalg's eight running sums p0..p7 over blocks of eight elements, combined in the association
+//     include/ssym_rulinalg.h names (SSYM_RULINALG_COMBINE, shared with the oracle; default
+//     ((((0+(p0+p4))+(p1+p5))+(p2+p6))+(p3+p7))), then the len%8 tail added one product at a time;
 //     every product and sum is rounded separately (no FMA: -ffp-contract=off and __dmul_rn/__dadd_rn);
 //   * the block structure depends on the PAIR's len, so each pair carries its own block count and
 //     switches from the eight sums to the tail exactly where the reference does.
@@ -20,6 +21,7 @@
 // and 32 target segments are staged in LDS (element-major, so lanes read consecutive doubles);
 // each thread keeps 2 x 2 pairs x 8 running sums in registers.
 #include "ssym_internal.hpp"
+#include "ssym_rulinalg.h"
 
 #include <algorithm>
 
@@ -125,10 +127,10 @@ __global__ __launch_bounds__(256) void refcos_sims_kernel(
                             p[a][b][i] = __dadd_rn(p[a][b][i], __dmul_rn(xs[a][i], yt[b][i]));
                     } else if (gm == q[a][b] && !done[a][b]) {
                         double s = 0.0;
-                        s = __dadd_rn(s, __dadd_rn(p[a][b][0], p[a][b][4]));
-                        s = __dadd_rn(s, __dadd_rn(p[a][b][1], p[a][b][5]));
-                        s = __dadd_rn(s, __dadd_rn(p[a][b][2], p[a][b][6]));
-                        s = __dadd_rn(s, __dadd_rn(p[a][b][3], p[a][b][7]));
+                        s = SSYM_RULINALG_STEP(__dadd_rn, s, p[a][b][0], p[a][b][4]);
+                        s = SSYM_RULINALG_STEP(__dadd_rn, s, p[a][b][1], p[a][b][5]);
+                        s = SSYM_RULINALG_STEP(__dadd_rn, s, p[a][b][2], p[a][b][6]);
+                        s = SSYM_RULINALG_STEP(__dadd_rn, s, p[a][b][3], p[a][b][7]);
 #pragma unroll
                         for (int i = 0; i < 8; ++i)
                             if ((unsigned)i < rem[a][b])
@@ -219,10 +221,10 @@ __global__ __launch_bounds__(256) void refcos_match_one_kernel(
     const double p4 = __shfl(p, g0 + 4), p5 = __shfl(p, g0 + 5), p6 = __shfl(p, g0 + 6), p7 = __shfl(p, g0 + 7);
     if (i8 == 0 && s < nSrc) {
         double acc = 0.0;
-        acc = __dadd_rn(acc, __dadd_rn(p0, p4));
-        acc = __dadd_rn(acc, __dadd_rn(p1, p5));
-        acc = __dadd_rn(acc, __dadd_rn(p2, p6));
-        acc = __dadd_rn(acc, __dadd_rn(p3, p7));
+        acc = SSYM_RULINALG_STEP(__dadd_rn, acc, p0, p4);
+        acc = SSYM_RULINALG_STEP(__dadd_rn, acc, p1, p5);
+        acc = SSYM_RULINALG_STEP(__dadd_rn, acc, p2, p6);
+        acc = SSYM_RULINALG_STEP(__dadd_rn, acc, p3, p7);
         for (uint32_t i = 0; i < rem; ++i)
             acc = __dadd_rn(acc, __dmul_rn(srcRaw[base + 8 * qb + i], sq[8 * qb + i]));
         dot = acc;

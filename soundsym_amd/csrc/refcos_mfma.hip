@@ -35,6 +35,7 @@
 // The true first minimum w has key(w) <= key(s) <= key_hi(s) for all s, so key_lo(w) <= threshold: it is
 // among the candidates, and the fold over exact keys in index order returns what the reference returns.
 #include "ssym_internal.hpp"
+#include "ssym_rulinalg.h"
 
 #include <algorithm>
 #include <cmath>
@@ -407,10 +408,10 @@ __global__ __launch_bounds__(256) void refcos_pairs_kernel(
         const double p4 = __shfl(p, g0 + 4), p5 = __shfl(p, g0 + 5), p6 = __shfl(p, g0 + 6), p7 = __shfl(p, g0 + 7);
         if (i8 == 0 && live) {
             double acc = 0.0;
-            acc = __dadd_rn(acc, __dadd_rn(p0, p4));
-            acc = __dadd_rn(acc, __dadd_rn(p1, p5));
-            acc = __dadd_rn(acc, __dadd_rn(p2, p6));
-            acc = __dadd_rn(acc, __dadd_rn(p3, p7));
+            acc = SSYM_RULINALG_STEP(__dadd_rn, acc, p0, p4);      // (the association: include/ssym_rulinalg.h)
+            acc = SSYM_RULINALG_STEP(__dadd_rn, acc, p1, p5);
+            acc = SSYM_RULINALG_STEP(__dadd_rn, acc, p2, p6);
+            acc = SSYM_RULINALG_STEP(__dadd_rn, acc, p3, p7);
             for (uint32_t i = 0; i < rem; ++i)
                 acc = __dadd_rn(acc, __dmul_rn(srcRaw[ba + 8 * qb + i], tgtRaw[bb + 8 * qb + i]));
             const double nrm = __dmul_rn(srcNorm[pr.x], tgtNorm[pr.y]);   // src/sound.rs:30
@@ -477,7 +478,13 @@ bool refcos_mfma_supported(const ssym_ctx *ctx, const SegmentSet &src, const Seg
     const uint64_t maxLen = (uint64_t)std::min(src.max_frames, tgt.max_frames) * src.dim;
     // (its staging reads a tile's first value in place of the values beyond a segment's end: there must be one; a tile's
     //  128 segments are addressed by 32-bit offsets)
-    return (uint64_t)src.n * tgt.n >= 65536 && maxLen <= (1u << 20) && src.total_frames > 0 && tgt.total_frames > 0;
+    // Each SIDE separately: a tile's 128 consecutive segments are addressed relative to the tile's first value with
+    // 32-bit offsets and their lengths are kept as unsigned, so 128 of a side's longest segments must stay below 2^32
+    // values whatever the other side's lengths are (long segments against short ones would otherwise pass the test
+    // on the common prefix and stage wrong data).
+    const uint64_t tileSrc = (uint64_t)src.max_frames * src.dim * 128, tileTgt = (uint64_t)tgt.max_frames * tgt.dim * 128;
+    return (uint64_t)src.n * tgt.n >= 65536 && maxLen <= (1u << 20) && tileSrc < (1ull << 32) && tileTgt < (1ull << 32) &&
+           src.total_frames > 0 && tgt.total_frames > 0;
 }
 
 size_t refcos_list_capacity(uint32_t n_src, uint32_t n_tgt)

@@ -72,6 +72,20 @@ class Comm:
     def __init__(self, engine: "Engine", ptr: int, rank: int, world: int):
         self.engine, self.ptr, self.rank, self.world = engine, ptr, rank, world
 
+    def set_timeout(self, milliseconds: int) -> None:
+        """ssym_comm_set_timeout: the deadline of one match_sharded step (a rank that never arrives)."""
+        nat.check(nat.lib().ssym_comm_set_timeout(self.ptr, int(milliseconds)), self.engine.ctx)
+
+    @property
+    def dead(self) -> bool:
+        """ssym_comm_is_dead: aborted by a failure; every further step raises SSYM_E_COMM."""
+        return bool(self.ptr) and nat.lib().ssym_comm_is_dead(self.ptr) == 1
+
+    def inject_fault(self, phase: int, kind: int) -> None:
+        """ssym_comm_inject_fault (containment tests): the next step fails in `phase`; kind 0 = the local work
+        reports an error and the rank takes part, kind 1 = the rank leaves the step without its collectives."""
+        nat.check(nat.lib().ssym_comm_inject_fault(self.ptr, phase, kind), self.engine.ctx)
+
     def close(self):
         if self.ptr and self.engine.ctx:
             nat.lib().ssym_comm_destroy(self.engine.ctx, self.ptr)
@@ -82,6 +96,16 @@ class Comm:
             self.close()
         except Exception:
             pass
+
+
+def comm_available() -> bool:
+    """ssym_comm_available: the library itself could bind every RCCL symbol it calls (what the ranks of a job agree
+    on before any of them enters comm_create)."""
+    try:
+        nat.load_rccl()
+    except ImportError:
+        pass                  # (the library still looks for librccl.so.1 / $SSYM_RCCL_LIB by itself)
+    return nat.lib().ssym_comm_available() == 1
 
 
 class LocalGroup:

@@ -95,12 +95,22 @@ def init_comm(engine, rank: int, world: int, group=None):
         raise RuntimeError("init_comm with world > 1 needs an initialised torch.distributed group to hand the id over")
     on_gpu = dist.get_backend(group) == "nccl"
     dev = torch.device("cuda", engine.device) if on_gpu else torch.device("cpu")
+    # byte 0: rank 0 could draw the id.  A failure on rank 0 reaches every rank here, BEFORE any of them enters
+    # ncclCommInitRank (which would wait for rank 0 for ever); all ranks then raise the same error.
+    msg = bytearray(1 + 128)
+    why = ""
     if rank == 0:
-        t = torch.frombuffer(bytearray(comm_unique_id()), dtype=torch.uint8).to(dev)
-    else:
-        t = torch.zeros(128, dtype=torch.uint8, device=dev)
+        try:
+            msg[1:] = comm_unique_id()
+            msg[0] = 1
+        except Exception as ex:                                # noqa: BLE001 -- reported on every rank below
+            why = f": {ex}"
+    t = torch.frombuffer(msg, dtype=torch.uint8).to(dev) if rank == 0 else torch.zeros(129, dtype=torch.uint8, device=dev)
     dist.broadcast(t, src=0, group=group)
-    return engine.comm_create(bytes(t.cpu().numpy().tobytes()), rank, world)
+    raw = bytes(t.cpu().numpy().tobytes())
+    if raw[0] != 1:
+        raise RuntimeError("init_comm: rank 0 could not obtain an RCCL unique id (ssym_comm_unique_id)" + why)
+    return engine.comm_create(raw[1:], rank, world)
 
 
 def match_sharded(engine, comm, d, q, index_base, out_idx=None, out_cost=None, distance=None, prune=False):

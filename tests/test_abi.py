@@ -20,7 +20,7 @@ def test_header_and_binding_list_agree():
 def test_library_exports_every_declared_symbol(native_lib):
     for name in _declared():
         assert hasattr(native_lib, name), name
-    assert native_lib.ssym_abi_version() == 2
+    assert native_lib.ssym_abi_version() == 3
 
 
 def test_struct_layouts_match_header():

@@ -28,7 +28,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
         assert key in line, key
     assert line["metric"] == "segment-pairs/sec (DTW cost+argmin)" and line["unit"] == "segment-pairs/s"
     assert line["n_gpus"] == 1 and line["steps"] == 2 and line["warmup"] == 1 and line["higher_is_better"] is True
-    assert line["scaling"] == "weak" and line["vs_baseline"] is None and line["dtype"] == "f32" and line["data"] == "synthetic"
+    assert line["scaling"] == "n/a" and line["vs_baseline"] is None and line["dtype"] == "f32" and line["data"] == "synthetic"
     assert "workload" in line["config"] and line["config"]["indices_equal_planted"] is True
     rl = line["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
@@ -42,7 +42,9 @@ def test_bench_early_abandon_leg_is_identical_to_the_full_search():
     ea = line["early_abandon"]
     assert ea["identical_to_full_search"] is True and ea["value"] > 0
     assert 0 < ea["filter_cells_swept_frac"] <= 1
-    assert set(line["secondary"]) >= {"refcos", "chain", "mfcc", "match_one"}
+    assert set(line["secondary"]) >= {"refcos", "chain", "mfcc", "match_one", "host_batch"}
+    hb = line["secondary"]["host_batch"]
+    assert hb["indices_equal_planted"] is True and hb["pack_ms"] > 0 and hb["ms_per_call"] > 0
     ncp = ea["no_close_pair"]
     assert ncp["identical_to_full_search"] is True and ncp["pruned_ms_per_step"] > 0
 
@@ -53,7 +55,7 @@ def test_bench_sharded_path_through_the_library_collectives():
                 shape=("--sources", "512", "--targets", "256", "--frames", "64"))
     assert line["config"]["indices_equal_planted"] is True and line["config"]["collective_ms"] > 0
     assert line["config"]["per_rank"][0]["attempts"] == 1
-    assert line["scaling"] == "weak" and line["n_gpus"] == 1      # (strong is reported from 2 GPUs on)
+    assert line["scaling"] == "n/a" and line["n_gpus"] == 1       # (strong is reported from 2 GPUs on)
 
 
 def test_bench_banded_workload_shape():
@@ -79,3 +81,33 @@ def test_bench_two_ranks_rehearsal_over_gloo():
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["sources_per_gpu"] == 256
     assert line["config"]["indices_equal_planted"] is True and len(line["config"]["per_rank"]) == 2
     assert abs(line["value"] - 512 * 256 / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-6
+
+
+def test_bench_gpus_2_starts_its_own_ranks():
+    # the driver's command shape for one GPU, with --gpus 2 and NO launcher around it: bench.py starts the two ranks
+    # itself (before any GPU call of its own), relays rank 0's one line and the launcher's exit code.  gloo here
+    # because the box has one GPU; on a multi-GPU node the same command runs RCCL inside the library.
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["SSYM_BENCH_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--no-secondary", "--sources", "512", "--targets", "256", "--frames", "64"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["sources_per_gpu"] == 256
+    assert line["config"]["indices_equal_planted"] is True and len(line["config"]["per_rank"]) == 2
+
+
+def test_bench_self_launch_relays_a_failing_rank():
+    # a rank that dies makes the whole run exit non-zero and print no record (SSYM_BENCH_FAIL_RANK makes rank 1 exit
+    # before it joins the process group; the launcher then ends rank 0 as well)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["SSYM_BENCH_BACKEND"] = "gloo"
+    env["SSYM_BENCH_FAIL_RANK"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--no-secondary", "--sources", "128", "--targets", "64", "--frames", "16"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.strip().splitlines() if l.startswith("{")]

@@ -237,3 +237,143 @@ def test_multi_rank_one_rank_overflows_and_every_rank_repeats(oracle):
         assert tm["attempts"] == 2, (r, tm)
         assert np.array_equal(idx, want_idx) and np.allclose(cost, want_cost, rtol=1e-12, atol=0)
     assert (want_idx == 0).all()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Failure containment (include/soundsym_amd.h, "FAILURE on one rank is part of the protocol"): no rank may be left
+# waiting, and a failure that can still be reported is reported by EVERY rank with the same status.
+# ---------------------------------------------------------------------------------------------------------
+def _run_ranks_with_fault(world, fault_rank, phase, kind, timeout_ms=20000, absent_rank=None, steps_after=1):
+    """A thread per rank on the one GPU (in-process transport).  Returns per rank a dict: the status code the faulty
+    step raised (None = no error), the seconds it took, whether the communicator is dead, and what a further step on
+    the same communicator did."""
+    import threading
+    import time
+    from soundsym_amd import _native as nat
+    from soundsym_amd.engine import LocalGroup
+    n, m, f, dim = 240, 96, 24, 13
+    g = synth.make_grid(n, m, f, dim, 0x5EED0A70)
+    to = np.arange(m + 1, dtype=np.uint64) * f
+    e0 = Engine(metric="dtw", dtype="f32")
+    so = np.arange(n + 1, dtype=np.uint64) * f
+    want = e0.match(e0.dictionary(g.sources.reshape(-1), so, dim), e0.queries(g.targets.reshape(-1), to, dim))
+    e0.close()
+    shards, bases = _split(list(g.sources), world, dim, np.float32)
+    group = LocalGroup(world)
+    res = [dict() for _ in range(world)]
+    ready = threading.Barrier(world)
+
+    def rank_main(r):
+        try:
+            e = Engine(metric="dtw", dtype="f32")
+            d = e.dictionary(shards[r][0], shards[r][1], dim)
+            q = e.queries(g.targets.reshape(-1), to, dim)
+            comm = e.comm_create_local(group, r)
+            comm.set_timeout(timeout_ms)
+            idx, cost = e.match_sharded(comm, d, q, index_base=bases[r])         # a healthy step first
+            res[r]["healthy"] = bool(np.array_equal(idx, want[0]) and np.array_equal(cost, want[1]))
+            if r == fault_rank:
+                comm.inject_fault(phase, kind)
+            ready.wait(timeout=120)
+            t0 = time.perf_counter()
+            code = None
+            if r != absent_rank:
+                try:
+                    e.match_sharded(comm, d, q, index_base=bases[r])
+                except nat.SsymError as ex:
+                    code, res[r]["msg"] = ex.code, str(ex)
+            res[r]["code"], res[r]["seconds"] = code, time.perf_counter() - t0
+            res[r]["dead"] = comm.dead
+            after = []
+            for _ in range(steps_after):
+                try:
+                    idx, cost = e.match_sharded(comm, d, q, index_base=bases[r])
+                    after.append(bool(np.array_equal(idx, want[0]) and np.array_equal(cost, want[1])))
+                except nat.SsymError as ex:
+                    after.append(ex.code)
+            res[r]["after"] = after
+            comm.close()
+            e.close()
+        except Exception as ex:                                  # noqa: BLE001
+            res[r]["crash"] = repr(ex)
+            try:
+                ready.abort()
+            except Exception:
+                pass
+
+    threads = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+        assert not t.is_alive(), "a rank is still waiting: the containment failed"
+    group.close()
+    for r in range(world):
+        assert "crash" not in res[r], (r, res[r])
+        assert res[r]["healthy"], r
+    return res
+
+
+@pytest.mark.parametrize("phase", [1, 2])
+def test_a_failing_rank_takes_part_and_every_rank_returns_its_status(phase):
+    from soundsym_amd import _native as nat
+    res = _run_ranks_with_fault(3, fault_rank=1, phase=phase, kind=0)
+    for r in range(3):
+        assert res[r]["code"] == nat.SSYM_E_NOMEM, (r, res[r])             # the same status on all three
+        assert res[r]["seconds"] < 5.0, (r, res[r])                        # nobody waited for a deadline
+        assert f"rank 1 of 3, phase {phase}" in res[r]["msg"], res[r]["msg"]
+        assert not res[r]["dead"]
+        assert res[r]["after"] == [True], (r, res[r])                      # the communicator is still in step
+    assert "injected failure" in res[1]["msg"] and "injected failure" not in res[0]["msg"]
+
+
+@pytest.mark.parametrize("phase", [1, 2])
+def test_a_rank_that_leaves_the_step_does_not_hang_its_peers(phase):
+    from soundsym_amd import _native as nat
+    res = _run_ranks_with_fault(3, fault_rank=2, phase=phase, kind=1)
+    assert res[2]["code"] == nat.SSYM_E_HIP and res[2]["dead"]
+    for r in (0, 1):
+        assert res[r]["code"] == nat.SSYM_E_TIMEOUT, (r, res[r])
+        assert res[r]["seconds"] < 20.0 and res[r]["dead"], (r, res[r])
+    for r in range(3):
+        assert res[r]["after"] == [nat.SSYM_E_COMM], (r, res[r])          # an aborted communicator answers SSYM_E_COMM
+
+
+def test_a_rank_that_never_calls_is_met_by_the_deadline():
+    from soundsym_amd import _native as nat
+    res = _run_ranks_with_fault(3, fault_rank=None, phase=0, kind=0, timeout_ms=1500, absent_rank=0, steps_after=0)
+    for r in (1, 2):
+        assert res[r]["code"] == nat.SSYM_E_TIMEOUT and res[r]["dead"], (r, res[r])
+        assert 1.0 < res[r]["seconds"] < 10.0, (r, res[r])
+
+
+def test_world1_rccl_fault_injection_and_abort():
+    """The same rules on a real RCCL communicator (world 1: all one GPU allows): a reported failure leaves the
+    communicator usable, a rank that leaves the step aborts it (ncclCommAbort) and later calls answer SSYM_E_COMM."""
+    from soundsym_amd import _native as nat
+    n, m, f, dim = 200, 64, 20, 13
+    g = synth.make_grid(n, m, f, dim, 0x5EED0A71)
+    e = Engine(metric="dtw", dtype="f32")
+    d, q = _grid_sets(e, g, f, dim)
+    want = e.match(d, q)
+    comm = sharding.init_comm(e, 0, 1)
+    comm.set_timeout(5000)
+    for phase in (1, 2):
+        comm.inject_fault(phase, 0)
+        with pytest.raises(nat.SsymError) as ei:
+            sharding.match_sharded(e, comm, d, q, 0)
+        assert ei.value.code == nat.SSYM_E_NOMEM and not comm.dead
+        got = sharding.match_sharded(e, comm, d, q, 0)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    comm.inject_fault(2, 1)
+    with pytest.raises(nat.SsymError) as ei:
+        sharding.match_sharded(e, comm, d, q, 0)
+    assert ei.value.code == nat.SSYM_E_HIP and comm.dead
+    with pytest.raises(nat.SsymError) as ei:
+        sharding.match_sharded(e, comm, d, q, 0)
+    assert ei.value.code == nat.SSYM_E_COMM
+    comm.close()
+    # the context survives its communicator
+    got = e.match(d, q)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    e.close()

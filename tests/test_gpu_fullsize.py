@@ -94,24 +94,6 @@ def test_config5_shape_banded_512x512x256x40():
     e.close()
 
 
-def _banded_grid(n, m, f, dim, seed):
-    """configs[4]-shaped data from numpy's generator (synth.make_grid takes ~10 s at this size): sources with the
-    MFCC-like 4/(1+k) decay and a slow per-segment drift, targets = a permutation's sources, time-warped by
-    repeating / dropping <= 8 % of the frames (well inside the band) plus noise -- the planted neighbour of
-    target t is perm[t] by construction."""
-    rng = np.random.default_rng(seed)
-    sig = (4.0 / (1.0 + np.arange(dim))).astype(np.float32)
-    src = rng.standard_normal((n, f, dim), dtype=np.float32) * sig
-    src += (rng.standard_normal((n, 1, dim), dtype=np.float32) * sig) * np.linspace(0, 1, f, dtype=np.float32)[None, :, None]
-    perm = rng.permutation(n)[:m]
-    pos = np.cumsum(rng.choice(np.array([0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2]),
-                               size=(m, f)), axis=1)
-    pos = np.clip(np.round(pos * (f - 1) / np.maximum(pos[:, -1:], 1)), 0, f - 1).astype(np.int64)
-    tgt = np.take_along_axis(src[perm], pos[:, :, None], axis=1)
-    tgt = tgt + 0.05 * sig * rng.standard_normal((m, f, dim), dtype=np.float32)
-    return src, tgt.astype(np.float32), perm
-
-
 def test_config5_full_size_4096x4096x256x40_band32(oracle):
     """BASELINE configs[4] at FULL size on one GPU: 4096 x 4096 segments, 256 frames x 40 dims, Sakoe-Chiba
     r = 32.  Planted indices, run-to-run identical bits, 16 sampled targets' winners against the oracle over
@@ -120,7 +102,10 @@ def test_config5_full_size_4096x4096x256x40_band32(oracle):
     from bounds import worst_case_bound
     n = m = 4096
     f, dim, band = 256, 40, 32
-    src, tgt, perm = _banded_grid(n, m, f, dim, 0x5EED0C05)
+    # the bench's workload itself: same generator, same seed (0x5EED0000 + config number; `bench.py
+    # --workload c5` draws exactly this grid)
+    g = synth.make_grid(n, m, f, dim, 0x5EED0005)
+    src, tgt, perm = g.sources, g.targets, g.planted
     so = np.arange(n + 1, dtype=np.uint64) * f
     to = np.arange(m + 1, dtype=np.uint64) * f
     e = Engine(metric="dtw", dtype="f32", band=band)
@@ -156,11 +141,12 @@ def test_config5_full_size_4096x4096x256x40_band32(oracle):
     assert worst < 1e-2, worst        # (in practice the f16 filter is within ~1e-3 relative at this shape)
 
 
-def test_config4_16384x4096_source_sharded_on_one_gpu(dtw):
+def test_config4_16384x4096_source_sharded_on_one_gpu(dtw, oracle):
     """BASELINE configs[3]: 16384 x 4096 segments, 128 frames x 13 dims, source axis split in 8
     shards.  The 8 ranks' work is run one after the other on this GPU (same calls a rank makes:
     match with index_base, then the gathered [8, M] candidates through the HIP merge kernel);
-    the planted neighbours are known from the generator alone."""
+    the planted neighbours are known from the generator alone, and 16 sampled targets' winners and
+    costs are checked against the oracle over ALL 16 384 sources (`bench.py --workload c4` draws this grid)."""
     import torch
     from soundsym_amd import sharding
     g = synth.make_grid(16384, 4096, 128, 13, 0x5EED0004)
@@ -183,3 +169,13 @@ def test_config4_16384x4096_source_sharded_on_one_gpu(dtw):
     assert refined <= 8 * 4096 * 3, refined
     c = out_cost.cpu().numpy()
     assert np.isfinite(c).all() and (c > 0).all()
+    # 16 sampled targets end to end against the oracle (all 16 384 sources each: 262 144 pairs)
+    pick = np.arange(77, 4096, 256)
+    assert pick.size == 16
+    sf, so = g.flat("sources", np.float64)
+    tsel = np.ascontiguousarray(g.targets[pick], dtype=np.float64).reshape(-1)
+    tosel = np.arange(pick.size + 1, dtype=np.uint64) * 128
+    want_idx, want_cost = oracle.dtw_match_all(sf, so, tsel, tosel, 13, nthreads=oracle.max_threads())
+    assert np.array_equal(out_idx.cpu().numpy().view(np.uint32)[pick].astype(np.int64), want_idx)
+    assert np.allclose(c[pick], want_cost, rtol=1e-5, atol=0)                     # the north star's tolerance
+    assert np.allclose(c[pick], want_cost, rtol=1e-12, atol=0)                    # what the exact kernel delivers

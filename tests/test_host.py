@@ -160,6 +160,18 @@ def test_from_timestamps_rounds_half_away_from_zero_and_checks_the_range():
     import pytest
     with pytest.raises(IndexError):
         SoundSequence.from_timestamps(s, [(0.0, 10.0, "past the end")])   # samples [0, 100] of 100
+    # `as usize` saturates: a negative or NaN time is sample 0 and the call proceeds (src/sound.rs:422-424)
+    from soundsym_amd.api import _round_as_usize
+    assert [_round_as_usize(x) for x in (-3.7, float("nan"), 0.4, 2.5, float("inf"))] == [0, 0, 0, 3, 2 ** 64 - 1]
+    s = Sound(np.arange(100, dtype=np.float64), 10.0, np.zeros(12))
+
+    class _NoEngine:
+        def mfcc(self, samples, rate, ncoeffs):
+            return np.zeros((0, ncoeffs))
+    seq = SoundSequence.from_timestamps(s, [(-1.0, 0.3, "negative start"), (float("nan"), 0.0, "nan start")], engine=_NoEngine())
+    assert [x.samples().tolist() for x in seq.sounds()] == [[0.0, 1.0, 2.0, 3.0], [0.0]]
+    with pytest.raises(IndexError):
+        SoundSequence.from_timestamps(s, [(0.5, 0.1, "start beyond end + 1")], engine=_NoEngine())
 
 
 def test_dictionary_residency_follows_the_content_not_the_length():
@@ -175,3 +187,12 @@ def test_dictionary_residency_follows_the_content_not_the_length():
     d.sounds[1] = b
     d.sounds.reverse()
     assert not d._same(key, d._content_key())
+    # every way of changing the list moves the key; looking at it does not; assigning a new list does
+    for change in (lambda: d.sounds.append(c), lambda: d.sounds.pop(), lambda: d.sounds.insert(0, c), lambda: d.sounds.remove(c),
+                   lambda: d.sounds.extend([c]), lambda: d.sounds.sort(key=id), lambda: d.sounds.__delitem__(0),
+                   lambda: setattr(d, "sounds", [a, b]), lambda: d.sounds.clear()):
+        key = d._content_key()
+        _ = d.sounds[0] if d.sounds else None, len(d.sounds), list(d.sounds)
+        assert d._same(key, d._content_key())
+        change()
+        assert not d._same(key, d._content_key())

@@ -202,3 +202,52 @@ def test_rows_f_golden_fixture_matches_oracle(oracle):
     assert m.shape == f["mfcc"].shape and np.all(np.abs(m - f["mfcc"]) <= 1e-12 * (1 + np.abs(f["mfcc"])))
     ci, cv = oracle.chain(g["src"], g["src_off"], 12, f["chain_start"], f["chain_dist"])
     assert np.array_equal(ci, f["chain_idx"]) and np.array_equal(cv, f["chain_val"])
+
+
+def test_rulinalg_combine_is_one_shared_constant(oracle, tmp_path):
+    """include/ssym_rulinalg.h: the association of rulinalg's combine step (s + (p0 + p4) against (s + p0) + p4; which
+    of the two rulinalg 0.4.2 uses could not be checked in this image).  The C oracle, the Python restatement and
+    the product read the same constant; the two choices really differ (so the constant is not vacuous), and the C
+    oracle built with the other value equals the Python restatement of that value."""
+    import ctypes
+    import subprocess
+    import oracle.oracle as om
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "ssym_rulinalg.h")).read()
+    assert "#define SSYM_RULINALG_COMBINE 0" in hdr or "#define SSYM_RULINALG_COMBINE 1" in hdr
+    assert oracle.lib.ssym_oracle_rulinalg_combine() == om.RULINALG_COMBINE
+    for f in ("soundsym_amd/csrc/refcos.hip", "soundsym_amd/csrc/refcos_mfma.hip", "oracle/ssym_oracle.c"):
+        text = open(os.path.join(root, f)).read()
+        assert "ssym_rulinalg.h" in text and "SSYM_RULINALG_STEP" in text, f
+    other = 1 - om.RULINALG_COMBINE
+    out = str(tmp_path / "libssym_oracle_other.so")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle"), "-B", f"EXTRA=-DSSYM_RULINALG_COMBINE={other}",
+                           f"OUT={out}"], stdout=subprocess.DEVNULL)
+    lib = ctypes.CDLL(out)
+    lib.ssym_oracle_dot.restype = ctypes.c_double
+    lib.ssym_oracle_dot.argtypes = [ctypes.POINTER(ctypes.c_double)] * 2 + [ctypes.c_size_t]
+    assert lib.ssym_oracle_rulinalg_combine() == other
+
+    def py_dot(x, y, combine):
+        p = [0.0] * 8
+        n8 = x.size // 8 * 8
+        for i in range(0, n8, 8):
+            for k in range(8):
+                p[k] = p[k] + float(x[i + k]) * float(y[i + k])
+        s = 0.0
+        for a, b in ((0, 4), (1, 5), (2, 6), (3, 7)):
+            s = s + (p[a] + p[b]) if combine == 0 else (s + p[a]) + p[b]
+        for i in range(n8, x.size):
+            s = s + float(x[i]) * float(y[i])
+        return s
+
+    rng = np.random.default_rng(7)
+    differ = 0
+    for _ in range(200):
+        n = int(rng.integers(8, 200))
+        x, y = rng.standard_normal(n), rng.standard_normal(n)
+        px, py = x.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), y.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+        d_this, d_other = oracle.dot(x, y), lib.ssym_oracle_dot(px, py, n)
+        assert d_this == py_dot(x, y, om.RULINALG_COMBINE) and d_other == py_dot(x, y, other)
+        differ += d_this != d_other
+    assert differ > 20, differ          # the two associations part in the last place often enough to matter
