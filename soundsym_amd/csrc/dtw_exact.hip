@@ -16,6 +16,7 @@
 #include "ssym_internal.hpp"
 
 #include <algorithm>
+#include <type_traits>
 
 namespace ssym {
 
@@ -594,6 +595,228 @@ __global__ __launch_bounds__(512) void dtw_exact_pipe_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// Two-phase variant (round 3): the local costs of a 64-row chunk FIRST, by all four waves of a workgroup and without
+// any dependency between cells, the recurrence AFTERWARDS, by one wave over costs that are already there.
+//
+// The kernels above evaluate c(i,j) inside the anti-diagonal step: ~220 instructions per step for 13 values (3 f64
+// operations per value, the f64 square root, conversions, LDS reads), of which the recurrence itself is ~15 -- and they
+// run on a wavefront that is two thirds full without a band (a 64-row chunk needs Fb + 63 steps for Fb columns) and one
+// third full inside one (lane l is busy for 2r + 1 of the chunk's 2r + 127 steps).  Splitting the two
+//   * takes the local costs off the dependent chain: a short candidate list (what a rank of a source-sharded step,
+//     or early abandoning's M candidates, hands over) is bound by the LENGTH of a pair's chain, and the chain is now
+//     ~15 instructions per step instead of ~220;
+//   * computes only the cells that exist: 64 x Fb per chunk without a band, 64 x (2r + 1) inside one (in diagonal
+//     coordinates x = j - i + r), every lane busy -- 1.5x / 3x fewer instructions than on the wavefront.
+// Same operations in the same order per cell as the kernels above and as the oracle (k ascending, sub / mul / add and
+// the square root rounded separately, then c + min3 with the same comparisons), so the bits are the same.
+//
+// LDS: cells[x][lane] f64 for one PANEL of at most 128 x-values (64 KB; x = column inside the panel, or diagonal), the
+// staged target frames (zero-padded to DIMR, f32 when the context's features are), two boundary rows.  Targets
+// longer than a panel are swept panel by panel: the wavefront of a panel ends with every lane on the panel's last
+// column, `mine` (D(i, j-1)) simply stays in its register, and the first step of the next panel finds D(i-1, j-1) in
+// the shuffle of the step before exactly as inside a panel -- no extra state.
+template <int DIMR, typename BT>
+__global__ __launch_bounds__(256) void dtw_exact_cells_kernel(
+    const double *__restrict__ srcRaw, const uint64_t *__restrict__ srcOff,
+    const double *__restrict__ tgtRaw, const uint64_t *__restrict__ tgtOff, uint32_t nSrc,
+    uint32_t nTgt, uint32_t dim, int band, int squared, const uint2 *__restrict__ pairs,
+    const uint32_t *__restrict__ countDev, uint32_t maxPairs, uint32_t fbCap, uint32_t panelX,
+    double *__restrict__ out, uint64_t totalHi)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr bool BF32 = sizeof(BT) == 4;
+    constexpr int LD = exact_ld<DIMR>(BF32);
+    constexpr int VPR = 16 / (int)sizeof(BT);    // values per 128-bit LDS read
+    constexpr int NV = (DIMR + VPR - 1) / VPR;
+    typedef BT bvec __attribute__((ext_vector_type(VPR)));
+    double *bound0 = smem;                       // [fbCap]
+    double *bound1 = smem + fbCap;               // [fbCap]
+    double *cells = smem + 2 * (size_t)fbCap;    // [panelX][64]
+    BT *ldsB = reinterpret_cast<BT *>(cells + (size_t)panelX * 64);     // [rows][LD] (16-byte aligned: fbCap is even)
+    const double INF = __builtin_inf();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const bool banded = band >= 0;               // block-uniform
+
+    uint64_t total;
+    if (pairs) {
+        uint32_t c = *countDev;
+        total = c < maxPairs ? c : maxPairs;
+    } else {
+        total = (uint64_t)nSrc * nTgt;
+    }
+    if (total > totalHi)        // the list length (it lives on the device) decides between this kernel and its siblings
+        return;
+    for (uint64_t k = blockIdx.x; k < total; k += gridDim.x) {
+        uint32_t s, t;
+        if (pairs) {
+            uint2 p = pairs[k];
+            s = p.x;
+            t = p.y;
+        } else {
+            s = (uint32_t)(k / nTgt);
+            t = (uint32_t)(k % nTgt);
+        }
+        const int Fa = (int)(srcOff[s + 1] - srcOff[s]);
+        const int Fb = (int)(tgtOff[t + 1] - tgtOff[t]);
+        const double *a0 = srcRaw + srcOff[s] * dim;
+        const double *b0 = tgtRaw + tgtOff[t] * dim;
+        if (Fa == 0 || Fb == 0) {                // block-uniform
+            if (threadIdx.x == 0)
+                out[k] = INF;
+            continue;
+        }
+        __syncthreads();                         // the previous pair's LDS is no longer read
+        if (!banded)
+            for (int i = threadIdx.x; i < Fb * DIMR; i += 256) {
+                const int fr = i / DIMR, e = i % DIMR;
+                ldsB[(size_t)fr * LD + e] = (BT)(e < (int)dim ? b0[(size_t)fr * dim + e] : 0.0);
+            }
+        double result = INF;
+        int chunk = 0;
+        for (int c0 = 0; c0 < Fa; c0 += 64, ++chunk) {
+            const int r = c0 + lane;
+            const bool rowValid = r < Fa;
+            const int rowsHere = min(64, Fa - c0);
+            double ar[DIMR];                     // the lane's own source frame (every wave holds the chunk's rows)
+            {
+                const double *arow = a0 + (size_t)(rowValid ? r : c0) * dim;
+#pragma unroll
+                for (int e = 0; e < DIMR; ++e)
+                    ar[e] = e < (int)dim ? arow[e] : 0.0;
+            }
+            const double *boundPrev = (chunk & 1) ? bound0 : bound1;
+            double *boundCur = (chunk & 1) ? bound1 : bound0;
+            int jlo = 0, jhi = Fb - 1;
+            if (banded) {
+                jlo = max(0, c0 - band);
+                jhi = min(Fb - 1, c0 + rowsHere - 1 + band);
+            }
+            const int wlo = banded ? jlo : 0, whi = banded ? jhi : Fb - 1;     // staged frames: rows wlo..whi
+            // wave 0 may still be walking the previous chunk's last panel: the window it reads from (banded) and the
+            // boundary row it reads (this chunk's boundCur is that chunk's boundPrev) change only after it is done
+            __syncthreads();
+            if (banded) {
+                for (int i = threadIdx.x; i < (whi - wlo + 1) * DIMR; i += 256) {
+                    const int fr = i / DIMR, e = i % DIMR;
+                    ldsB[(size_t)fr * LD + e] = (BT)(e < (int)dim ? b0[(size_t)(wlo + fr) * dim + e] : 0.0);
+                }
+            }
+            for (int j = threadIdx.x; j < Fb; j += 256)
+                boundCur[j] = INF;
+            // x of a cell: its column inside the panel, or (banded) its diagonal j - i + band in 0 .. 2 band
+            const int nPanels = banded ? 1 : (Fb + (int)panelX - 1) / (int)panelX;
+            double mine = INF;                   // D(r, j-1)      } the recurrence's state, in wave 0
+            double diagReg = INF;                // D(r-1, j-1)    }
+            for (int p = 0; p < nPanels; ++p) {
+                const int j0 = p * (int)panelX;
+                const int Xp = banded ? 2 * band + 1 : min((int)panelX, Fb - j0);
+                const int xorg = banded ? r - band : j0;          // j = xorg + x
+                __syncthreads();                 // frames staged; the cells of the previous panel have been consumed
+                // ---- phase 1: the panel's local costs, x = wave, wave + 4, ... (no cell waits for another) ----
+                // (two cells per trip, their sums interleaved by the scheduler: one cell alone is a chain of DIMR dependent
+                //  additions and the square root's refinement steps)
+                auto frame_of = [&](int x, bvec (&bv)[NV]) {
+                    const int jc = min(max(xorg + x, wlo), whi) - wlo;        // (a clamped cell is never used)
+                    const bvec *bp = reinterpret_cast<const bvec *>(ldsB + (size_t)jc * LD);
+#pragma unroll
+                    for (int e = 0; e < NV; ++e)
+                        bv[e] = bp[e];
+                };
+                for (int x = wave; x < Xp; x += 8) {
+                    const bool two = x + 4 < Xp;                              // wave-uniform
+                    bvec bv0[NV], bv1[NV];
+                    frame_of(x, bv0);
+                    frame_of(two ? x + 4 : x, bv1);
+                    // sum_k (a_k - b_k)^2, k ascending, sub / mul / add rounded separately (the oracle's order);
+                    // (0 - 0)^2 = +0.0 added to a non-negative sum changes nothing: the padding is invisible
+                    double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+                    for (int e = 0; e < DIMR; ++e) {
+                        const double d0 = __dsub_rn(ar[e], (double)bv0[e / VPR][e % VPR]);
+                        const double d1 = __dsub_rn(ar[e], (double)bv1[e / VPR][e % VPR]);
+                        acc0 = __dadd_rn(acc0, __dmul_rn(d0, d0));
+                        acc1 = __dadd_rn(acc1, __dmul_rn(d1, d1));
+                    }
+                    cells[(size_t)x * 64 + lane] = squared ? acc0 : sqrt(acc0);
+                    if (two)
+                        cells[(size_t)(x + 4) * 64 + lane] = squared ? acc1 : sqrt(acc1);
+                }
+                __syncthreads();
+                // ---- phase 2: the recurrence over the panel, one wave, lane l on row c0 + l, column tau - l ----
+                // What a step depends on is the chain  D(r-1, j) of the lane above (one DPP move) -> min3 -> add, so
+                // everything else is taken off it: the step's cost and lane 0's row-above value are read from LDS one
+                // step ahead, lane 0's diagonal is its row-above value of the step before like every other lane's, and
+                // min(D(i-1, j), D(i-1, j-1)) is formed before D(i, j-1) joins.  (Order of the comparisons: the oracle
+                // starts from D(i-1, j) and takes D(i, j-1), then D(i-1, j-1), each if smaller.  Taking D(i-1, j-1)
+                // first gives the same value in every case: a NaN in the first place stays, a NaN elsewhere is skipped,
+                // and equal numbers are the same number.)
+                if (wave == 0) {
+                    const int tauLo = banded ? jlo : j0;
+                    const int tauHi = banded ? jhi + rowsHere : j0 + Xp + rowsHere - 1;      // exclusive
+                    const bool isLane0 = lane == 0, isLane63 = lane == 63;
+                    const double *cl = cells + lane;
+                    // FIRST: the chunk starts at row 0 (nothing above it); BANDED: compile-time copies of the two
+                    // block-uniform flags, so that the loop body is straight-line code
+                    auto walk = [&](auto FIRST, auto BANDED) {
+                        constexpr bool kFirst = decltype(FIRST)::value, kBanded = decltype(BANDED)::value;
+                        int x = tauLo - lane - xorg;
+                        double cv = cl[(size_t)min(max(x, 0), Xp - 1) * 64];
+                        // lane 0's D(r-1, tau): the boundary row, read one step ahead and masked when it is used
+                        double bRaw = kFirst ? INF : boundPrev[min(tauLo, Fb - 1)];
+                        if (isLane0)                                                            // lane 0's D(r-1, tau-1)
+                            diagReg = kFirst ? (tauLo == 0 ? 0.0 : INF)
+                                             : ((tauLo >= 1 && tauLo <= Fb) ? boundPrev[tauLo - 1] : INF);
+#pragma unroll 2
+                        for (int tau = tauLo; tau < tauHi; ++tau) {
+                            const double c = cv;
+                            cv = cl[(size_t)min(max(x + 1, 0), Xp - 1) * 64];               // the next step's cost
+                            const double bA = (kFirst || tau >= Fb) ? INF : bRaw;
+                            if (!kFirst)
+                                bRaw = boundPrev[min(tau + 1, Fb - 1)];
+                            double fromAbove = shfl_up1(mine);        // D(r-1, j) for lanes >= 1
+                            fromAbove = isLane0 ? bA : fromAbove;
+                            double best = fromAbove;                  // D(i-1, j)
+                            if (diagReg < best) best = diagReg;       // D(i-1, j-1)
+                            if (mine < best) best = mine;             // D(i,   j-1)
+                            const double cur = __dadd_rn(c, best);
+                            const bool inX = (unsigned)x < (unsigned)Xp;      // in the panel / inside the band
+                            const int j = x + xorg;
+                            // without a band a lane outside the panel holds still (its D(r, j-1) is the previous panel's
+                            // last column); inside a band the cells of the row beyond the band ARE +inf, as in the
+                            // kernels above
+                            const bool active = rowValid && (kBanded ? (unsigned)j < (unsigned)Fb : inX);
+                            const double next = (kBanded && !inX) ? INF : cur;
+                            mine = active ? next : mine;
+                            if (isLane63 && active)
+                                boundCur[j] = next;
+                            diagReg = fromAbove;
+                            ++x;
+                        }
+                    };
+                    if (c0 == 0) {
+                        if (banded)
+                            walk(std::true_type{}, std::true_type{});
+                        else
+                            walk(std::true_type{}, std::false_type{});
+                    } else {
+                        if (banded)
+                            walk(std::false_type{}, std::true_type{});
+                        else
+                            walk(std::false_type{}, std::false_type{});
+                    }
+                    // (after its last column a lane holds still, so the last row's lane ends on D(Fa-1, Fb-1); when that
+                    //  cell lies outside the band the chunk never reaches its column, and the pair's cost is +inf)
+                    result = (!banded || abs(Fa - Fb) <= band) ? mine : INF;
+                }
+            }
+        }
+        if (wave == 0 && (Fa - 1) % 64 == lane)
+            out[k] = result;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // A handful of short queries against a dictionary of short entries in ONE launch (ssym_match_one / small
 // ssym_match_batch calls with the dtw metric: the reference's one-query-at-a-time pattern).  One wave per
 // (entry, query) pair: lane = entry frame (entries of at most 64 frames: one chunk, no boundary rows), the
@@ -796,6 +1019,58 @@ int32_t launch_dtw_exact(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet 
     // cost configs[4] a workgroup per CU: 6 x 26 KB fit the 160 KB, 5 x 27 KB did)
     const uint32_t winRows = ctx->band >= 0 ? std::min<uint32_t>(fbEven, (64 + 2 * (uint32_t)ctx->band + 1) & ~1u) : fbEven;
     const size_t regLds = 2 * (size_t)fbEven * sizeof(double) + (size_t)winRows * ldr * (bf32 ? sizeof(float) : sizeof(double));
+    // frames of up to 48 values, bands of up to r = 63: local costs first, recurrence afterwards (dtw_exact_cells_kernel).
+    // Measured on MI355X (tools/exact_timing.py, against the kernels below): inside a band it wins at every list length
+    // (configs[4]: 4096 pairs 2.12 -> 1.49 ms, 512 pairs 0.51 -> 0.19 ms, every pair of 128 x 128 segments 6.5 -> 5.2 ms);
+    // without a band it wins while the list is short enough to be bound by the length of a pair's chain (512 pairs of
+    // 128 x 128 frames 0.187 -> 0.080 ms: what a rank of a source-sharded step re-scores after the bound exchange) and
+    // loses once the chip is full (4096 pairs 0.48 -> 0.57 ms: its 64 KB of cells admit two workgroups per CU), so there
+    // it takes lists of up to 4 pairs per CU and sources of up to 256 frames, and the kernels below take the rest.
+    static const bool cellsOff = getenv("SSYM_EXACT_CELLS") && atoi(getenv("SSYM_EXACT_CELLS")) == 0;
+    uint64_t lowBound = 0;              // lists at least this long are the business of the kernels below
+    {
+        const bool banded = ctx->band >= 0;
+        const uint32_t panelX = banded ? 2 * (uint32_t)ctx->band + 1 : std::min<uint32_t>(fbEven, 128);
+        const size_t cellsLds = 2 * (size_t)fbEven * sizeof(double) + (size_t)panelX * 64 * sizeof(double) +
+                                (size_t)winRows * ldr * (bf32 ? sizeof(float) : sizeof(double));
+        const uint64_t cellsMax = banded ? ~0ull : (uint64_t)ctx->num_cus * 4;
+        const bool cellsOk = !cellsOff && dimr && dimr <= 48 && panelX <= 128 && cellsLds <= 150 * 1024 &&
+                             (banded || (src.max_frames <= 256 && regLds <= 64 * 1024)) &&      // (its siblings below are gated by length)
+                             (pairs != nullptr || total <= cellsMax);
+        if (cellsOk) {
+            const unsigned cgrid = (unsigned)std::min<uint64_t>(std::min<uint64_t>(total, cellsMax), (uint64_t)ctx->num_cus * 8);
+#define SSYM_EXACT_CELLS2(D_, T_)                                                                              \
+    do {                                                                                                       \
+        auto kern = dtw_exact_cells_kernel<D_, T_>;                                                            \
+        if (cellsLds > 64 * 1024)                                                                              \
+            SSYM_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                                    (int)cellsLds));                                           \
+        kern<<<cgrid, 256, cellsLds, st>>>(src.raw, src.off, tgt.raw, tgt.off, src.n, tgt.n, dim, ctx->band,  \
+                                           ctx->squared, pairs, count_dev, max_pairs, fbEven, panelX, out,     \
+                                           cellsMax);                                                          \
+    } while (0)
+#define SSYM_EXACT_CELLS(D_)                                                                                   \
+    do {                                                                                                       \
+        if (bf32)                                                                                              \
+            SSYM_EXACT_CELLS2(D_, float);                                                                      \
+        else                                                                                                   \
+            SSYM_EXACT_CELLS2(D_, double);                                                                     \
+    } while (0)
+            switch (dimr) {
+            case 12: SSYM_EXACT_CELLS(12); break;
+            case 14: SSYM_EXACT_CELLS(14); break;
+            case 16: SSYM_EXACT_CELLS(16); break;
+            case 40: SSYM_EXACT_CELLS(40); break;
+            default: SSYM_EXACT_CELLS(48); break;
+            }
+#undef SSYM_EXACT_CELLS
+#undef SSYM_EXACT_CELLS2
+            SSYM_HIP_CHECK(ctx, hipGetLastError());
+            if (total <= cellsMax)          // (max_pairs bounds the list: nothing longer can turn up)
+                return SSYM_OK;
+            lowBound = cellsMax + 1;
+        }
+    }
     uint64_t regLo = 0;
     // sources of 65...512 frames: row chunks pipelined over the waves of a workgroup (dtw_exact_pipe_kernel)
     const uint32_t pipeW = (src.max_frames + 63) / 64;
@@ -812,7 +1087,7 @@ int32_t launch_dtw_exact(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet 
     const bool pipeOk = !pipeOff && ctx->band < 0 && dimr && dimr <= 48 && pipeW >= 2 && pipeW <= 8 &&
                         pipeLds <= 150 * 1024 && regLds <= 64 * 1024;
     const unsigned *redoFlag = nullptr;
-    if (pipeOk && !(pairs == nullptr && total > pipeMax)) {
+    if (pipeOk && lowBound <= pipeMax && !(pairs == nullptr && total > pipeMax)) {
         int32_t rcf = ensure(ctx, ctx->pipe_flag, 8 * sizeof(unsigned));
         if (rcf != SSYM_OK)
             return rcf;
@@ -831,7 +1106,7 @@ int32_t launch_dtw_exact(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet 
                                                     (int)pipeLds));                                            \
         kern<<<std::min<unsigned>(grid, (unsigned)pipeMax), 64 * pipeW, pipeLds, st>>>(                       \
             src.raw, src.off, tgt.raw, tgt.off, src.n, tgt.n, dim, ctx->band, ctx->squared, pairs, count_dev,  \
-            max_pairs, fbEven, out, (uint64_t)0, pipeMax, failCount, forceGiveUp);                             \
+            max_pairs, fbEven, out, lowBound, pipeMax, failCount, forceGiveUp);                             \
     } while (0)
 #define SSYM_EXACT_PIPE(D_)                                                                                    \
     do {                                                                                                       \
@@ -853,6 +1128,8 @@ int32_t launch_dtw_exact(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet 
         // longer lists: the one-wave-per-pair kernel below; a list the pipelined kernel certainly took: that kernel
         // only as the redo of a give-up (it leaves at once otherwise)
         regLo = (!pairs || max_pairs <= pipeMax) ? ~0ull : pipeMax + 1;
+    } else {
+        regLo = lowBound;
     }
     if (dimr && regLds <= (size_t)(dimr >= 64 ? 150 : 64) * 1024) {
 #define SSYM_EXACT_REG(...)                                                                                    \

@@ -31,7 +31,7 @@ build)
 test)
     export SSYM_LIB=$lib SSYM_ORACLE_LIB=$ora SSYM_RULINALG_COMBINE=1
     cd $root
-    python3 -m pytest tests -q -x -m "not gpu" -k "not golden" -p no:cacheprovider
+    python3 -m pytest tests -q -x -m "not gpu" -k "not golden and not needs_the_gpu" -p no:cacheprovider
     python3 -m pytest tests -q -x -m gpu -k "(refcos or chain or topk or api or random or numerics or comm) and not golden and not bench" -p no:cacheprovider
     ;;
 *) echo "usage: $0 build|test"; exit 2 ;;
