@@ -407,17 +407,30 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
     if (ctx->metric == SSYM_METRIC_REFCOS) {
         // The plain first-minimum search goes through the f64 matrix pipe (refcos_mfma.hip): every pair's dot as a
         // GEMM, a rigorous interval per key, and the reference's own arithmetic only on the few pairs that can
-        // hold a target's minimum -- same bits out.  Top-k, the sharded phases (no host look at the list) and small
-        // problems keep the exact tile kernel on every pair; so does a call whose candidate list overflowed.
-        bool viaMfma = k_top == 1 && !ctx->stream_only && refcos_mfma_supported(ctx, src, tgt);
+        // hold a target's minimum (top-k: one of its k smallest keys) -- same bits out.  Small problems keep the exact
+        // tile kernel on every pair; so does a call whose candidate list overflowed.
+        // (a sharded step only enqueues: its candidate list's header travels in the gathered status like the dtw
+        //  lists', and the attempt every rank repeats after an overflow -- so_cap set -- takes the exact tile kernel)
+        bool viaMfma = !(ctx->stream_only && (ctx->so_cap || k_top > 1)) && refcos_mfma_supported(ctx, src, tgt);
+        ctx->so_refcos = false;
         if (viaMfma) {
             const uint32_t *h1dev = nullptr, *h2dev = nullptr;
             uint32_t h1[2] = {0, 0}, h2[2] = {0, 0};
             SSYM_HIP_CHECK(ctx, hipEventRecord(ev[0], st));
-            rc = launch_refcos_match_mfma(ctx, src, tgt, distDev, index_base, idxDev, costDev, &h1dev, &h2dev);
+            rc = launch_refcos_match_mfma(ctx, src, tgt, distDev, index_base, idxDev, costDev, &h1dev, &h2dev, k_top);
             if (rc != SSYM_OK)
                 return rc;
             SSYM_HIP_CHECK(ctx, hipEventRecord(ev[2], st));
+            if (ctx->stream_only) {              // ssym_match_sharded reads the headers after the step's one synchronisation
+                ctx->so_hdr1 = h1dev;
+                ctx->so_hdr2 = h2dev;
+                ctx->so_refcos = true;
+                ctx->so_filter = false;
+                tm.used_filter = 1;
+                tm.main_launches = 1;
+                ctx->timings = tm;
+                return SSYM_OK;                  // (device outputs: the sharded step's send block)
+            }
             SSYM_HIP_CHECK(ctx, hipMemcpyAsync(h1, h1dev, sizeof(h1), hipMemcpyDeviceToHost, st));
             SSYM_HIP_CHECK(ctx, hipMemcpyAsync(h2, h2dev, sizeof(h2), hipMemcpyDeviceToHost, st));
             SSYM_HIP_CHECK(ctx, hipStreamSynchronize(st));

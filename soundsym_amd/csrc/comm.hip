@@ -695,13 +695,13 @@ int32_t match_sharded_step(ssym_ctx *ctx, ssym_comm *comm, const ssym_dict *dict
             local(2, [&]() -> int32_t {
                 ctx->pending = keep;
                 ctx->so_hdr1 = ctx->so_hdr2 = nullptr;
-                ctx->so_filter = false;
+                ctx->so_filter = ctx->so_refcos = false;
                 const int32_t r = match_finish_impl(ctx, bounds, sendIdx, sendCost, SSYM_OUT_DEVICE | (flags & SSYM_DTW_FORCE_EXACT));
                 finished = r == SSYM_OK;
                 return r;
             });
         if (finished) {
-            comm_status_kernel<<<1, 1, 0, st>>>(ctx->so_filter ? ctx->so_hdr1 : nullptr, sendStatus);
+            comm_status_kernel<<<1, 1, 0, st>>>((ctx->so_filter || ctx->so_refcos) ? ctx->so_hdr1 : nullptr, sendStatus);
         } else {          // an empty shard reports the fold start; so does a rank whose local work failed, with its status
             comm_fill_block_kernel<<<fillGrid, 256, 0, st>>>(sendCost, sendIdx, sendStatus, foldStart, index_base, M,
                                                              (uint32_t)(-failed), (uint32_t)failedPhase);
@@ -722,7 +722,7 @@ int32_t match_sharded_step(ssym_ctx *ctx, ssym_comm *comm, const ssym_dict *dict
                                              (const char *)comm->recv.ptr + blk - kStatusWords * sizeof(uint32_t), blk,
                                              kStatusWords * sizeof(uint32_t), (size_t)G, hipMemcpyDeviceToHost, st));
         ownCount[0] = ownCount[1] = 0;
-        const bool ownLists = finished && ctx->so_filter && ctx->so_hdr2;
+        const bool ownLists = finished && (ctx->so_filter || ctx->so_refcos) && ctx->so_hdr2;
         if (ownLists)
             SSYM_HIP_CHECK(ctx, hipMemcpyAsync(ownCount, ctx->so_hdr2, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         const unsigned pipeMask = ctx->pipe_mask;
@@ -770,6 +770,12 @@ int32_t match_sharded_step(ssym_ctx *ctx, ssym_comm *comm, const ssym_dict *dict
             sel_ms += ev_ms2(ev[0], ev[3]);
             ref_ms += ev_ms2(ev[3], ev[4]);
             red_ms += ev_ms2(ev[4], ev[5]);
+            tm.n_refined = ownCount[0];
+        } else if (finished && ctx->so_refcos) {       // refcos through the matrix pipe: main kernel | exact keys and fold
+            tm.used_filter = 1;
+            tm.main_launches = 1;
+            tm.main_ms = ev_ms2(ctx->ev[0], ctx->ev[1]);
+            red_ms += ev_ms2(ctx->ev[1], ctx->ev[2]);
             tm.n_refined = ownCount[0];
         }
         bool anyOverflow = false;

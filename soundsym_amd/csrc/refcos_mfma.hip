@@ -87,14 +87,19 @@ __device__ __forceinline__ void refcos_key_interval(double dotm, double sasb, do
 
 // Epilogue shared by the two main loops: dots -> key intervals -> thresholds and list 1.  `info` is LDS no wave reads
 // any more (the caller has passed its last barrier); sLen holds the tile's segment lengths.
-template <bool WRITE_SIMS>
+// TOPK (ssym_match_topk): the threshold a column offers is not its smallest key_hi but the kTop-th smallest DISTINCT
+// one among the wave's 64 rows (kTop rounds of "smallest value above the previous round's", +inf when the rows hold
+// fewer): at least kTop pairs then have their exact key below it, so the kTop-th smallest exact key of the target does
+// too, and every member of the exact top kTop has key_lo <= key <= threshold -- the same argument as for dtw
+// (select.hip), with the smallest such bound over all waves and tiles as the target's threshold.
+template <bool WRITE_SIMS, bool TOPK>
 __device__ __forceinline__ void refcos_epilogue(double4v (&acc)[4][4], RowInfo *info, const unsigned *sLen, int tid, int lane,
                                                 int wm, int wn, int lr, int lg, uint32_t sTile, uint32_t tTile, uint32_t nSrc,
                                                 uint32_t nTgt, const double *__restrict__ srcNorm,
                                                 const double *__restrict__ tgtNorm, const double *__restrict__ dist,
                                                 double defaultDist, unsigned long long *__restrict__ thr,
                                                 uint32_t *__restrict__ hdr, PairEntry *__restrict__ list, uint32_t cap,
-                                                double *__restrict__ dotOut)
+                                                double *__restrict__ dotOut, uint32_t kTop)
 {
     // ---- epilogue: dots -> key intervals -> thresholds and list 1 ------------------------------------------
     // D[4 i + lane / 16][lane % 16]: this lane holds, per block pair (a, b), source rows 4 i + lg and target column lr
@@ -122,6 +127,7 @@ __device__ __forceinline__ void refcos_epilogue(double4v (&acc)[4][4], RowInfo *
         const unsigned lb = sLen[kMT + col];
         const RowInfo ci = info[kMT + col];
         double klos[4][4];
+        double khis[TOPK ? 4 : 1][TOPK ? 4 : 1];
         double colMin = INF;
 #pragma unroll
         for (int a = 0; a < 4; ++a)
@@ -141,11 +147,31 @@ __device__ __forceinline__ void refcos_epilogue(double4v (&acc)[4][4], RowInfo *
                         dotOut[(size_t)s * nTgt + t] = __ddiv_rn(acc[a][b][i], nrm);
                 }
                 klos[a][i] = klo;
-                colMin = fmin(colMin, khi);
+                if (TOPK)
+                    khis[a][i] = khi;
+                else
+                    colMin = fmin(colMin, khi);
             }
-        // smallest key_hi of the wave's 64 rows in this column, then against the threshold every tile works on
-        colMin = fmin(colMin, __shfl_xor(colMin, 16));
-        colMin = fmin(colMin, __shfl_xor(colMin, 32));
+        // smallest key_hi of the wave's 64 rows in this column (TOPK: the kTop-th smallest distinct one), then against
+        // the threshold every tile works on
+        if (TOPK) {
+            double prev = -1.0;                                           // (keys are >= 0)
+            for (uint32_t r = 0; r < kTop; ++r) {
+                double m = INF;
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        m = (khis[a][i] > prev && khis[a][i] < m) ? khis[a][i] : m;
+                m = fmin(m, __shfl_xor(m, 16));
+                m = fmin(m, __shfl_xor(m, 32));
+                prev = m;                                                 // +inf once the rows are used up: it stays
+            }
+            colMin = prev;
+        } else {
+            colMin = fmin(colMin, __shfl_xor(colMin, 16));
+            colMin = fmin(colMin, __shfl_xor(colMin, 32));
+        }
         unsigned long long seen = kInfBitsU;
         if (lg == 0 && t < nTgt)
             seen = atomicMin(&thr[t], (unsigned long long)__double_as_longlong(colMin));    // keys are >= 0: bits order like values
@@ -197,14 +223,15 @@ __device__ __forceinline__ void refcos_epilogue(double4v (&acc)[4][4], RowInfo *
 // m + 16 k, B[k][n] in lane n + 16 k, D[4 i + lane / 16][lane % 16] in register pair i (measured: not the f32 forms' 4 (lane / 16) + i).  The summation index
 // is free to permute: lane group g = lane / 16 takes elements 4 g .. 4 g + 3 of a chunk, one per MFMA step, so
 // a lane's four A (or B) values of a chunk are 32 contiguous bytes of LDS -- two ds_read_b128.
-template <bool WRITE_SIMS>
+template <bool WRITE_SIMS, bool TOPK>
 __global__ __launch_bounds__(256, 2) void refcos_mfma_kernel(
     const double *__restrict__ srcRaw, const uint64_t *__restrict__ srcOff, const double *__restrict__ srcNorm,
     const double *__restrict__ tgtRaw, const uint64_t *__restrict__ tgtOff, const double *__restrict__ tgtNorm,
     uint32_t nSrc, uint32_t nTgt, uint32_t dim, unsigned long long srcVals, unsigned long long tgtVals,
     const double *__restrict__ dist, double defaultDist, unsigned long long *__restrict__ thr /* [nTgt] smallest key_hi so far (bits) */,
     uint32_t *__restrict__ hdr /* {count, overflow} */, PairEntry *__restrict__ list, uint32_t cap,
-    double *__restrict__ dotOut /* nullable: [nSrc][nTgt] sims from the matrix pipe's dots (ssym_pair_matrix, exact = 2) */)
+    double *__restrict__ dotOut /* nullable: [nSrc][nTgt] sims from the matrix pipe's dots (ssym_pair_matrix, exact = 2) */,
+    uint32_t kTop /* TOPK: entries wanted per target */)
 {
     __shared__ __attribute__((aligned(16))) double sA[2][kMT * kLdk];
     __shared__ __attribute__((aligned(16))) double sB[2][kNT * kLdk];
@@ -347,8 +374,8 @@ __global__ __launch_bounds__(256, 2) void refcos_mfma_kernel(
         return;
     }
 #endif
-    refcos_epilogue<WRITE_SIMS>(acc, reinterpret_cast<RowInfo *>(&sA[0][0]), sLen, tid, lane, wm, wn, lr, lg, sTile, tTile, nSrc,
-                                nTgt, srcNorm, tgtNorm, dist, defaultDist, thr, hdr, list, cap, dotOut);
+    refcos_epilogue<WRITE_SIMS, TOPK>(acc, reinterpret_cast<RowInfo *>(&sA[0][0]), sLen, tid, lane, wm, wn, lr, lg, sTile, tTile,
+                                      nSrc, nTgt, srcNorm, tgtNorm, dist, defaultDist, thr, hdr, list, cap, dotOut, kTop);
 }
 
 // list 1 against the final thresholds -> list 2 (pairs only)
@@ -383,7 +410,7 @@ __global__ __launch_bounds__(256) void refcos_pairs_kernel(
     const double *__restrict__ srcRaw, const uint64_t *__restrict__ srcOff, const double *__restrict__ srcNorm,
     const double *__restrict__ tgtRaw, const uint64_t *__restrict__ tgtOff, const double *__restrict__ tgtNorm,
     uint32_t dim, const double *__restrict__ dist, double defaultDist, const uint32_t *__restrict__ hdr2,
-    const uint2 *__restrict__ pairs, double *__restrict__ keys, unsigned long long *__restrict__ bestKey)
+    const uint2 *__restrict__ pairs, double *__restrict__ keys, unsigned long long *__restrict__ bestKey /* NULL: top-k */)
 {
     const uint32_t n = hdr2[0];
     const int i8 = threadIdx.x & 7;
@@ -418,9 +445,15 @@ __global__ __launch_bounds__(256) void refcos_pairs_kernel(
             const double sim = __ddiv_rn(acc, nrm);                       // src/sound.rs:32
             const double d = dist ? dist[pr.y] : defaultDist;
             const double key = fabs(__dsub_rn(sim, d));                   // src/sound.rs:359
-            keys[k] = key;
-            if (key < 2.0)                                                // the fold's start value (NaN: false)
-                atomicMin(&bestKey[pr.y], (unsigned long long)__double_as_longlong(key));
+            if (bestKey) {
+                keys[k] = key;
+                if (key < 2.0)                                            // the fold's start value (NaN: false)
+                    atomicMin(&bestKey[pr.y], (unsigned long long)__double_as_longlong(key));
+            } else {
+                // top-k: the rounds of select.hip's fold take every finite key; only keys below the fold start 2.0 qualify
+                // (src/sound.rs:361-362; NaN never does)
+                keys[k] = key < 2.0 ? key : __builtin_inf();
+            }
         }
     }
 }
@@ -498,11 +531,11 @@ size_t refcos_list_capacity(uint32_t n_src, uint32_t n_tgt)
 // overflow}) so that the caller can look at it after its synchronisation and fall back to the exact tile kernel.
 int32_t launch_refcos_match_mfma(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, const double *dist_dev,
                                  uint32_t index_base, uint32_t *out_idx_dev, double *out_cost_dev,
-                                 const uint32_t **list1_hdr, const uint32_t **list2_hdr)
+                                 const uint32_t **list1_hdr, const uint32_t **list2_hdr, uint32_t k_top)
 {
     const uint32_t N = src.n, M = tgt.n;
     hipStream_t st = ctx->stream;
-    const size_t cap = refcos_list_capacity(N, M);
+    const size_t cap = std::min<uint64_t>((uint64_t)N * M, (uint64_t)refcos_list_capacity(N, M) * std::min<uint32_t>(k_top, 8));
     int32_t rc = ensure(ctx, ctx->cand, 4 * sizeof(uint32_t) + sizeof(PairEntry) * cap);
     if (rc == SSYM_OK)
         rc = ensure(ctx, ctx->cand2, 4 * sizeof(uint32_t) + sizeof(uint2) * cap);
@@ -517,7 +550,7 @@ int32_t launch_refcos_match_mfma(ssym_ctx *ctx, const SegmentSet &src, const Seg
     uint32_t *hdr1 = (uint32_t *)ctx->cand.ptr;
     PairEntry *list1 = (PairEntry *)(hdr1 + 4);
     uint32_t *hdr2 = (uint32_t *)ctx->cand2.ptr;
-    uint2 *pairs = (uint2 *)(hdr2 + 4);
+    uint2 *pairs = (uint2 *)(hdr2 + 2);              // (the layout of the dtw lists: launch_dtw_final folds it for top-k)
     unsigned long long *thr = (unsigned long long *)ctx->tmin.ptr;
     unsigned long long *bestKey = (unsigned long long *)ctx->best.ptr;
     uint32_t *bestIdx = (uint32_t *)(bestKey + M);
@@ -525,18 +558,34 @@ int32_t launch_refcos_match_mfma(ssym_ctx *ctx, const SegmentSet &src, const Seg
 
     refcos_init_kernel<<<(M + 255) / 256, 256, 0, st>>>(thr, bestKey, bestIdx, M, hdr1, hdr2);
     dim3 grid((M + kNT - 1) / kNT, (N + kMT - 1) / kMT);
-    refcos_mfma_kernel<false><<<grid, 256, 0, st>>>(src.raw, src.off, src.norm, tgt.raw, tgt.off, tgt.norm, N, M, src.dim,
-                                             (unsigned long long)src.total_frames * src.dim,
-                                             (unsigned long long)tgt.total_frames * tgt.dim, dist_dev, 1.0, thr, hdr1, list1,
-                                             (uint32_t)cap, nullptr);
+    if (k_top > 1)
+        refcos_mfma_kernel<false, true><<<grid, 256, 0, st>>>(src.raw, src.off, src.norm, tgt.raw, tgt.off, tgt.norm, N, M, src.dim,
+                                                 (unsigned long long)src.total_frames * src.dim,
+                                                 (unsigned long long)tgt.total_frames * tgt.dim, dist_dev, 1.0, thr, hdr1,
+                                                 list1, (uint32_t)cap, nullptr, k_top);
+    else
+        refcos_mfma_kernel<false, false><<<grid, 256, 0, st>>>(src.raw, src.off, src.norm, tgt.raw, tgt.off, tgt.norm, N, M, src.dim,
+                                                 (unsigned long long)src.total_frames * src.dim,
+                                                 (unsigned long long)tgt.total_frames * tgt.dim, dist_dev, 1.0, thr, hdr1,
+                                                 list1, (uint32_t)cap, nullptr, 1);
     SSYM_HIP_CHECK(ctx, hipGetLastError());
     SSYM_HIP_CHECK(ctx, hipEventRecord(ctx->ev[1], st));          // main kernel | selection, exact keys, fold
     const unsigned keepBlocks = (unsigned)std::min<size_t>((cap + 255) / 256, 65535u * 16u);
     refcos_keep_kernel<<<keepBlocks, 256, 0, st>>>(hdr1, list1, (uint32_t)cap, thr, hdr2, pairs);
     refcos_pairs_kernel<<<std::min<unsigned>((unsigned)((cap + 31) / 32), (unsigned)ctx->num_cus * 16), 256, 0, st>>>(
-        src.raw, src.off, src.norm, tgt.raw, tgt.off, tgt.norm, src.dim, dist_dev, 1.0, hdr2, pairs, keys, bestKey);
-    refcos_fold_idx_kernel<<<keepBlocks, 256, 0, st>>>(hdr2, pairs, keys, bestKey, bestIdx);
-    refcos_fold_out_kernel<<<(M + 255) / 256, 256, 0, st>>>(bestKey, bestIdx, M, index_base, out_idx_dev, out_cost_dev);
+        src.raw, src.off, src.norm, tgt.raw, tgt.off, tgt.norm, src.dim, dist_dev, 1.0, hdr2, pairs, keys,
+        k_top > 1 ? nullptr : bestKey);
+    if (k_top > 1) {
+        // the k rounds of the first-minimum fold over the exactly keyed candidates (select.hip; the keys are the values
+        // it folds and reports: no distance left to subtract)
+        SSYM_HIP_CHECK(ctx, hipGetLastError());
+        rc = launch_dtw_final(ctx, src, tgt, nullptr, (uint32_t)cap, index_base, k_top, out_idx_dev, out_cost_dev);
+        if (rc != SSYM_OK)
+            return rc;
+    } else {
+        refcos_fold_idx_kernel<<<keepBlocks, 256, 0, st>>>(hdr2, pairs, keys, bestKey, bestIdx);
+        refcos_fold_out_kernel<<<(M + 255) / 256, 256, 0, st>>>(bestKey, bestIdx, M, index_base, out_idx_dev, out_cost_dev);
+    }
     SSYM_HIP_CHECK(ctx, hipGetLastError());
     *list1_hdr = hdr1;
     *list2_hdr = hdr2;
@@ -564,11 +613,11 @@ int32_t launch_refcos_mfma_sims(ssym_ctx *ctx, const SegmentSet &src, const Segm
     refcos_init_kernel<<<(M + 255) / 256, 256, 0, st>>>((unsigned long long *)ctx->tmin.ptr, bestKey, (uint32_t *)(bestKey + M), M,
                                                        hdr1, (uint32_t *)ctx->cand2.ptr);
     dim3 grid((M + kNT - 1) / kNT, (N + kMT - 1) / kMT);
-    refcos_mfma_kernel<true><<<grid, 256, 0, st>>>(src.raw, src.off, src.norm, tgt.raw, tgt.off, tgt.norm, N, M, src.dim,
+    refcos_mfma_kernel<true, false><<<grid, 256, 0, st>>>(src.raw, src.off, src.norm, tgt.raw, tgt.off, tgt.norm, N, M, src.dim,
                                              (unsigned long long)src.total_frames * src.dim,
                                              (unsigned long long)tgt.total_frames * tgt.dim, nullptr,
                                              1.0, (unsigned long long *)ctx->tmin.ptr, hdr1, (PairEntry *)(hdr1 + 4),
-                                             (uint32_t)cap, sims);
+                                             (uint32_t)cap, sims, 1);
     SSYM_HIP_CHECK(ctx, hipGetLastError());
     return SSYM_OK;
 }

@@ -145,6 +145,7 @@ struct ssym_ctx {
     uint64_t so_cap = 0;
     const uint32_t *so_hdr1 = nullptr, *so_hdr2 = nullptr;
     bool so_filter = false;         // the last stream-only phase ran the filter path (events ev[1..6] are its)
+    bool so_refcos = false;         // ... ran the refcos search through the matrix pipe (so_hdr1 / so_hdr2 are its lists, ev[0..2] its events)
     // ssym_match_begin .. ssym_match_finish (two-phase match of a source-sharded run)
     struct Pending {
         bool valid = false, filter = false, has_dist = false;
@@ -346,7 +347,7 @@ int32_t launch_dtw_match_few(ssym_ctx *ctx, const SegmentSet &src, const void *q
 bool refcos_mfma_supported(const ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt);
 int32_t launch_refcos_match_mfma(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, const double *dist_dev,
                                  uint32_t index_base, uint32_t *out_idx_dev, double *out_cost_dev,
-                                 const uint32_t **list1_hdr, const uint32_t **list2_hdr);
+                                 const uint32_t **list1_hdr, const uint32_t **list2_hdr, uint32_t k_top = 1);
 int32_t launch_refcos_mfma_sims(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, double *sims);
 char *stage_take(ssym_ctx *ctx, size_t bytes);      // pack.hip: room in the call's pinned window (NULL: none)
 int32_t launch_refcos_argmin(ssym_ctx *ctx, uint32_t n_src, uint32_t n_tgt, const double *sims,

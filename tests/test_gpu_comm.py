@@ -239,6 +239,53 @@ def test_multi_rank_one_rank_overflows_and_every_rank_repeats(oracle):
     assert (want_idx == 0).all()
 
 
+def test_sharded_refcos_goes_through_the_matrix_pipe(oracle):
+    """A refcos shard of 65 536 pairs and more runs its search on the f64 matrix pipe inside ssym_match_sharded too
+    (filter + exact keys of the candidates; the list's header travels in the gathered status): world-1 RCCL and two
+    in-process ranks, plain and with per-target distances, bit for bit the oracle's answer; a shard whose list
+    overflows (every source tied with every other) makes every rank repeat the tail on the exact tile kernel."""
+    rs, rt = synth.make_ragged(640, 260, 2, 24, 12, 0x5EED0A80)
+    src = [s_.astype(np.float64) * 0.05 for s_ in rs]
+    tgt = [t_.astype(np.float64) * 0.05 for t_ in rt]
+    src[400] = src[9].copy()
+    tgt[0] = src[9].copy()                                    # two equal keys across the shard boundary (refcos: not necessarily the winners)
+    sf, so = pack_segments(src, 12)
+    tf, to = pack_segments(tgt, 12)
+    dist = np.linspace(0.1, 1.3, 260)
+    r = Engine(metric="refcos", dtype="f64")
+    d, q = r.dictionary(sf, so, 12), r.queries(tf, to, 12)
+    comm = sharding.init_comm(r, 0, 1)
+    for dd in (None, dist):
+        want_idx, want_val = oracle.refcos_match_all(sf, so, tf, to, 12, distance=dd)
+        got = sharding.match_sharded(r, comm, d, q, 0, distance=dd)
+        tm = r.timings()
+        assert tm["used_filter"] == 1 and tm["attempts"] == 1 and tm["n_refined"] < 8 * 260, tm
+        assert np.array_equal(got[0], want_idx) and np.array_equal(got[1], want_val)
+    comm.close()
+    r.close()
+    cuts = [(0, 320), (320, 640)]
+    shards = [pack_segments(src[a:b], 12) for a, b in cuts]
+    for dd in (None, dist):
+        want_idx, want_val = oracle.refcos_match_all(sf, so, tf, to, 12, distance=dd)
+        res = _run_ranks(2, "refcos", "f64", shards, 12, tf, to, [a for a, _ in cuts], distance=dd)
+        for rk in range(2):
+            assert res[rk][2]["used_filter"] == 1 and res[rk][2]["attempts"] == 1
+            assert np.array_equal(res[rk][0], want_idx) and np.array_equal(res[rk][1], want_val), rk
+    # rank 0's sources all identical: its list 1 overflows, both ranks repeat the tail, rank 0 on the exact tile kernel
+    rng = np.random.default_rng(8)
+    one = rng.standard_normal((6, 12)) * 0.1
+    same = [one.copy() for _ in range(2200)]
+    other = [rng.standard_normal((6, 12)) * 0.1 for _ in range(300)]
+    tg2 = [rng.standard_normal((6, 12)) * 0.1 for _ in range(600)]
+    tf2, to2 = pack_segments(tg2, 12)
+    sfa, soa = pack_segments(same + other, 12)
+    want_idx, want_val = oracle.refcos_match_all(sfa, soa, tf2, to2, 12)
+    res = _run_ranks(2, "refcos", "f64", [pack_segments(same, 12), pack_segments(other, 12)], 12, tf2, to2, [0, 2200])
+    for rk in range(2):
+        assert res[rk][2]["attempts"] == 2, (rk, res[rk][2])
+        assert np.array_equal(res[rk][0], want_idx) and np.array_equal(res[rk][1], want_val), rk
+
+
 # ---------------------------------------------------------------------------------------------------------
 # Failure containment (include/soundsym_amd.h, "FAILURE on one rank is part of the protocol"): no rank may be left
 # waiting, and a failure that can still be reported is reported by EVERY rank with the same status.

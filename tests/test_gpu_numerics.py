@@ -193,6 +193,42 @@ def nat_pair_matrix(e, d, q, mode):
     return out
 
 
+@pytest.mark.parametrize("k", [2, 5, 17, 64])
+def test_refcos_topk_through_the_matrix_pipe_is_bit_exact(oracle, k):
+    # ssym_match_topk on the reference's metric: threshold = the k-th smallest distinct key_hi a wave's rows offer,
+    # exact keys of what it cannot exclude, k rounds of the first-minimum fold -- rows equal to the oracle's bit for bit
+    n, m, dim = 420, 200, 12
+    src, tgt = _refcos_sets(0x5EED7100 + k, n, m, 2, 30, dim)
+    tgt[0] = src[7].copy()
+    src[11] = src[7].copy()
+    src[300] = src[7].copy()                                        # a three-way tie: lowest index first at every rank
+    src[5] = np.zeros_like(src[5])                                  # norm 0: never an entry
+    src[9] = np.zeros((0, dim))
+    tgt[3] = np.zeros((0, dim))                                     # an empty target: its row is all NO_MATCH
+    sf, so = pack_segments(src, dim)
+    tf, to = pack_segments(tgt, dim)
+    e = Engine(metric="refcos", dtype="f64")
+    d, q = e.dictionary(sf, so, dim), e.queries(tf, to, dim)
+    dist = np.linspace(-0.2, 1.4, m)
+    for dd in (None, dist):
+        idx, key = e.match_topk(d, q, k, dd)
+        tm = e.timings()
+        assert tm["used_filter"] == 1, "top-k should have gone through the matrix pipe"
+        if k <= 17:            # (a wave offers the k-th smallest bound of ITS 64 rows: at k = 64 that is its largest, and
+            assert tm["n_refined"] < n * m // 4, tm                   #  nearly every pair is keyed exactly -- still correct)
+        want_idx, want_key = oracle.topk(oracle.refcos_matrix(sf, so, tf, to, dim), k, distance=dd)
+        have = want_idx >= 0
+        got_idx = idx.astype(np.int64)
+        got_idx[idx == 0xFFFFFFFF] = -1
+        assert np.array_equal(got_idx, want_idx)
+        assert np.array_equal(key[have], want_key[have]) and np.isnan(key[~have]).all()
+    one, val = e.match(d, q)
+    idx, key = e.match_topk(d, q, k)
+    won = idx[:, 0] != 0xFFFFFFFF
+    assert np.array_equal(one[won], idx[won, 0]) and np.array_equal(val[won], key[won, 0])
+    e.close()
+
+
 def test_refcos_mfma_overflowing_list_falls_back_to_the_exact_kernel(oracle):
     # every source identical: every pair ties, list 1 cannot hold them -> the exact tile kernel takes the call
     dim, f, n, m = 12, 6, 2200, 600

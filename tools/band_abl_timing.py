@@ -11,10 +11,12 @@ n = m = 4096
 f, d, r = 256, 40, 32
 if len(sys.argv) > 1:
     f, d, r = (int(x) for x in sys.argv[1:4])
+if len(sys.argv) > 5:
+    n, m = int(sys.argv[4]), int(sys.argv[5])
 g = synth.make_grid(n, m, f, d, 0x5EED0003)
 e = Engine(metric="dtw", dtype="f32", band=r)
-off = np.arange(n + 1, dtype=np.uint64) * f
-dd, q = e.dictionary(g.sources.reshape(-1), off, d), e.queries(g.targets.reshape(-1), off, d)
+dd = e.dictionary(g.sources.reshape(-1), np.arange(n + 1, dtype=np.uint64) * f, d)
+q = e.queries(g.targets.reshape(-1), np.arange(m + 1, dtype=np.uint64) * f, d)
 ms = []
 for it in range(6):
     try:
@@ -22,4 +24,4 @@ for it in range(6):
     except Exception as ex:            # (wrong filter values may overflow the candidate list: the timing is still valid)
         print("match raised:", type(ex).__name__)
     ms.append(e.timings()["main_ms"])
-print(os.environ.get("SSYM_LIB", "product library"), (f, d, r), "filter main_ms:", [round(x, 2) for x in ms[2:]])
+print(os.environ.get("SSYM_LIB", "product library"), (n, m, f, d, r), "filter main_ms:", [round(x, 2) for x in ms[2:]])
