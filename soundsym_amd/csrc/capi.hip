@@ -102,7 +102,7 @@ int32_t ssym_ctx_destroy(ssym_ctx *ctx)
     DeviceBuf *bufs[] = {&ctx->handoff, &ctx->cmat, &ctx->tmin, &ctx->cand, &ctx->cand2, &ctx->cand_xmin,
                          &ctx->cand_cost, &ctx->best, &ctx->selmask, &ctx->selcnt, &ctx->topk,
                          &ctx->abandon, &ctx->prune_pairs, &ctx->prune_cost, &ctx->one_ticket, &ctx->dist, &ctx->part, &ctx->out_idx, &ctx->out_cost,
-                         &ctx->pipe_flag, &ctx->tmin2};
+                         &ctx->pipe_flag, &ctx->tmin2, &ctx->zeros};
     for (DeviceBuf *b : bufs)
         if (b->ptr)
             (void)hipFree(b->ptr);

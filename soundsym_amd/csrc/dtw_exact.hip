@@ -1030,10 +1030,12 @@ int32_t launch_dtw_exact(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet 
     uint64_t lowBound = 0;              // lists at least this long are the business of the kernels below
     {
         const bool banded = ctx->band >= 0;
-        const uint32_t panelX = banded ? 2 * (uint32_t)ctx->band + 1 : std::min<uint32_t>(fbEven, 128);
+        static const int panelEnv = getenv("SSYM_CELLS_PANEL") ? atoi(getenv("SSYM_CELLS_PANEL")) : 0;         // experiments
+        static const long long maxEnv = getenv("SSYM_CELLS_MAX") ? atoll(getenv("SSYM_CELLS_MAX")) : 0;
+        const uint32_t panelX = banded ? 2 * (uint32_t)ctx->band + 1 : std::min<uint32_t>(fbEven, panelEnv > 0 ? panelEnv : 128);
         const size_t cellsLds = 2 * (size_t)fbEven * sizeof(double) + (size_t)panelX * 64 * sizeof(double) +
                                 (size_t)winRows * ldr * (bf32 ? sizeof(float) : sizeof(double));
-        const uint64_t cellsMax = banded ? ~0ull : (uint64_t)ctx->num_cus * 4;
+        const uint64_t cellsMax = banded ? ~0ull : (maxEnv > 0 ? (uint64_t)maxEnv : (uint64_t)ctx->num_cus * 4);
         const bool cellsOk = !cellsOff && dimr && dimr <= 48 && panelX <= 128 && cellsLds <= 150 * 1024 &&
                              (banded || (src.max_frames <= 256 && regLds <= 64 * 1024)) &&      // (its siblings below are gated by length)
                              (pairs != nullptr || total <= cellsMax);

@@ -39,6 +39,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
 
 namespace ssym {
 
@@ -47,7 +48,8 @@ namespace {
 constexpr int kMT = 128;            // sources per workgroup tile
 constexpr int kNT = 128;            // targets per workgroup tile
 constexpr int kKC = 16;             // elements per staged chunk (one 128-byte line per segment)
-constexpr int kLdk = kKC + 2;       // LDS row stride in doubles (16-byte aligned rows)
+constexpr int kLdk = kKC;           // LDS row stride in doubles: rows are 128 bytes, their 16-byte pieces XOR-swizzled (below)
+constexpr int rm_wait_vmcnt(int n) { return 0x0F70 | (n & 15) | ((n >> 4) << 14); }   // s_waitcnt vmcnt(n), nothing else
 typedef double double4v __attribute__((ext_vector_type(4)));
 typedef double double2v __attribute__((ext_vector_type(2)));
 
@@ -120,38 +122,50 @@ __device__ __forceinline__ void refcos_epilogue(double4v (&acc)[4][4], RowInfo *
     const double INF = __builtin_inf();
     const double cUnit = 1.1102230246251565e-16 * 1.02;
     // (segments beyond the sets' ends carry norm 0 in `info`: their pairs come out as [+inf, +inf] without a test)
+    // Pass 1, row-major: a row's values are fetched once for its four columns (the columns' sit in registers), every dot
+    // becomes its key interval, key_lo takes the dot's place in the accumulator registers (the dot is not needed
+    // again) and key_hi goes into the column's running minimum -- no second set of 64 values, no spills.
+    RowInfo ci[4];
+    unsigned lb[4];
+    double colMin[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        ci[b] = info[kMT + wn * 64 + b * 16 + lr];
+        lb[b] = sLen[kMT + wn * 64 + b * 16 + lr];
+        colMin[b] = INF;
+    }
+    double khis[TOPK ? 4 : 1][TOPK ? 4 : 1][TOPK ? 4 : 1];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = wm * 64 + a * 16 + 4 * i + lg;
+            const RowInfo ri = info[row];
+            const unsigned la = sLen[row];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const unsigned len = la < lb[b] ? la : lb[b];               // src/sound.rs:24-28
+                const double nrm = __dmul_rn(ri.norm, ci[b].norm);          // src/sound.rs:30
+                double klo, khi;
+                refcos_key_interval(acc[a][b][i], ri.sq * ci[b].sq, ri.inv * ci[b].inv, nrm, (3.0 * (double)len + 16.0) * cUnit,
+                                    ci[b].dist, klo, khi);
+                if (WRITE_SIMS) {
+                    const uint32_t s = sTile + row, t = tTile + wn * 64 + b * 16 + lr;
+                    if (s < nSrc && t < nTgt)
+                        dotOut[(size_t)s * nTgt + t] = __ddiv_rn(acc[a][b][i], nrm);
+                }
+                acc[a][b][i] = klo;
+                if (TOPK)
+                    khis[b][a][i] = khi;
+                else
+                    colMin[b] = fmin(colMin[b], khi);
+            }
+        }
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         const int col = wn * 64 + b * 16 + lr;
         const uint32_t t = tTile + col;
-        const unsigned lb = sLen[kMT + col];
-        const RowInfo ci = info[kMT + col];
-        double klos[4][4];
-        double khis[TOPK ? 4 : 1][TOPK ? 4 : 1];
-        double colMin = INF;
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = wm * 64 + a * 16 + 4 * i + lg;
-                const RowInfo ri = info[row];
-                const unsigned la = sLen[row];
-                const unsigned len = la < lb ? la : lb;                   // src/sound.rs:24-28
-                const double nrm = __dmul_rn(ri.norm, ci.norm);           // src/sound.rs:30
-                double klo, khi;
-                refcos_key_interval(acc[a][b][i], ri.sq * ci.sq, ri.inv * ci.inv, nrm, (3.0 * (double)len + 16.0) * cUnit,
-                                    ci.dist, klo, khi);
-                if (WRITE_SIMS) {
-                    const uint32_t s = sTile + row;
-                    if (s < nSrc && t < nTgt)
-                        dotOut[(size_t)s * nTgt + t] = __ddiv_rn(acc[a][b][i], nrm);
-                }
-                klos[a][i] = klo;
-                if (TOPK)
-                    khis[a][i] = khi;
-                else
-                    colMin = fmin(colMin, khi);
-            }
+        double cmin = colMin[b];
         // smallest key_hi of the wave's 64 rows in this column (TOPK: the kTop-th smallest distinct one), then against
         // the threshold every tile works on
         if (TOPK) {
@@ -162,21 +176,21 @@ __device__ __forceinline__ void refcos_epilogue(double4v (&acc)[4][4], RowInfo *
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        m = (khis[a][i] > prev && khis[a][i] < m) ? khis[a][i] : m;
+                        m = (khis[b][a][i] > prev && khis[b][a][i] < m) ? khis[b][a][i] : m;
                 m = fmin(m, __shfl_xor(m, 16));
                 m = fmin(m, __shfl_xor(m, 32));
                 prev = m;                                                 // +inf once the rows are used up: it stays
             }
-            colMin = prev;
+            cmin = prev;
         } else {
-            colMin = fmin(colMin, __shfl_xor(colMin, 16));
-            colMin = fmin(colMin, __shfl_xor(colMin, 32));
+            cmin = fmin(cmin, __shfl_xor(cmin, 16));
+            cmin = fmin(cmin, __shfl_xor(cmin, 32));
         }
         unsigned long long seen = kInfBitsU;
         if (lg == 0 && t < nTgt)
-            seen = atomicMin(&thr[t], (unsigned long long)__double_as_longlong(colMin));    // keys are >= 0: bits order like values
+            seen = atomicMin(&thr[t], (unsigned long long)__double_as_longlong(cmin));    // keys are >= 0: bits order like values
         seen = __shfl(seen, lr);
-        const double cur = fmin(colMin, __longlong_as_double((long long)seen));
+        const double cur = fmin(cmin, __longlong_as_double((long long)seen));
         // list 1: pairs the threshold known so far does not exclude (the final threshold can only be smaller).  A lane
         // counts its own, one prefix sum over the wave and ONE atomic reserve the room, then every lane writes its entries.
         unsigned mine = 0;
@@ -184,7 +198,7 @@ __device__ __forceinline__ void refcos_epilogue(double4v (&acc)[4][4], RowInfo *
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                mine += (klos[a][i] <= cur && klos[a][i] < INF) ? 1u : 0u;
+                mine += (acc[a][b][i] <= cur && acc[a][b][i] < INF) ? 1u : 0u;
         unsigned incl = mine;                                             // inclusive prefix sum over the 64 lanes
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -201,12 +215,12 @@ __device__ __forceinline__ void refcos_epilogue(double4v (&acc)[4][4], RowInfo *
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (klos[a][i] <= cur && klos[a][i] < INF) {
+                    if (acc[a][b][i] <= cur && acc[a][b][i] < INF) {
                         if (pos < cap) {
                             PairEntry e;
                             e.s = sTile + wm * 64 + a * 16 + 4 * i + lg;
                             e.t = t;
-                            e.key_lo = klos[a][i];
+                            e.key_lo = acc[a][b][i];
                             list[pos] = e;
                         } else {
                             hdr[1] = 1;
@@ -231,10 +245,13 @@ __global__ __launch_bounds__(256, 2) void refcos_mfma_kernel(
     const double *__restrict__ dist, double defaultDist, unsigned long long *__restrict__ thr /* [nTgt] smallest key_hi so far (bits) */,
     uint32_t *__restrict__ hdr /* {count, overflow} */, PairEntry *__restrict__ list, uint32_t cap,
     double *__restrict__ dotOut /* nullable: [nSrc][nTgt] sims from the matrix pipe's dots (ssym_pair_matrix, exact = 2) */,
-    uint32_t kTop /* TOPK: entries wanted per target */)
+    uint32_t kTop /* TOPK: entries wanted per target */, const double *__restrict__ zeros /* >= 16 bytes of 0.0 */)
 {
-    __shared__ __attribute__((aligned(16))) double sA[2][kMT * kLdk];
-    __shared__ __attribute__((aligned(16))) double sB[2][kNT * kLdk];
+    // four DISTINCT objects, addressed with compile-time buffer numbers: the compiler orders a DMA into LDS against every
+    // LDS read it cannot prove disjoint (s_waitcnt vmcnt(0) in front of the operand reads -- with one two-buffer array
+    // the DMA of chunk c + 1 was waited for before chunk c's first MFMA)
+    __shared__ __attribute__((aligned(16))) double sA0[kMT * kLdk], sA1[kMT * kLdk];
+    __shared__ __attribute__((aligned(16))) double sB0[kNT * kLdk], sB1[kNT * kLdk];
     __shared__ unsigned long long sBase[kMT + kNT];
     __shared__ unsigned sLen[kMT + kNT];
     __shared__ unsigned sMaxLen[2];
@@ -266,13 +283,23 @@ __global__ __launch_bounds__(256, 2) void refcos_mfma_kernel(
     const unsigned kMax = min(sMaxLen[0], sMaxLen[1]);    // beyond it every product of the tile is zero
     const unsigned nChunks = (kMax + kKC - 1) / kKC;
 
-    // staging: thread -> (row = tid / 8 + 32 p, elements 2 (tid % 8), + 1) for p = 0..3, both sides: 16 doubles in flight.
+    // staging: thread -> (row = tid / 8 + 32 p, one 16-byte piece of the row's 128-byte chunk) for p = 0..3, both sides.
     // The rows of a tile are consecutive segments, i.e. one contiguous stretch of the value buffer: a row's start is
     // a 32-bit offset from the tile's first value, kept in registers with the row's length, so that the eight loads
     // of a chunk issue back to back (with the lengths and starts looked up in LDS in front of every load, and a branch
-    // around it, the fetch phase cost ~40 % of a chunk's MFMA time).  Beyond a row's end the tile's first value is
-    // read instead and zeroed afterwards.
-    const int se = 2 * (tid & 7), sr = tid >> 3;          // two elements (16 bytes) per lane, 32 rows per sweep, 4 sweeps
+    // around it, the fetch phase cost ~40 % of a chunk's MFMA time).
+    // Global -> LDS by DMA (global_load_lds, 16 bytes per lane): no staging registers, no selects, no LDS stores (round 2
+    // staged through registers and zeroed there: 1.5 % slower).
+    // A wave's DMA lands as 1 KB of consecutive lanes, i.e. 8 rows x 8 pieces of 16 bytes with a row stride of 128
+    // bytes -- which would be an 8-way bank conflict for the MFMA operand reads (16 lanes read one piece of 16
+    // consecutive rows).  So the 8 pieces of a row are stored XOR-swizzled: position q of row r holds piece
+    // q ^ ((r >> 1) & 7), chosen on the LOAD side (the lane at position q fetches that piece), undone on the read side;
+    // rows 2k and 2k + 1 share a swizzle and differ in the upper half of the 64 banks, rows of different k differ in the
+    // position: the 16 rows of an operand read cover all 64 banks once.  What lies beyond a segment's end is read from
+    // 16 bytes of zeros instead; the one piece that straddles the end of a segment of odd length is corrected in LDS
+    // after it has landed.
+    const int sr = tid >> 3;                               // row of sweep 0 (32 rows per sweep, 4 sweeps)
+    const int se = 2 * ((tid & 7) ^ ((sr >> 1) & 7));      // the two elements of the piece this lane's position holds
     const unsigned long long tbA = min(sBase[0], srcVals - 1), tbB = min(sBase[kMT], tgtVals - 1);
     const double *const tileA = srcRaw + tbA, *const tileB = tgtRaw + tbB;
     unsigned relA[4], relB[4], lenA[4], lenB[4];
@@ -284,32 +311,32 @@ __global__ __launch_bounds__(256, 2) void refcos_mfma_kernel(
         relA[p] = lenA[p] ? (unsigned)(sBase[row] - tbA) : 0u;
         relB[p] = lenB[p] ? (unsigned)(sBase[kMT + row] - tbB) : 0u;
     }
-    // (a 16-byte load may start on a segment's last value: the value behind it is read too and zeroed; the buffers
-    //  carry kRawTailPad doubles behind their end, pack.hip; 8-byte alignment is all a segment's start guarantees)
-    double2v stA[4], stB[4];
     unsigned stE = 0;
-    auto fetch = [&](unsigned c) {                         // loads only: nothing here waits for them
+    auto fetch = [&](unsigned c, auto BUF) {               // DMAs only: nothing here waits for them
+        double *const dA = decltype(BUF)::value ? sA1 : sA0, *const dB = decltype(BUF)::value ? sB1 : sB0;
         stE = c * kKC + se;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            stA[p] = *reinterpret_cast<const double2v *>(tileA + (stE < lenA[p] ? relA[p] + stE : 0u));
-            stB[p] = *reinterpret_cast<const double2v *>(tileB + (stE < lenB[p] ? relB[p] + stE : 0u));
+            const double *ga = stE < lenA[p] ? tileA + relA[p] + stE : zeros;
+            const double *gb = stE < lenB[p] ? tileB + relB[p] + stE : zeros;
+            // (LDS side: the wave's 8 rows of this sweep, lanes in order; M0 carries the wave-uniform base)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)ga,
+                                             (__attribute__((address_space(3))) void *)&dA[(32 * p + 8 * wave) * kLdk], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gb,
+                                             (__attribute__((address_space(3))) void *)&dB[(32 * p + 8 * wave) * kLdk], 16, 0, 0);
         }
     };
-    auto stash = [&](int buf) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p)                        // (the values count as used whatever the selects below say:
-            asm volatile("" : "+v"(stA[p]), "+v"(stB[p])); //  the loads stay unconditional, no branch around them)
+    auto stash = [&](auto BUF) {                           // once the DMAs have landed: the straddling pieces
+        double *const dA = decltype(BUF)::value ? sA1 : sA0, *const dB = decltype(BUF)::value ? sB1 : sB0;
+        __builtin_amdgcn_s_waitcnt(rm_wait_vmcnt(0));
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int row = sr + 32 * p;
-            double2v a = stA[p], b = stB[p];
-            a[0] = stE < lenA[p] ? a[0] : 0.0;
-            a[1] = stE + 1 < lenA[p] ? a[1] : 0.0;
-            b[0] = stE < lenB[p] ? b[0] : 0.0;
-            b[1] = stE + 1 < lenB[p] ? b[1] : 0.0;
-            *reinterpret_cast<double2v *>(&sA[buf][row * kLdk + se]) = a;
-            *reinterpret_cast<double2v *>(&sB[buf][row * kLdk + se]) = b;
+            if (stE + 1 == lenA[p])
+                dA[row * kLdk + 2 * (tid & 7) + 1] = 0.0;
+            if (stE + 1 == lenB[p])
+                dB[row * kLdk + 2 * (tid & 7) + 1] = 0.0;
         }
     };
 
@@ -321,24 +348,25 @@ __global__ __launch_bounds__(256, 2) void refcos_mfma_kernel(
             acc[a][b] = double4v{0.0, 0.0, 0.0, 0.0};
 
     const int lr = lane & 15, lg = lane >> 4;
-    if (nChunks > 0) {
-        fetch(0);
-        stash(0);
-    }
-    __syncthreads();
-    for (unsigned c = 0; c < nChunks; ++c) {
-        const int buf = (int)(c & 1);
+    const int swz = (lr >> 1) & 7;                         // the swizzle of this lane's operand rows (16 blk + lr, any blk)
+    // one chunk: the other buffer is filled while this one is multiplied
+    auto chunk = [&](unsigned c, auto BUF) {
+        constexpr bool kOdd = decltype(BUF)::value;
+        using Other = std::integral_constant<bool, !kOdd>;
+        const double *const rA = kOdd ? sA1 : sA0, *const rB = kOdd ? sB1 : sB0;
 #ifndef SSYM_RM_NOFETCH   // (tools only: without it the MFMAs run on the first chunk over and over)
         if (c + 1 < nChunks)
-            fetch(c + 1);                                  // global loads in flight under the MFMAs
+            fetch(c + 1, Other{});                         // in flight under the MFMAs (DMA: straight into the other buffer,
+                                                           // which nobody has read since the barrier that ended chunk c - 1)
 #endif
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {                   // two MFMA steps per 16-byte LDS read
             double av[4][2], bv[4][2];                     // [block][step]
 #pragma unroll
             for (int blk = 0; blk < 4; ++blk) {
-                const double2v a2 = *reinterpret_cast<const double2v *>(&sA[buf][(wm * 64 + blk * 16 + lr) * kLdk + 4 * lg + 2 * hf]);
-                const double2v b2 = *reinterpret_cast<const double2v *>(&sB[buf][(wn * 64 + blk * 16 + lr) * kLdk + 4 * lg + 2 * hf]);
+                const int pc = 2 * ((2 * lg + hf) ^ swz);
+                const double2v a2 = *reinterpret_cast<const double2v *>(&rA[(wm * 64 + blk * 16 + lr) * kLdk + pc]);
+                const double2v b2 = *reinterpret_cast<const double2v *>(&rB[(wn * 64 + blk * 16 + lr) * kLdk + pc]);
                 av[blk][0] = a2[0]; av[blk][1] = a2[1];
                 bv[blk][0] = b2[0]; bv[blk][1] = b2[1];
             }
@@ -350,15 +378,23 @@ __global__ __launch_bounds__(256, 2) void refcos_mfma_kernel(
                     for (int b = 0; b < 4; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a][st], bv[b][st], acc[a][b], 0, 0, 0);
 #ifndef SSYM_RM_NOFETCH
-            // the next chunk goes to LDS in the shadow of the MFMAs (its loads were issued 32 MFMAs ago; the other
-            // buffer has not been read since the barrier that ended the previous chunk)
-            if (hf == 0 && c + 1 < nChunks)
-                stash(buf ^ 1);
 #endif
         }
 #ifndef SSYM_RM_NOFETCH
+        if (c + 1 < nChunks)
+            stash(Other{});                                // the DMAs were issued 64 MFMAs ago: this wait is a formality
         __syncthreads();
 #endif
+    };
+    if (nChunks > 0) {
+        fetch(0, std::false_type{});
+        stash(std::false_type{});
+    }
+    __syncthreads();
+    for (unsigned c = 0; c < nChunks; c += 2) {
+        chunk(c, std::false_type{});
+        if (c + 1 < nChunks)
+            chunk(c + 1, std::true_type{});
     }
 
 #ifdef SSYM_RM_NOEPI      // tools only: the main loop alone, every accumulator kept alive (results meaningless)
@@ -374,7 +410,7 @@ __global__ __launch_bounds__(256, 2) void refcos_mfma_kernel(
         return;
     }
 #endif
-    refcos_epilogue<WRITE_SIMS, TOPK>(acc, reinterpret_cast<RowInfo *>(&sA[0][0]), sLen, tid, lane, wm, wn, lr, lg, sTile, tTile,
+    refcos_epilogue<WRITE_SIMS, TOPK>(acc, reinterpret_cast<RowInfo *>(&sA0[0]), sLen, tid, lane, wm, wn, lr, lg, sTile, tTile,
                                       nSrc, nTgt, srcNorm, tgtNorm, dist, defaultDist, thr, hdr, list, cap, dotOut, kTop);
 }
 
@@ -520,6 +556,19 @@ bool refcos_mfma_supported(const ssym_ctx *ctx, const SegmentSet &src, const Seg
            src.total_frames > 0 && tgt.total_frames > 0;
 }
 
+// 256 bytes of zeros on the device, made once per context (stream-ordered before their first use)
+static int32_t refcos_zeros(ssym_ctx *ctx, const double **out)
+{
+    if (!ctx->zeros.ptr) {
+        int32_t rc = ensure(ctx, ctx->zeros, 256);
+        if (rc != SSYM_OK)
+            return rc;
+        SSYM_HIP_CHECK(ctx, hipMemsetAsync(ctx->zeros.ptr, 0, 256, ctx->stream));
+    }
+    *out = (const double *)ctx->zeros.ptr;
+    return SSYM_OK;
+}
+
 size_t refcos_list_capacity(uint32_t n_src, uint32_t n_tgt)
 {
     const uint64_t tiles = (n_src + kMT - 1) / kMT;
@@ -545,6 +594,9 @@ int32_t launch_refcos_match_mfma(ssym_ctx *ctx, const SegmentSet &src, const Seg
         rc = ensure(ctx, ctx->tmin, sizeof(unsigned long long) * M);
     if (rc == SSYM_OK)
         rc = ensure(ctx, ctx->best, (sizeof(unsigned long long) + sizeof(uint32_t)) * (size_t)M + 16);
+    const double *zeros = nullptr;
+    if (rc == SSYM_OK)
+        rc = refcos_zeros(ctx, &zeros);
     if (rc != SSYM_OK)
         return rc;
     uint32_t *hdr1 = (uint32_t *)ctx->cand.ptr;
@@ -562,12 +614,12 @@ int32_t launch_refcos_match_mfma(ssym_ctx *ctx, const SegmentSet &src, const Seg
         refcos_mfma_kernel<false, true><<<grid, 256, 0, st>>>(src.raw, src.off, src.norm, tgt.raw, tgt.off, tgt.norm, N, M, src.dim,
                                                  (unsigned long long)src.total_frames * src.dim,
                                                  (unsigned long long)tgt.total_frames * tgt.dim, dist_dev, 1.0, thr, hdr1,
-                                                 list1, (uint32_t)cap, nullptr, k_top);
+                                                 list1, (uint32_t)cap, nullptr, k_top, zeros);
     else
         refcos_mfma_kernel<false, false><<<grid, 256, 0, st>>>(src.raw, src.off, src.norm, tgt.raw, tgt.off, tgt.norm, N, M, src.dim,
                                                  (unsigned long long)src.total_frames * src.dim,
                                                  (unsigned long long)tgt.total_frames * tgt.dim, dist_dev, 1.0, thr, hdr1,
-                                                 list1, (uint32_t)cap, nullptr, 1);
+                                                 list1, (uint32_t)cap, nullptr, 1, zeros);
     SSYM_HIP_CHECK(ctx, hipGetLastError());
     SSYM_HIP_CHECK(ctx, hipEventRecord(ctx->ev[1], st));          // main kernel | selection, exact keys, fold
     const unsigned keepBlocks = (unsigned)std::min<size_t>((cap + 255) / 256, 65535u * 16u);
@@ -606,6 +658,9 @@ int32_t launch_refcos_mfma_sims(ssym_ctx *ctx, const SegmentSet &src, const Segm
         rc = ensure(ctx, ctx->tmin, sizeof(unsigned long long) * M);
     if (rc == SSYM_OK)
         rc = ensure(ctx, ctx->best, (sizeof(unsigned long long) + sizeof(uint32_t)) * (size_t)M + 16);
+    const double *zeros = nullptr;
+    if (rc == SSYM_OK)
+        rc = refcos_zeros(ctx, &zeros);
     if (rc != SSYM_OK)
         return rc;
     uint32_t *hdr1 = (uint32_t *)ctx->cand.ptr;
@@ -617,7 +672,7 @@ int32_t launch_refcos_mfma_sims(ssym_ctx *ctx, const SegmentSet &src, const Segm
                                              (unsigned long long)src.total_frames * src.dim,
                                              (unsigned long long)tgt.total_frames * tgt.dim, nullptr,
                                              1.0, (unsigned long long *)ctx->tmin.ptr, hdr1, (PairEntry *)(hdr1 + 4),
-                                             (uint32_t)cap, sims, 1);
+                                             (uint32_t)cap, sims, 1, zeros);
     SSYM_HIP_CHECK(ctx, hipGetLastError());
     return SSYM_OK;
 }

@@ -16,6 +16,8 @@
 
 namespace ssym {
 
+constexpr unsigned long long kInfBitsSel = 0x7ff0000000000000ull;      // +inf as order-preserving key bits
+
 // ---------------------------------------------------------------------------------------------
 // Error bound of the f16-split MFMA filter (dtw_filter_kernel.hpp), u = 2^-24, s = common scale.
 //
@@ -69,10 +71,14 @@ __global__ void fill_u32_kernel(uint32_t *p, uint32_t v, uint32_t n)
         p[i] = v;
 }
 
-constexpr int kSelChunk = 64;   // sources scanned per thread
+constexpr int kSelChunk = 64;   // sources per (target, chunk) hit mask
+constexpr int kSelTgt = 64;     // targets per workgroup of the two kernels below
+constexpr int kSelSub = 4;      // threads per (target, chunk): 16 sources each (one thread per 64 sources left the
+                                // 8-GPU share of configs[2], 512 sources, with 128 workgroups of dependent f64 chains:
+                                // 38 + 27 us for the two kernels; four threads per chunk: see DESIGN.md 7)
 
 // ub[t] = min_s key_hi(s,t) as order-preserving u64 bits
-__global__ __launch_bounds__(256) void dtw_colmin_kernel(
+__global__ __launch_bounds__(kSelTgt * kSelSub) void dtw_colmin_kernel(
     const float *__restrict__ cmat, uint32_t nSrc, uint32_t nTgt,
     uint32_t mPad, const double *__restrict__ dist, const int *__restrict__ srcLen,
     const float *__restrict__ srcMaxSq, const int *__restrict__ tgtLen, const float *__restrict__ tgtMaxSq,
@@ -81,63 +87,83 @@ __global__ __launch_bounds__(256) void dtw_colmin_kernel(
 {
     // s, t are record SLOTS (the filter's coordinates); the caller's per-target distance is looked up
     // through the slot's segment
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nTgt)
-        return;
-    const double delta = dist ? dist[permT[t]] : 0.0;
-    const double nb = (double)tgtMaxSq[t];
-    const int fb = tgtLen[t];
-    const uint32_t s0 = blockIdx.y * kSelChunk;
-    const uint32_t s1 = min(s0 + kSelChunk, nSrc);
-    // top-k rounds (prev != NULL): the smallest bound strictly above the previous round's
-    const double floorv = prev ? __longlong_as_double((long long)prev[t]) : -1.0;
-    double best = __builtin_inf();
-    for (uint32_t s = s0; s < s1; ++s) {
-        const size_t o = (size_t)s * mPad + t;
-        double klo, khi;
-        dtw_key_interval(mp, (double)cmat[o], 0.0, (double)srcMaxSq[s], nb, srcLen[s], fb, delta, klo, khi);
-        if (khi < best && khi > floorv)
-            best = khi;
+    __shared__ unsigned long long sBest[kSelTgt];
+    const uint32_t tx = threadIdx.x % kSelTgt, ty = threadIdx.x / kSelTgt;
+    const uint32_t t = blockIdx.x * kSelTgt + tx;
+    if (ty == 0)
+        sBest[tx] = kInfBitsSel;
+    __syncthreads();
+    if (t < nTgt) {
+        const double delta = dist ? dist[permT[t]] : 0.0;
+        const double nb = (double)tgtMaxSq[t];
+        const int fb = tgtLen[t];
+        const uint32_t s0 = blockIdx.y * kSelChunk + ty * (kSelChunk / kSelSub);
+        const uint32_t s1 = min(s0 + kSelChunk / kSelSub, nSrc);
+        // top-k rounds (prev != NULL): the smallest bound strictly above the previous round's
+        const double floorv = prev ? __longlong_as_double((long long)prev[t]) : -1.0;
+        double best = __builtin_inf();
+        for (uint32_t s = s0; s < s1; ++s) {
+            const size_t o = (size_t)s * mPad + t;
+            double klo, khi;
+            dtw_key_interval(mp, (double)cmat[o], 0.0, (double)srcMaxSq[s], nb, srcLen[s], fb, delta, klo, khi);
+            if (khi < best && khi > floorv)
+                best = khi;
+        }
+        if (best < __builtin_inf())
+            atomicMin(&sBest[tx], (unsigned long long)__double_as_longlong(best));
     }
-    if (best < __builtin_inf())
-        atomicMin(&ub[t], (unsigned long long)__double_as_longlong(best));
+    __syncthreads();
+    if (ty == 0 && t < nTgt && sBest[tx] != kInfBitsSel)
+        atomicMin(&ub[t], sBest[tx]);
 }
 
 // Stage-1 list, grouped by target (certify.hip keeps a target's records in registers across its
 // run of sources), built without a contended counter in three passes:
-//   mark:    one thread per (target, 64-source chunk) -> u64 hit mask, per-target count += popcount
+//   mark:    four threads per (target, 64-source chunk) -> u64 hit mask, per-target count += popcount
 //   scan:    segment start per target = exclusive sum of the counts; hdr[0] = total, hdr[1] = total > cap
 //   scatter: every thread with hits claims popcount slots inside its target's segment
 // cand layout: [0] = count (the number wanted, even past cap), [1] = overflow flag, pairs from cand + 2
-__global__ __launch_bounds__(256) void dtw_mark_kernel(
+__global__ __launch_bounds__(kSelTgt * kSelSub) void dtw_mark_kernel(
     const float *__restrict__ cmat, uint32_t nSrc, uint32_t nTgt,
     uint32_t mPad, const double *__restrict__ dist, const int *__restrict__ srcLen,
     const float *__restrict__ srcMaxSq, const int *__restrict__ tgtLen, const float *__restrict__ tgtMaxSq,
     MarginParams mp, const uint32_t *__restrict__ permT, const unsigned long long *__restrict__ ub,
     unsigned long long *__restrict__ mask, uint32_t *__restrict__ cnt)
 {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nTgt)
-        return;
-    unsigned long long hits = 0;
-    const double thr = __longlong_as_double((long long)ub[t]);
-    if (thr < __builtin_inf()) {     // else no finite cost for this target: the fold keeps (0, +inf)
-        const double delta = dist ? dist[permT[t]] : 0.0;
-        const double nb = (double)tgtMaxSq[t];
-        const int fb = tgtLen[t];
-        const uint32_t s0 = blockIdx.y * kSelChunk;
-        const uint32_t s1 = min(s0 + kSelChunk, nSrc);
-        for (uint32_t s = s0; s < s1; ++s) {
-            const size_t o = (size_t)s * mPad + t;
-            double klo, khi;
-            dtw_key_interval(mp, (double)cmat[o], 0.0, (double)srcMaxSq[s], nb, srcLen[s], fb, delta, klo, khi);
-            if (klo <= thr)
-                hits |= 1ull << (s - s0);
+    __shared__ unsigned long long sHits[kSelTgt];
+    const uint32_t tx = threadIdx.x % kSelTgt, ty = threadIdx.x / kSelTgt;
+    const uint32_t t = blockIdx.x * kSelTgt + tx;
+    if (ty == 0)
+        sHits[tx] = 0;
+    __syncthreads();
+    if (t < nTgt) {
+        unsigned long long hits = 0;
+        const double thr = __longlong_as_double((long long)ub[t]);
+        if (thr < __builtin_inf()) {     // else no finite cost for this target: the fold keeps (0, +inf)
+            const double delta = dist ? dist[permT[t]] : 0.0;
+            const double nb = (double)tgtMaxSq[t];
+            const int fb = tgtLen[t];
+            const uint32_t c0 = blockIdx.y * kSelChunk;
+            const uint32_t s0 = c0 + ty * (kSelChunk / kSelSub);
+            const uint32_t s1 = min(s0 + kSelChunk / kSelSub, nSrc);
+            for (uint32_t s = s0; s < s1; ++s) {
+                const size_t o = (size_t)s * mPad + t;
+                double klo, khi;
+                dtw_key_interval(mp, (double)cmat[o], 0.0, (double)srcMaxSq[s], nb, srcLen[s], fb, delta, klo, khi);
+                if (klo <= thr)
+                    hits |= 1ull << (s - c0);
+            }
         }
+        if (hits)
+            atomicOr(&sHits[tx], hits);
     }
-    mask[(size_t)blockIdx.y * nTgt + t] = hits;
-    if (hits)
-        atomicAdd(&cnt[t], (uint32_t)__popcll(hits));
+    __syncthreads();
+    if (ty == 0 && t < nTgt) {
+        const unsigned long long hits = sHits[tx];
+        mask[(size_t)blockIdx.y * nTgt + t] = hits;
+        if (hits)
+            atomicAdd(&cnt[t], (uint32_t)__popcll(hits));
+    }
 }
 
 // one block: cnt[t] -> exclusive prefix (in place), total into hdr[0], overflow flag into hdr[1]
@@ -611,9 +637,9 @@ int32_t launch_dtw_bounds(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
         seed_bounds_kernel<<<(tgt.n + 255) / 256, 256, 0, st>>>(seed_by_slot, tgt.n, ub);
     else
         fill_u64_kernel<<<(tgt.n + 255) / 256, 256, 0, st>>>(ub, kInfBits, tgt.n);
-    dim3 grid((tgt.n + 255) / 256, nChunks);
+    dim3 grid((tgt.n + kSelTgt - 1) / kSelTgt, nChunks);
     if (k_top <= 1) {
-        dtw_colmin_kernel<<<grid, 256, 0, st>>>(cmat, src.n, tgt.n, tgt.n_pad, dist_dev, src.len,
+        dtw_colmin_kernel<<<grid, kSelTgt * kSelSub, 0, st>>>(cmat, src.n, tgt.n, tgt.n_pad, dist_dev, src.len,
                                                 src.max_sqnorm, tgt.len, tgt.max_sqnorm, mp, tgt.perm, nullptr, ub);
     } else {
         unsigned long long *prev;
@@ -622,7 +648,7 @@ int32_t launch_dtw_bounds(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
         if (rc != SSYM_OK)
             return rc;
         for (uint32_t r = 0; r < k_top; ++r) {
-            dtw_colmin_kernel<<<grid, 256, 0, st>>>(cmat, src.n, tgt.n, tgt.n_pad, dist_dev, src.len, src.max_sqnorm,
+            dtw_colmin_kernel<<<grid, kSelTgt * kSelSub, 0, st>>>(cmat, src.n, tgt.n, tgt.n_pad, dist_dev, src.len, src.max_sqnorm,
                                                     tgt.len, tgt.max_sqnorm, mp, tgt.perm, r ? prev : nullptr, ub);
             topk_advance_kernel<<<(tgt.n + 255) / 256, 256, 0, st>>>(ub, prev, tgt.n, (int)r, r + 1 == k_top);
         }
@@ -837,7 +863,8 @@ int32_t launch_dtw_select(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
     uint32_t *cnt = (uint32_t *)ctx->selcnt.ptr, *fill = cnt + tgt.n;
     SSYM_HIP_CHECK(ctx, hipMemsetAsync(cnt, 0, sizeof(uint32_t) * 2 * (size_t)tgt.n, st));
     dim3 grid((tgt.n + 255) / 256, nChunks);
-    dtw_mark_kernel<<<grid, 256, 0, st>>>(cmat, src.n, tgt.n, tgt.n_pad, dist_dev, src.len,
+    dim3 markGrid((tgt.n + kSelTgt - 1) / kSelTgt, nChunks);
+    dtw_mark_kernel<<<markGrid, kSelTgt * kSelSub, 0, st>>>(cmat, src.n, tgt.n, tgt.n_pad, dist_dev, src.len,
                                           src.max_sqnorm, tgt.len, tgt.max_sqnorm, mp, tgt.perm, ub, mask, cnt);
     dtw_scan_kernel<<<1, 1024, 0, st>>>(cnt, tgt.n, cap, hdr);
     dtw_scatter_kernel<<<grid, 256, 0, st>>>(mask, tgt.n, cnt, fill, hdr, pairs);

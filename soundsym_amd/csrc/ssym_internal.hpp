@@ -125,6 +125,7 @@ struct ssym_ctx {
     ssym::DeviceBuf part;       // refcos partial argmin
     ssym::DeviceBuf one_ticket; // refcos_match_one_kernel: the "last workgroup" counter (zero between calls)
     ssym::DeviceBuf out_idx, out_cost;  // staging for host outputs
+    ssym::DeviceBuf zeros;      // 256 bytes of 0.0: what refcos_mfma_kernel's staging DMA reads beyond a segment's end
     // dtw_exact_pipe_kernel: 8 give-up counters, one per launch (round robin); pipe_mask = the slots this API
     // call used, read back with the call's results into ssym_timings.exact_redone
     ssym::DeviceBuf pipe_flag;
