@@ -50,6 +50,10 @@ impl Rank {
 
     /// One batch of targets (the loop of clone_from_dictionary, src/sound.rs:451-455, or of morph_to with
     /// `distance`): every rank passes the SAME targets and gets the SAME global indices back.
+    /// Failure: a rank whose work inside ssym_match_sharded fails still takes part, and EVERY rank gets that rank's
+    /// status as its `Err`.  A rank that returns BEFORE the call (ssym_queries_create failing on this rank only) never
+    /// arrives: its peers return SSYM_E_TIMEOUT after the communicator's deadline (ssym_comm_set_timeout) and their
+    /// communicator is aborted (SSYM_E_COMM from then on): drop the Rank and build a new one.
     pub unsafe fn match_all(&self, tgt_feats: *const c_void, tgt_offsets: &[u64], dim: u32,
                             distance: Option<&[f64]>) -> Result<Vec<u32>, String> {
         let n = (tgt_offsets.len() - 1) as u32;

@@ -411,7 +411,10 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
         // tile kernel on every pair; so does a call whose candidate list overflowed.
         // (a sharded step only enqueues: its candidate list's header travels in the gathered status like the dtw
         //  lists', and the attempt every rank repeats after an overflow -- so_cap set -- takes the exact tile kernel)
-        bool viaMfma = !(ctx->stream_only && (ctx->so_cap || k_top > 1)) && refcos_mfma_supported(ctx, src, tgt);
+        // Top-k goes that way up to k = 8: a wave offers the k-th smallest bound of ITS 64 rows, which loosens with k --
+        // 4096 x 4096 x 128f x 12d: k = 2 / 4 / 8 / 16 key 11 / 55 / 194 / 553 pairs per target exactly and take 1.2 / 1.7 /
+        // 3.1 / 6.9 ms against 4.5 / 4.6 / 4.8 / 5.3 ms on the exact tile kernel (tools/refcos_topk_timing.py).
+        bool viaMfma = !(ctx->stream_only && (ctx->so_cap || k_top > 1)) && k_top <= 8 && refcos_mfma_supported(ctx, src, tgt);
         ctx->so_refcos = false;
         if (viaMfma) {
             const uint32_t *h1dev = nullptr, *h2dev = nullptr;
