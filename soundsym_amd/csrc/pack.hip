@@ -226,6 +226,7 @@ void free_segments(ssym_ctx *ctx, SegmentSet &set)
     dev_free(ctx, set.max_sqnorm);
     dev_free(ctx, set.perm);
     dev_free(ctx, set.centroid);
+    dev_free(ctx, set.len_order);
     set = SegmentSet{};
 }
 
@@ -240,6 +241,7 @@ static int32_t build_derived(ssym_ctx *ctx, SegmentSet &set)
     dev_free(ctx, set.max_sqnorm); set.max_sqnorm = nullptr;
     dev_free(ctx, set.perm); set.perm = nullptr;
     dev_free(ctx, set.centroid); set.centroid = nullptr; set.centroid_n = 0;
+    dev_free(ctx, set.len_order); set.len_order = nullptr; set.len_order_n = 0;
 
     set.max_frames = 0;
     for (uint32_t i = 0; i < n; ++i)

@@ -18,140 +18,252 @@
 //     switches from the eight sums to the tail exactly where the reference does.
 //
 // Mapping: a 256-thread workgroup owns a 32 x 32 tile of pairs; 64-element chunks of the 32 source
-// and 32 target segments are staged in LDS (element-major, so lanes read consecutive doubles);
-// each thread keeps 2 x 2 pairs x 8 running sums in registers.
+// and 32 target segments reach LDS by DMA; eight lanes share a pair, one running sum each
+// (refcos_sims8_kernel below).
 #include "ssym_internal.hpp"
 #include "ssym_rulinalg.h"
 
 #include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+#include <vector>
 
 namespace ssym {
 
-constexpr int kTS = 32;       // sources per tile
-constexpr int kTT = 32;       // targets per tile
-constexpr int kCH = 64;       // elements per staged chunk
-constexpr int kLd = kTS + 1;  // padded leading dimension of the element-major LDS images
+// ---------------------------------------------------------------------------------------------
+// EIGHT LANES PER PAIR -- lane i of a group keeps rulinalg's running sum p_i, as refcos_match_one_kernel and
+// refcos_pairs_kernel do -- and a 4 x 8 block of pairs per group.
+//
+// Rounds 1-2 gave a thread 2 x 2 pairs x 8 sums: per block of eight elements it read 32 values from LDS for 64
+// multiply + add instructions, and with four waves of a workgroup on four SIMDs the LDS (one per CU) delivered half of
+// what the VALUs could take: 0.30 of the f64 issue rate, VALU busy 0.38, a seventh of the LDS cycles bank conflicts
+// (profiles/r03_refcos_tile.md keeps its counters).  With a lane per running sum the state of a pair is ONE register
+// pair per lane, a group holds 4 sources x 8 targets = 32 pairs, and a block of eight elements costs 12 reads for 64
+// instructions: 4096 x 4096 x 128f x 12d 4.36 -> 3.07 ms, ragged 4...160 frames 1.42 -> 0.62 ms, VALU busy 0.58.
+//
+// A pair accumulates while the block index m is below ITS q = min(|me|, |you|) / 8 and is finished at m == q (combine
+// step, then the len % 8 tail, one product at a time: exactly where and how the reference does it).  The rows of a tile
+// are taken in the order of their length (SegmentSet::len_order; results go back to the caller's positions), so the q of
+// a wave's 8 x 32 pairs lie close together: blocks below the wave's smallest q run without a test per pair, the few
+// between its smallest and largest q with one.  Nothing is multiplied that the reference does not multiply (no zero
+// padding enters a sum), so non-finite values behave as in the reference.
+constexpr int kS8Rows = 32;              // sources (and targets) per workgroup tile
+constexpr int kS8Chunk = 64;             // elements per staged chunk: 8 blocks of eight, one 512-byte row per segment
 
-__global__ __launch_bounds__(256) void refcos_sims_kernel(
-    const double *__restrict__ srcRaw, const uint64_t *__restrict__ srcOff,
-    const double *__restrict__ srcNorm, const double *__restrict__ tgtRaw,
-    const uint64_t *__restrict__ tgtOff, const double *__restrict__ tgtNorm, uint32_t nSrc,
-    uint32_t nTgt, uint32_t dim, uint32_t maxLenVals, double *__restrict__ sims)
+__global__ __launch_bounds__(256, 2) void refcos_sims8_kernel(
+    const double *__restrict__ srcRaw, const uint64_t *__restrict__ srcOff, const double *__restrict__ srcNorm,
+    const uint32_t *__restrict__ srcOrder, const double *__restrict__ tgtRaw, const uint64_t *__restrict__ tgtOff,
+    const double *__restrict__ tgtNorm, const uint32_t *__restrict__ tgtOrder, uint32_t nSrc, uint32_t nTgt, uint32_t dim,
+    double *__restrict__ sims)
 {
-    __shared__ double sS[kCH * kLd];
-    __shared__ double sT[kCH * kLd];
-    __shared__ unsigned long long sBase[kTS + kTT];   // value offset of each staged segment
-    __shared__ unsigned sLen[kTS + kTT];              // length in values
+    // Two buffers per side, four DISTINCT objects (the compiler orders a DMA into LDS against every LDS read it cannot
+    // prove disjoint, see refcos_mfma.hip).  A row's chunk is 512 bytes, row after row as the DMA lands them; its eight
+    // 64-byte blocks are stored XOR-swizzled by bit 3 of the row, so that the two groups of a 16-lane read phase (same
+    // source rows: a broadcast; target rows 8 apart) fall into different quarters of the banks.
+    __shared__ __attribute__((aligned(16))) double sS0[kS8Rows * kS8Chunk], sS1[kS8Rows * kS8Chunk];
+    __shared__ __attribute__((aligned(16))) double sT0[kS8Rows * kS8Chunk], sT1[kS8Rows * kS8Chunk];
+    __shared__ unsigned long long sBase[2 * kS8Rows];
+    __shared__ unsigned sLen[2 * kS8Rows];
+    __shared__ uint32_t sSeg[2 * kS8Rows];
+    __shared__ unsigned sMaxQ;
 
     const int tid = threadIdx.x;
-    const int tx = tid & 15, ty = tid >> 4;
-    const uint32_t sTile = blockIdx.y * kTS, tTile = blockIdx.x * kTT;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int i8 = lane & 7, gl = lane >> 3;              // element lane, group of the wave
+    const int quad = 2 * wave + (gl >> 2), oct = gl & 3;  // the group's 4 sources and 8 targets inside the tile
+    const int g0 = lane & ~7;
+    const uint32_t sTile = blockIdx.y * kS8Rows, tTile = blockIdx.x * kS8Rows;
 
-    if (tid < kTS + kTT) {
-        const bool isS = tid < kTS;
-        const uint32_t g = isS ? sTile + tid : tTile + (tid - kTS);
+    if (tid == 0)
+        sMaxQ = 0;
+    __syncthreads();
+    if (tid < 2 * kS8Rows) {
+        const bool isS = tid < kS8Rows;
+        const uint32_t pos = isS ? sTile + tid : tTile + (tid - kS8Rows);
         const uint32_t n = isS ? nSrc : nTgt;
-        const uint64_t *off = isS ? srcOff : tgtOff;
         unsigned long long base = 0;
         unsigned len = 0;
-        if (g < n) {
-            base = off[g] * dim;
-            len = (unsigned)((off[g + 1] - off[g]) * dim);
+        uint32_t seg = 0xffffffffu;
+        if (pos < n) {
+            seg = (isS ? srcOrder : tgtOrder)[pos];
+            const uint64_t *off = isS ? srcOff : tgtOff;
+            base = off[seg] * dim;
+            len = (unsigned)((off[seg + 1] - off[seg]) * dim);
         }
         sBase[tid] = base;
         sLen[tid] = len;
+        sSeg[tid] = seg;
     }
     __syncthreads();
 
-    // this thread's 2 x 2 pairs: sources {ty, ty+16}, targets {tx, tx+16}
-    unsigned q[2][2], rem[2][2];
-    bool done[2][2];
-    double p[2][2][8];
-    double dot[2][2];
+    // this group's pairs: q (whole blocks) and the tail per pair follow from the two lengths
+    unsigned la[4], lb[8];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 4; ++a)
+        la[a] = sLen[4 * quad + a];
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const unsigned la = sLen[ty + 16 * a], lb = sLen[kTS + tx + 16 * b];
-            const unsigned len = la < lb ? la : lb;            // src/sound.rs:24-28
-            q[a][b] = len / 8;
-            rem[a][b] = len % 8;
-            done[a][b] = false;
-            dot[a][b] = 0.0;
+    for (int b = 0; b < 8; ++b)
+        lb[b] = sLen[kS8Rows + 8 * oct + b];
+    unsigned qLo = 0xffffffffu, qHi = 0;                  // over the wave's pairs that exist
+    bool liveA[4], liveB[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-                p[a][b][i] = 0.0;
+    for (int a = 0; a < 4; ++a)
+        liveA[a] = sSeg[4 * quad + a] != 0xffffffffu;
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+        liveB[b] = sSeg[kS8Rows + 8 * oct + b] != 0xffffffffu;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool live = liveA[a] && liveB[b];
+            const unsigned q = min(la[a], lb[b]) / 8;
+            qLo = live ? min(qLo, q) : qLo;
+            qHi = live ? max(qHi, q) : qHi;
         }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        qLo = min(qLo, (unsigned)__shfl_xor((int)qLo, o));
+        qHi = max(qHi, (unsigned)__shfl_xor((int)qHi, o));
+    }
+    qLo = (unsigned)__builtin_amdgcn_readfirstlane((int)qLo);
+    qHi = (unsigned)__builtin_amdgcn_readfirstlane((int)qHi);
+    const bool waveLive = qLo != 0xffffffffu;             // (a wave whose pairs all lie beyond the sets has nothing to do)
+    if (lane == 0 && waveLive)
+        atomicMax(&sMaxQ, qHi);
+    __syncthreads();
+    const unsigned nChunks = (sMaxQ + kS8Chunk / 8 - 1) / (kS8Chunk / 8);     // whole blocks only: the tails are fetched at the end
 
-    const unsigned nChunks = (maxLenVals + kCH - 1) / kCH + 1;   // +1: a block index == q exists
-    for (unsigned c = 0; c < nChunks; ++c) {
-        // ---- stage chunk c of the 32 + 32 segments, element-major, zero beyond each length ----
-        __syncthreads();
-        {
-            const int row = tid >> 3;          // 0..31
-            const int e0 = (tid & 7) * 8;      // 8 consecutive elements
+    double p[4][8];
 #pragma unroll
-            for (int side = 0; side < 2; ++side) {
-                const unsigned long long base = sBase[side * kTS + row];
-                const unsigned len = sLen[side * kTS + row];
-                const double *raw = side ? tgtRaw : srcRaw;
-                double *dst = side ? sT : sS;
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const unsigned e = c * kCH + e0 + i;
-                    dst[(e0 + i) * kLd + row] = e < len ? raw[base + e] : 0.0;
+        for (int b = 0; b < 8; ++b)
+            p[a][b] = 0.0;
+
+    // staging by DMA (global_load_lds, 16 bytes per lane, no registers): in round j the workgroup's 256 lanes land 4 KB =
+    // rows 8 j .. 8 j + 7 of one side, lane t the 16-byte piece t % 32 of row 8 j + t / 32.  What a lane fetches is the
+    // piece that belongs at its position after the swizzle; beyond a row's end it fetches the row's first piece instead
+    // (whatever lies there is never added to a sum).
+    const int stRowL = tid >> 5, stPiece = tid & 31;      // row within a round, physical piece
+    // (bit 3 of row 8 (j & 3) + stRowL is j & 1: the logical element of this position, for even and odd rounds)
+    const unsigned stElem0 = 8 * (stPiece >> 2) + 2 * (stPiece & 3), stElem1 = 8 * ((stPiece >> 2) ^ 1) + 2 * (stPiece & 3);
+    auto fetch = [&](unsigned c, auto BUF) {
+        double *const dS = decltype(BUF)::value ? sS1 : sS0, *const dT = decltype(BUF)::value ? sT1 : sT0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {                     // rounds 0..3: sources, 4..7: targets
+            // (the rows' starts and lengths are looked up in LDS every time: kept in registers they were spilled, and a
+            //  scratch reload in front of every DMA serialised the eight of them)
+            const int idx = (j < 4 ? 0 : kS8Rows) + 8 * (j & 3) + stRowL;
+            const unsigned e = c * kS8Chunk + ((j & 1) ? stElem1 : stElem0);
+            const double *g = (j < 4 ? srcRaw : tgtRaw) + sBase[idx] + (e < sLen[idx] ? e : 0u);
+            double *const d = (j < 4 ? dS : dT) + (8 * (j & 3) + 2 * wave) * kS8Chunk;      // the wave's 1 KB of this round
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                             (__attribute__((address_space(3))) void *)d, 16, 0, 0);
+        }
+    };
+
+    // operand addresses: row base + the swizzled block + the lane's element
+    const int swzB = oct & 1;                              // (rows 8 oct + b: bit 3 of the row = oct & 1; source rows 4 quad + a: quad >> 1)
+    const int swzA = (quad >> 1) & 1;
+    auto chunk = [&](unsigned c, auto BUF) {
+        constexpr bool kOdd = decltype(BUF)::value;
+        using Other = std::integral_constant<bool, !kOdd>;
+        const double *const rS = (kOdd ? sS1 : sS0) + (4 * quad) * kS8Chunk + i8;
+        const double *const rT = (kOdd ? sT1 : sT0) + (8 * oct) * kS8Chunk + i8;
+        if (c + 1 < nChunks)
+            fetch(c + 1, Other{});                         // lands in the other buffer while this one is multiplied
+        if (waveLive) {
+#pragma unroll 2
+            for (int mp = 0; mp < kS8Chunk / 16; ++mp) {
+                const unsigned m0 = c * (kS8Chunk / 8) + 2 * mp;      // first block of the pair of blocks
+                if (m0 >= qHi)                                         // wave-uniform: no pair of the wave has a whole block left
+                    break;
+                double xa[4][2], yb[8][2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+                        xa[a][h] = rS[a * kS8Chunk + 8 * ((2 * mp + h) ^ swzA)];
+#pragma unroll
+                    for (int b = 0; b < 8; ++b)
+                        yb[b][h] = rT[b * kS8Chunk + 8 * ((2 * mp + h) ^ swzB)];
+                }
+                if (m0 + 1 < qLo) {
+                    // both blocks lie below every pair's q: p_i = p_i + xs[i] * ys[i], block m0 then block m0 + 1
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int a = 0; a < 4; ++a)
+#pragma unroll
+                            for (int b = 0; b < 8; ++b)
+                                p[a][b] = __dadd_rn(p[a][b], __dmul_rn(xa[a][h], yb[b][h]));
+                } else {
+                    // some pair of the wave ends here: a pair takes a block only while it is below its own q
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int a = 0; a < 4; ++a)
+#pragma unroll
+                            for (int b = 0; b < 8; ++b) {
+                                const unsigned q = min(la[a], lb[b]) / 8;          // src/sound.rs:24-28
+                                const double sum = __dadd_rn(p[a][b], __dmul_rn(xa[a][h], yb[b][h]));
+                                p[a][b] = m0 + h < q ? sum : p[a][b];
+                            }
                 }
             }
         }
-        __syncthreads();
-
-#pragma unroll 1
-        for (int m = 0; m < kCH / 8; ++m) {
-            const unsigned gm = c * (kCH / 8) + m;   // block-of-eight index within the segment
-            double xs[2][8], yt[2][8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                xs[0][i] = sS[(8 * m + i) * kLd + ty];
-                xs[1][i] = sS[(8 * m + i) * kLd + ty + 16];
-                yt[0][i] = sT[(8 * m + i) * kLd + tx];
-                yt[1][i] = sT[(8 * m + i) * kLd + tx + 16];
-            }
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    if (gm < q[a][b]) {
-                        // rulinalg dot main loop: p_i = p_i + xs[i] * ys[i]
-#pragma unroll
-                        for (int i = 0; i < 8; ++i)
-                            p[a][b][i] = __dadd_rn(p[a][b][i], __dmul_rn(xs[a][i], yt[b][i]));
-                    } else if (gm == q[a][b] && !done[a][b]) {
-                        double s = 0.0;
-                        s = SSYM_RULINALG_STEP(__dadd_rn, s, p[a][b][0], p[a][b][4]);
-                        s = SSYM_RULINALG_STEP(__dadd_rn, s, p[a][b][1], p[a][b][5]);
-                        s = SSYM_RULINALG_STEP(__dadd_rn, s, p[a][b][2], p[a][b][6]);
-                        s = SSYM_RULINALG_STEP(__dadd_rn, s, p[a][b][3], p[a][b][7]);
-#pragma unroll
-                        for (int i = 0; i < 8; ++i)
-                            if ((unsigned)i < rem[a][b])
-                                s = __dadd_rn(s, __dmul_rn(xs[a][i], yt[b][i]));
-                        dot[a][b] = s;
-                        done[a][b] = true;
-                    }
-                }
-        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): this wave's pieces of the next chunk have landed
+        asm volatile("" ::: "memory");
+        __syncthreads();                                   // ... everybody's have, and everybody is done with this buffer
+    };
+    if (nChunks > 0)
+        fetch(0, std::false_type{});
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("" ::: "memory");
+    __syncthreads();
+    for (unsigned c = 0; c < nChunks; c += 2) {
+        chunk(c, std::false_type{});
+        if (c + 1 < nChunks)
+            chunk(c + 1, std::true_type{});
     }
 
+    // every pair's eight sums are complete: rulinalg's combine step over the group's lanes, then the len % 8 tail one
+    // product at a time (lane i fetches element 8 q + i of both segments itself), the division, the store
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 4; ++a) {
+        const uint32_t sg = sSeg[4 * quad + a];
+        const unsigned long long baseA = sBase[4 * quad + a];
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const uint32_t s = sTile + ty + 16 * a, t = tTile + tx + 16 * b;
-            if (s < nSrc && t < nTgt) {
-                const double nrm = __dmul_rn(srcNorm[s], tgtNorm[t]);   // src/sound.rs:30
-                sims[(size_t)s * nTgt + t] = __ddiv_rn(dot[a][b], nrm); // src/sound.rs:32
+        for (int b = 0; b < 8; ++b) {
+            const uint32_t tg = sSeg[kS8Rows + 8 * oct + b];
+            const bool live = sg != 0xffffffffu && tg != 0xffffffffu;      // (group-uniform)
+            const unsigned len = min(la[a], lb[b]);
+            const unsigned q8 = len & ~7u, rem = len & 7u;
+            double t = 0.0;
+            if (live && (unsigned)i8 < rem)
+                t = __dmul_rn(srcRaw[baseA + q8 + i8], tgtRaw[sBase[kS8Rows + 8 * oct + b] + q8 + i8]);
+            const double pv = p[a][b];
+            const double p0 = __shfl(pv, g0 + 0), p1 = __shfl(pv, g0 + 1), p2 = __shfl(pv, g0 + 2), p3 = __shfl(pv, g0 + 3);
+            const double p4 = __shfl(pv, g0 + 4), p5 = __shfl(pv, g0 + 5), p6 = __shfl(pv, g0 + 6), p7 = __shfl(pv, g0 + 7);
+            double s = 0.0;
+            s = SSYM_RULINALG_STEP(__dadd_rn, s, p0, p4);
+            s = SSYM_RULINALG_STEP(__dadd_rn, s, p1, p5);
+            s = SSYM_RULINALG_STEP(__dadd_rn, s, p2, p6);
+            s = SSYM_RULINALG_STEP(__dadd_rn, s, p3, p7);
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                const double ti = __shfl(t, g0 + i);               // x[8 q + i] * y[8 q + i]
+                if ((unsigned)i < rem)
+                    s = __dadd_rn(s, ti);
             }
+            if (i8 == 0 && live) {
+                const double nrm = __dmul_rn(srcNorm[sg], tgtNorm[tg]);     // src/sound.rs:30
+                sims[(size_t)sg * nTgt + tg] = __ddiv_rn(s, nrm);           // src/sound.rs:32
+            }
+            __builtin_amdgcn_sched_barrier(0);      // one pair at a time: 32 pairs' loads and shuffles hoisted together spill
         }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -308,6 +420,29 @@ int32_t launch_refcos_match_few(ssym_ctx *ctx, const SegmentSet &src, const void
     return SSYM_OK;
 }
 
+// the set's segments ordered by length (stable), on the device; built once per content (pack.hip drops it with the rest)
+static int32_t ensure_len_order(ssym_ctx *ctx, const SegmentSet &set)
+{
+    if (set.len_order && set.len_order_n == set.n)
+        return SSYM_OK;
+    dev_free(ctx, set.len_order);
+    set.len_order = nullptr;
+    set.len_order_n = 0;
+    std::vector<uint32_t> order(set.n);
+    for (uint32_t i = 0; i < set.n; ++i)
+        order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+        return set.h_off[x + 1] - set.h_off[x] < set.h_off[y + 1] - set.h_off[y];
+    });
+    int32_t rc = dev_alloc(ctx, (void **)&set.len_order, sizeof(uint32_t) * std::max<uint32_t>(set.n, 1));
+    if (rc != SSYM_OK)
+        return rc;
+    SSYM_HIP_CHECK(ctx, hipMemcpyAsync(set.len_order, order.data(), sizeof(uint32_t) * set.n, hipMemcpyHostToDevice, ctx->stream));
+    SSYM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));      // (`order` goes out of scope)
+    set.len_order_n = set.n;
+    return SSYM_OK;
+}
+
 int32_t launch_refcos_sims(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, double *sims)
 {
     if (src.dim != tgt.dim) {
@@ -321,10 +456,14 @@ int32_t launch_refcos_sims(ssym_ctx *ctx, const SegmentSet &src, const SegmentSe
         ctx->err = "segment too long";
         return SSYM_E_UNSUPPORTED;
     }
-    dim3 grid((tgt.n + kTT - 1) / kTT, (src.n + kTS - 1) / kTS);
-    refcos_sims_kernel<<<grid, 256, 0, ctx->stream>>>(src.raw, src.off, src.norm, tgt.raw, tgt.off,
-                                                      tgt.norm, src.n, tgt.n, src.dim, (uint32_t)maxLen,
-                                                      sims);
+    int32_t rc = ensure_len_order(ctx, src);
+    if (rc == SSYM_OK)
+        rc = ensure_len_order(ctx, tgt);
+    if (rc != SSYM_OK)
+        return rc;
+    dim3 grid8((tgt.n + kS8Rows - 1) / kS8Rows, (src.n + kS8Rows - 1) / kS8Rows);
+    refcos_sims8_kernel<<<grid8, 256, 0, ctx->stream>>>(src.raw, src.off, src.norm, src.len_order, tgt.raw, tgt.off,
+                                                       tgt.norm, tgt.len_order, src.n, tgt.n, src.dim, sims);
     SSYM_HIP_CHECK(ctx, hipGetLastError());
     return SSYM_OK;
 }

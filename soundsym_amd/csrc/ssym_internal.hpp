@@ -90,6 +90,10 @@ struct SegmentSet {
     // SSYM_DTW_PRUNE: mean frame per segment [n][dim] (caller order), built on first use (prune.hip)
     mutable float *centroid = nullptr;
     mutable uint32_t centroid_n = 0;
+    // refcos tile kernel (refcos.hip): the segments ordered by length, built on first use (the 4 x 8 pairs an 8-lane group
+    // accumulates then end within a few blocks of each other); results stay in the caller's order
+    mutable uint32_t *len_order = nullptr;
+    mutable uint32_t len_order_n = 0;
 };
 
 }  // namespace ssym
