@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
 """tools/refcos_matrix_timing.py -- the bit-exact similarity matrix (ssym_pair_matrix, refcos) on the benchmark's shape and
-on ragged segments: the exact tile kernels of csrc/refcos.hip (SSYM_REFCOS_SIMS8=0: round 1's 2 x 2 pairs per thread;
-default: eight lanes per pair).  Device time is the match's main_ms with the matrix pipe switched off, which runs the
-same kernel on every pair."""
+on ragged segments: the exact tile kernel of csrc/refcos.hip (refcos_sims8_kernel, eight lanes per pair).  Device time
+is the match's main_ms with the matrix pipe switched off, which runs the same kernel on every pair."""
 import os, sys
 os.environ["SSYM_REFCOS_MFMA"] = "0"
 import numpy as np
