@@ -179,3 +179,32 @@ def test_config4_16384x4096_source_sharded_on_one_gpu(dtw, oracle):
     assert np.array_equal(out_idx.cpu().numpy().view(np.uint32)[pick].astype(np.int64), want_idx)
     assert np.allclose(c[pick], want_cost, rtol=1e-5, atol=0)                     # the north star's tolerance
     assert np.allclose(c[pick], want_cost, rtol=1e-12, atol=0)                    # what the exact kernel delivers
+
+
+def test_config4_eight_ranks_through_ssym_match_sharded(dtw):
+    """BASELINE configs[3] as it is stated -- 16384 x 4096 segments, source-sharded across 8 ranks -- through the call the
+    bench makes per rank, ssym_match_sharded: eight ranks as eight threads of this process on the one GPU (the in-process
+    transport in RCCL's place: same block layout, same bound exchange, same merge over 8 shards).  Every rank must return
+    the whole answer: the planted neighbours, identical costs on all ranks, equal to what the unsharded search of the
+    same 16384 sources returns, and a shard that does not hold a target's neighbour re-scores next to nothing."""
+    from test_gpu_comm import _run_ranks
+    from soundsym_amd import sharding
+    n, m, f, dim, world = 16384, 4096, 128, 13, 8
+    g = synth.make_grid(n, m, f, dim, 0x5EED0004)
+    to = np.arange(m + 1, dtype=np.uint64) * f
+    shards, bases = [], []
+    for r in range(world):
+        lo, hi = sharding.shard_range(n, world, r)
+        shards.append((np.ascontiguousarray(g.sources[lo:hi]).reshape(-1), np.arange(hi - lo + 1, dtype=np.uint64) * f))
+        bases.append(lo)
+    res = _run_ranks(world, "dtw", "f32", shards, dim, g.targets.reshape(-1), to, bases)
+    so = np.arange(n + 1, dtype=np.uint64) * f
+    want_idx, want_cost = dtw.match(dtw.dictionary(g.sources.reshape(-1), so, dim), dtw.queries(g.targets.reshape(-1), to, dim))
+    assert np.array_equal(want_idx, g.planted)
+    refined = 0
+    for r in range(world):
+        idx, cost, tm = res[r]
+        assert np.array_equal(idx, want_idx) and np.array_equal(cost, want_cost), r
+        assert tm["attempts"] == 1 and tm["used_filter"] == 1
+        refined += tm["n_refined"]
+    assert refined <= 3 * m, refined
