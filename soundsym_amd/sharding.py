@@ -121,27 +121,72 @@ def match_sharded(engine, comm, d, q, index_base, out_idx=None, out_cost=None, d
                                 out_cost=out_cost, prune=prune)
 
 
+def _all_ranks_ok(err, like, group=None):
+    """One tiny all-reduce(MAX) of "this rank's local phase failed": every rank learns whether ANY rank failed, so that all
+    of them leave the step together (the rule of ssym_match_sharded, spelled with torch.distributed)."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return err is None
+    on_host = dist.get_backend(group) == "gloo"
+    t = torch.tensor([0 if err is None else 1], dtype=torch.int32, device="cpu" if on_host else like.device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return int(t.item()) == 0
+
+
+class ShardedStepError(RuntimeError):
+    """A rank's local phase of match_sharded_torch failed; raised on EVERY rank of the group (on the failing one with
+    its own exception as the cause)."""
+
+
 def match_sharded_torch(engine, d, q, index_base, out_idx, out_cost, bounds, group=None, distance=None, prune=False):
     """The same step with torch.distributed collectives around the two-phase C-ABI calls (gloo rehearsals):
     filter, agree on the per-target bound with the other ranks, select / re-score against it, gather every
     rank's winners and merge them.  All tensors are CUDA tensors on this rank's GPU; returns (idx [M], cost [M]).
     prune=True (plain nearest-neighbour search only): every rank scores one candidate pair per target
     first, the costs are reduced with MIN, and the filters abandon against them -- one more exchange of
-    M f64 values, same results."""
+    M f64 values, same results.
+    A rank whose local work raises still takes part in every collective of the step (with +inf bounds / the fold start
+    as its block) and ALL ranks raise ShardedStepError afterwards: no rank is left inside a collective, as in
+    ssym_match_sharded."""
     import torch
 
-    if prune and distance is None:
-        cand = torch.empty_like(bounds)
-        engine.match_candidates(d, q, cand)
-        reduce_bounds(cand, group)
-        torch.cuda.current_stream().synchronize()
-        engine.match_begin_pruned(d, q, bounds, cand, index_base=index_base)
-    else:
-        engine.match_begin(d, q, bounds, distance=distance, index_base=index_base)
+    err = None
+    try:
+        if prune and distance is None:
+            cand = torch.empty_like(bounds)
+            try:
+                engine.match_candidates(d, q, cand)
+            except Exception as ex:                        # noqa: BLE001 -- reported by every rank below
+                err = ex
+                cand.fill_(float("inf"))
+            reduce_bounds(cand, group)
+            torch.cuda.current_stream().synchronize() if cand.is_cuda else None
+            if err is None:
+                engine.match_begin_pruned(d, q, bounds, cand, index_base=index_base)
+        elif err is None:
+            engine.match_begin(d, q, bounds, distance=distance, index_base=index_base)
+    except Exception as ex:                                # noqa: BLE001
+        err = err or ex
+    if err is not None:
+        bounds.fill_(float("inf"))
     reduce_bounds(bounds, group)
-    torch.cuda.current_stream().synchronize()      # the library runs on its own stream
-    engine.match_finish(bounds, out_idx, out_cost)
+    if bounds.is_cuda:
+        torch.cuda.current_stream().synchronize()      # the library runs on its own stream
+    if err is None:
+        try:
+            engine.match_finish(bounds, out_idx, out_cost)
+        except Exception as ex:                            # noqa: BLE001
+            err = ex
+    if err is not None:
+        out_idx.fill_(0)
+        out_cost.fill_(float("inf"))
     costs, idxs = gather_candidates(out_cost, out_idx, group)
+    if not _all_ranks_ok(err, bounds, group):
+        if err is not None:
+            raise ShardedStepError(f"this rank's local phase failed: {err}") from err
+        raise ShardedStepError("another rank's local phase failed; this rank's results are void")
     return merge_shards(engine, costs, idxs, distance)
 
 

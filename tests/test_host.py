@@ -196,3 +196,54 @@ def test_dictionary_residency_follows_the_content_not_the_length():
         assert d._same(key, d._content_key())
         change()
         assert not d._same(key, d._content_key())
+
+
+def _failing_step_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        m = 6
+
+        class StubEngine:                      # the C-ABI calls of one rank; rank 1's filter phase fails
+            def match_begin(self, d, q_, bounds, distance=None, index_base=0):
+                if rank == 1:
+                    raise RuntimeError("injected: out of memory in the filter phase")
+                bounds.fill_(3.0)
+
+            def match_finish(self, bounds, out_idx, out_cost):
+                out_idx.fill_(rank)
+                out_cost.fill_(float(rank + 1))
+
+            def merge_shards(self, costs, idx, out_idx, out_cost, distance=None):
+                raise AssertionError("no merge after a failed step")
+
+        bounds = torch.zeros(m, dtype=torch.float64)
+        out_idx = torch.zeros(m, dtype=torch.int32)
+        out_cost = torch.zeros(m, dtype=torch.float64)
+        try:
+            sharding.match_sharded_torch(StubEngine(), None, None, 0, out_idx, out_cost, bounds)
+            q.put((rank, "no error"))
+        except sharding.ShardedStepError as ex:
+            q.put((rank, str(ex)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_torch_collective_step_fails_on_every_rank_together():
+    # the rehearsal path (torch.distributed collectives around the two-phase calls) follows ssym_match_sharded's rule: a
+    # rank whose local phase raises still takes part in every collective, and ALL ranks raise afterwards
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_step_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert "this rank's local phase failed" in got[1] and "injected" in got[1]
+    assert "another rank's local phase failed" in got[0]
