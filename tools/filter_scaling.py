@@ -9,6 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from soundsym_amd import Engine, synth
 
 m, f, d = 4096, 128, 13
+fs = int(sys.argv[1]) if len(sys.argv) > 1 else f      # source frames (64: single-pass tasks of half the length)
 g = synth.make_grid(4096, m, f, d, 0x5EED0003)
 e = Engine(metric="dtw", dtype="f32")
 to = np.arange(m + 1, dtype=np.uint64) * f
@@ -16,8 +17,8 @@ q = e.queries(torch.from_numpy(g.targets.reshape(-1)).cuda(), to, d)
 oi = torch.empty(m, dtype=torch.int32, device="cuda"); oc = torch.empty(m, dtype=torch.float64, device="cuda")
 rows = []
 for n in (128, 256, 512, 1024, 2048, 4096):
-    so = np.arange(n + 1, dtype=np.uint64) * f
-    dd = e.dictionary(torch.from_numpy(np.ascontiguousarray(g.sources[:n]).reshape(-1)).cuda(), so, d)
+    so = np.arange(n + 1, dtype=np.uint64) * fs
+    dd = e.dictionary(torch.from_numpy(np.ascontiguousarray(g.sources[:n, :fs]).reshape(-1)).cuda(), so, d)
     ms = []
     for it in range(8):
         e.match(dd, q, out_idx=oi, out_cost=oc)
