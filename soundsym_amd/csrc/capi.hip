@@ -106,6 +106,7 @@ int32_t ssym_ctx_destroy(ssym_ctx *ctx)
     for (DeviceBuf *b : bufs)
         if (b->ptr)
             (void)hipFree(b->ptr);
+    release_deferred(ctx);
     dev_cache_release(ctx);
     if (ctx->stage)
         (void)hipHostFree(ctx->stage);

@@ -739,6 +739,7 @@ int32_t match_sharded_step(ssym_ctx *ctx, ssym_comm *comm, const ssym_dict *dict
         rc = comm_wait_step(ctx, comm, cev[7]);             // the step's one synchronisation, under the deadline
         if (rc != SSYM_OK)
             return rc;
+        release_deferred(ctx);                              // (blocks ensure() replaced while the step was being enqueued)
         // ---- from here on every rank looks at the same gathered words and takes the same way ----
         for (int g = 0; g < G; ++g)
             if (status[kStatusWords * g + 2]) {
@@ -855,6 +856,7 @@ int32_t match_sharded_impl(ssym_ctx *ctx, ssym_comm *comm, const ssym_dict *dict
         comm_abort(comm);
         ctx->stream_only = false;
         (void)hipStreamSynchronize(ctx->stream);
+        release_deferred(ctx);
         ctx->pending_d2h.clear();
         ctx->pending.valid = false;
         ctx->err = keep + " [this rank left the sharded step: its communicator is aborted]";

@@ -15,6 +15,14 @@ int32_t ensure(ssym_ctx *ctx, DeviceBuf &b, size_t bytes)
 {
     if (bytes <= b.bytes && b.ptr)
         return SSYM_OK;
+    if (b.ptr && ctx->stream_only) {
+        // inside a sharded step the stream may hold collectives that only complete when every rank has arrived: waiting
+        // for it here would be a wait without the step's deadline.  The old block is released after the step's one
+        // (deadline-guarded) synchronisation instead (release_deferred, called by comm.hip).
+        ctx->deferred_free.push_back(b.ptr);
+        b.ptr = nullptr;
+        b.bytes = 0;
+    }
     if (b.ptr) {
         SSYM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         SSYM_HIP_CHECK(ctx, hipFree(b.ptr));
@@ -25,6 +33,13 @@ int32_t ensure(ssym_ctx *ctx, DeviceBuf &b, size_t bytes)
     SSYM_HIP_CHECK(ctx, hipMalloc(&b.ptr, want));
     b.bytes = want;
     return SSYM_OK;
+}
+
+void release_deferred(ssym_ctx *ctx)
+{
+    for (void *p : ctx->deferred_free)
+        (void)hipFree(p);
+    ctx->deferred_free.clear();
 }
 
 __global__ void widen_f32_kernel(const float *__restrict__ in, double *__restrict__ out, size_t n)

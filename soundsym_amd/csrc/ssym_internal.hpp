@@ -147,6 +147,7 @@ struct ssym_ctx {
     // entries of room (0 = the default) and leaves the device headers of its two candidate lists in so_hdr1 /
     // so_hdr2 for the caller, who reads them after the step's single synchronisation
     bool stream_only = false;
+    std::vector<void *> deferred_free;      // blocks ensure() replaced during a stream-only step: freed after its synchronisation
     uint64_t so_cap = 0;
     const uint32_t *so_hdr1 = nullptr, *so_hdr2 = nullptr;
     bool so_filter = false;         // the last stream-only phase ran the filter path (events ev[1..6] are its)
@@ -202,6 +203,7 @@ namespace ssym {
     } while (0)
 
 int32_t ensure(ssym_ctx *ctx, DeviceBuf &b, size_t bytes);
+void release_deferred(ssym_ctx *ctx);        // after a stream-only step's synchronisation (comm.hip)
 
 // Every extern "C" entry point runs its body through this: the header promises that no C++ exception crosses
 // the boundary (a Rust or C caller cannot unwind through it).  std::bad_alloc from the host-side containers
