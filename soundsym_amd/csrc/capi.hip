@@ -495,7 +495,9 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
                     if (rc != SSYM_OK)
                         return rc;
                     colCtr = (unsigned long long *)((char *)ctx->abandon.ptr + ctx->abandon.bytes) - 1;
-                    SSYM_HIP_CHECK(ctx, hipMemsetAsync(colCtr, 0, sizeof(*colCtr), st));
+                    rc = zero_words(ctx, colCtr, sizeof(*colCtr));
+                    if (rc != SSYM_OK)
+                        return rc;
                 }
                 SSYM_HIP_CHECK(ctx, hipEventRecord(ev[6], st));
                 rc = launch_dtw_filter(ctx, src, tgt, cmat, abandon, colCtr, prune ? prune_cand_slots(ctx, tgt) : nullptr);

@@ -1095,7 +1095,9 @@ int32_t launch_dtw_exact(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet 
             return rcf;
         const int slot = ctx->pipe_slot++ & 7;
         unsigned *failCount = (unsigned *)ctx->pipe_flag.ptr + slot;
-        SSYM_HIP_CHECK(ctx, hipMemsetAsync(failCount, 0, sizeof(unsigned), st));
+        rcf = zero_words(ctx, failCount, sizeof(unsigned));
+        if (rcf != SSYM_OK)
+            return rcf;
         ctx->pipe_mask |= 1u << slot;
         redoFlag = failCount;
         const char *fg = getenv("SSYM_EXACT_PIPE_FORCE_GIVEUP");

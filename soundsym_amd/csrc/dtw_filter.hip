@@ -267,7 +267,9 @@ static int32_t launch_band_cfg2(ssym_ctx *ctx, const SegmentSet &src, const Segm
     if (rc != SSYM_OK)
         return rc;
     unsigned *taskCtr = (unsigned *)ctx->handoff.ptr;
-    SSYM_HIP_CHECK(ctx, hipMemsetAsync(taskCtr, 0, sizeof(unsigned), ctx->stream));
+    rc = zero_words(ctx, taskCtr, sizeof(unsigned));
+    if (rc != SSYM_OK)
+        return rc;
     // operand planes the kernel multiplies: record layout 3 leaves the third one zero
     const bool two = filter_mfmas(filter_pieces(filter_dim_used((int)src.dim)), filter_dim_used((int)src.dim)) == 2;
     auto kern = two ? dtw_band_kernel<NTB, WB, OCC, SQ, LASTN, PRUNE, 2> : dtw_band_kernel<NTB, WB, OCC, SQ, LASTN, PRUNE, 3>;
@@ -392,7 +394,9 @@ int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
     if (rc != SSYM_OK)
         return rc;
     unsigned *taskCtr = (unsigned *)((char *)ctx->handoff.ptr + handBytes);
-    SSYM_HIP_CHECK(ctx, hipMemsetAsync(taskCtr, 0, 4 * ctrBytes, ctx->stream));
+    rc = zero_words(ctx, taskCtr, 4 * ctrBytes);
+    if (rc != SSYM_OK)
+        return rc;
     hipStream_t st = ctx->stream;
     const bool sq = ctx->squared != 0;
     const float outScale = (float)(sq ? 1.0 / (scale * scale) : 1.0 / scale);

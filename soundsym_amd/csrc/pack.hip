@@ -35,6 +35,26 @@ int32_t ensure(ssym_ctx *ctx, DeviceBuf &b, size_t bytes)
     return SSYM_OK;
 }
 
+// Small device blocks on the matching path are zeroed by a kernel of this library: hipMemsetAsync runs as a runtime
+// blit kernel that costs 5-10 us of idle stream on either side of it (profiles/r03_share512_1gpu.md), four of them per
+// filter-path step.
+__global__ void zero_words_kernel(uint32_t *p, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        p[i] = 0u;
+}
+
+int32_t zero_words(ssym_ctx *ctx, void *p, size_t bytes)
+{
+    const size_t n = (bytes + 3) / 4;
+    if (n == 0)
+        return SSYM_OK;
+    zero_words_kernel<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>((uint32_t *)p, n);
+    SSYM_HIP_CHECK(ctx, hipGetLastError());
+    return SSYM_OK;
+}
+
 void release_deferred(ssym_ctx *ctx)
 {
     for (void *p : ctx->deferred_free)

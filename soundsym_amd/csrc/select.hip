@@ -583,7 +583,9 @@ int32_t launch_dtw_select2(ssym_ctx *ctx, const SegmentSet &src, const SegmentSe
     uint2 *pairs2 = (uint2 *)(hdr2 + 2);
     const unsigned tb = (tgt.n + 255) / 256;
     fill_u64_kernel<<<tb, 256, 0, st>>>(ub, kInfBits, tgt.n);
-    SSYM_HIP_CHECK(ctx, hipMemsetAsync(hdr2, 0, sizeof(uint32_t) * 2, st));
+    rc = zero_words(ctx, hdr2, sizeof(uint32_t) * 2);
+    if (rc != SSYM_OK)
+        return rc;
     const unsigned blocks = std::max(1u, std::min((cap + 255) / 256, 2048u));
     if (lower_bound_only) {
         // wide frames: a filter cost bounds the pair from below only, so no new upper bound comes out of
@@ -861,7 +863,9 @@ int32_t launch_dtw_select(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
         return rc;
     unsigned long long *mask = (unsigned long long *)ctx->selmask.ptr;
     uint32_t *cnt = (uint32_t *)ctx->selcnt.ptr, *fill = cnt + tgt.n;
-    SSYM_HIP_CHECK(ctx, hipMemsetAsync(cnt, 0, sizeof(uint32_t) * 2 * (size_t)tgt.n, st));
+    rc = zero_words(ctx, cnt, sizeof(uint32_t) * 2 * (size_t)tgt.n);
+    if (rc != SSYM_OK)
+        return rc;
     dim3 grid((tgt.n + 255) / 256, nChunks);
     dim3 markGrid((tgt.n + kSelTgt - 1) / kSelTgt, nChunks);
     dtw_mark_kernel<<<markGrid, kSelTgt * kSelSub, 0, st>>>(cmat, src.n, tgt.n, tgt.n_pad, dist_dev, src.len,

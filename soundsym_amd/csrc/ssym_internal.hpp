@@ -203,7 +203,8 @@ namespace ssym {
     } while (0)
 
 int32_t ensure(ssym_ctx *ctx, DeviceBuf &b, size_t bytes);
-void release_deferred(ssym_ctx *ctx);        // after a stream-only step's synchronisation (comm.hip)
+void release_deferred(ssym_ctx *ctx);
+int32_t zero_words(ssym_ctx *ctx, void *p, size_t bytes);     // a multiple of 4 bytes, zeroed by a kernel on the context's stream        // after a stream-only step's synchronisation (comm.hip)
 
 // Every extern "C" entry point runs its body through this: the header promises that no C++ exception crosses
 // the boundary (a Rust or C caller cannot unwind through it).  std::bad_alloc from the host-side containers
