@@ -290,7 +290,8 @@ def test_sharded_refcos_goes_through_the_matrix_pipe(oracle):
 # Failure containment (include/soundsym_amd.h, "FAILURE on one rank is part of the protocol"): no rank may be left
 # waiting, and a failure that can still be reported is reported by EVERY rank with the same status.
 # ---------------------------------------------------------------------------------------------------------
-def _run_ranks_with_fault(world, fault_rank, phase, kind, timeout_ms=20000, absent_rank=None, steps_after=1):
+def _run_ranks_with_fault(world, fault_rank, phase, kind, timeout_ms=20000, absent_rank=None, steps_after=1, prune=False,
+                          distance=None):
     """A thread per rank on the one GPU (in-process transport).  Returns per rank a dict: the status code the faulty
     step raised (None = no error), the seconds it took, whether the communicator is dead, and what a further step on
     the same communicator did."""
@@ -303,7 +304,7 @@ def _run_ranks_with_fault(world, fault_rank, phase, kind, timeout_ms=20000, abse
     to = np.arange(m + 1, dtype=np.uint64) * f
     e0 = Engine(metric="dtw", dtype="f32")
     so = np.arange(n + 1, dtype=np.uint64) * f
-    want = e0.match(e0.dictionary(g.sources.reshape(-1), so, dim), e0.queries(g.targets.reshape(-1), to, dim))
+    want = e0.match(e0.dictionary(g.sources.reshape(-1), so, dim), e0.queries(g.targets.reshape(-1), to, dim), distance=distance)
     e0.close()
     shards, bases = _split(list(g.sources), world, dim, np.float32)
     group = LocalGroup(world)
@@ -317,7 +318,7 @@ def _run_ranks_with_fault(world, fault_rank, phase, kind, timeout_ms=20000, abse
             q = e.queries(g.targets.reshape(-1), to, dim)
             comm = e.comm_create_local(group, r)
             comm.set_timeout(timeout_ms)
-            idx, cost = e.match_sharded(comm, d, q, index_base=bases[r])         # a healthy step first
+            idx, cost = e.match_sharded(comm, d, q, index_base=bases[r], prune=prune, distance=distance)         # a healthy step first
             res[r]["healthy"] = bool(np.array_equal(idx, want[0]) and np.array_equal(cost, want[1]))
             if r == fault_rank:
                 comm.inject_fault(phase, kind)
@@ -326,7 +327,7 @@ def _run_ranks_with_fault(world, fault_rank, phase, kind, timeout_ms=20000, abse
             code = None
             if r != absent_rank:
                 try:
-                    e.match_sharded(comm, d, q, index_base=bases[r])
+                    e.match_sharded(comm, d, q, index_base=bases[r], prune=prune, distance=distance)
                 except nat.SsymError as ex:
                     code, res[r]["msg"] = ex.code, str(ex)
             res[r]["code"], res[r]["seconds"] = code, time.perf_counter() - t0
@@ -334,7 +335,7 @@ def _run_ranks_with_fault(world, fault_rank, phase, kind, timeout_ms=20000, abse
             after = []
             for _ in range(steps_after):
                 try:
-                    idx, cost = e.match_sharded(comm, d, q, index_base=bases[r])
+                    idx, cost = e.match_sharded(comm, d, q, index_base=bases[r], prune=prune, distance=distance)
                     after.append(bool(np.array_equal(idx, want[0]) and np.array_equal(cost, want[1])))
                 except nat.SsymError as ex:
                     after.append(ex.code)
@@ -372,6 +373,17 @@ def test_a_failing_rank_takes_part_and_every_rank_returns_its_status(phase):
         assert not res[r]["dead"]
         assert res[r]["after"] == [True], (r, res[r])                      # the communicator is still in step
     assert "injected failure" in res[1]["msg"] and "injected failure" not in res[0]["msg"]
+
+
+def test_a_failing_rank_in_a_pruned_step_and_in_a_step_with_distances():
+    # the same rule through the step's other shapes: early abandoning (one more all-reduce, of the candidates' costs, in
+    # front of the filter) and per-target distances (uploaded by the phase that failed: the merge still needs them)
+    from soundsym_amd import _native as nat
+    for kw in (dict(prune=True), dict(distance=np.linspace(0.0, 20.0, 96))):
+        res = _run_ranks_with_fault(3, fault_rank=0, phase=1, kind=0, **kw)
+        for r in range(3):
+            assert res[r]["code"] == nat.SSYM_E_NOMEM and not res[r]["dead"], (kw, r, res[r])
+            assert res[r]["after"] == [True], (kw, r, res[r])
 
 
 @pytest.mark.parametrize("phase", [1, 2])
