@@ -64,11 +64,18 @@ __global__ void fill_u64_kernel(unsigned long long *p, unsigned long long v, uin
         p[i] = v;
 }
 
-__global__ void fill_u32_kernel(uint32_t *p, uint32_t v, uint32_t n)
+// one launch for the two (or three) small blocks a stage starts from: n keys at +inf, optionally n indices at
+// "none", optionally a two-word list header at zero
+__global__ void init_best_kernel(unsigned long long *key, uint32_t *idx, uint32_t n, uint32_t *hdr)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n)
-        p[i] = v;
+    if (i < n) {
+        key[i] = kInfBitsSel;
+        if (idx)
+            idx[i] = 0xffffffffu;
+    }
+    if (hdr && i < 2)
+        hdr[i] = 0;
 }
 
 constexpr int kSelChunk = 64;   // sources per (target, chunk) hit mask
@@ -582,10 +589,7 @@ int32_t launch_dtw_select2(ssym_ctx *ctx, const SegmentSet &src, const SegmentSe
     uint32_t *hdr2 = (uint32_t *)ctx->cand2.ptr;
     uint2 *pairs2 = (uint2 *)(hdr2 + 2);
     const unsigned tb = (tgt.n + 255) / 256;
-    fill_u64_kernel<<<tb, 256, 0, st>>>(ub, kInfBits, tgt.n);
-    rc = zero_words(ctx, hdr2, sizeof(uint32_t) * 2);
-    if (rc != SSYM_OK)
-        return rc;
+    init_best_kernel<<<tb, 256, 0, st>>>(ub, nullptr, tgt.n, hdr2);
     const unsigned blocks = std::max(1u, std::min((cap + 255) / 256, 2048u));
     if (lower_bound_only) {
         // wide frames: a filter cost bounds the pair from below only, so no new upper bound comes out of
@@ -894,8 +898,7 @@ int32_t launch_dtw_final(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet 
     const unsigned blocks = std::max(1u, std::min((cap + 255) / 256, 1024u));
     const unsigned blocks2 = std::max(blocks, std::min(tb, 1024u));
     if (k_top <= 1) {
-        fill_u64_kernel<<<tb, 256, 0, st>>>(bestKey, kInfBits, tgt.n);
-        fill_u32_kernel<<<tb, 256, 0, st>>>(bestIdx, 0xffffffffu, tgt.n);
+        init_best_kernel<<<tb, 256, 0, st>>>(bestKey, bestIdx, tgt.n, nullptr);
         dtw_final_key_kernel<<<blocks, 256, 0, st>>>(hdr, pairs, costs, cap, dist_dev, nullptr, nullptr, bestKey);
         dtw_final_idx_kernel<<<blocks, 256, 0, st>>>(hdr, pairs, costs, cap, dist_dev, nullptr, nullptr, bestKey,
                                                      bestIdx);
@@ -908,8 +911,7 @@ int32_t launch_dtw_final(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet 
         if (rc != SSYM_OK)
             return rc;
         for (uint32_t r = 0; r < k_top; ++r) {
-            fill_u64_kernel<<<tb, 256, 0, st>>>(bestKey, kInfBits, tgt.n);
-            fill_u32_kernel<<<tb, 256, 0, st>>>(bestIdx, 0xffffffffu, tgt.n);
+            init_best_kernel<<<tb, 256, 0, st>>>(bestKey, bestIdx, tgt.n, nullptr);
             dtw_final_key_kernel<<<blocks, 256, 0, st>>>(hdr, pairs, costs, cap, dist_dev, r ? prevKey : nullptr,
                                                          prevIdx, bestKey);
             dtw_final_idx_kernel<<<blocks, 256, 0, st>>>(hdr, pairs, costs, cap, dist_dev, r ? prevKey : nullptr,

@@ -436,3 +436,20 @@ def test_world1_rccl_fault_injection_and_abort():
     got = e.match(d, q)
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
     e.close()
+
+
+def test_library_communicator_beside_a_torch_nccl_process_group():
+    """The process shape of a bench.py rank at N > 1: torch.distributed's "nccl" group initialised and used first,
+    then the library's communicator, then both in turn (tools/rccl_beside_torch.py, its own process because a
+    process group is process-wide state).  The library must bind the RCCL that torch already loaded -- one copy of
+    RCCL in the process, not two -- and its sharded step must equal the unsharded match."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "rccl_beside_torch.py")], capture_output=True,
+                         text=True, timeout=600, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["comm_available"] and rec["sharded_equals_match"] and rec["planted"] and rec["torch_allreduce"] == 1.0
+    libs = [p for p in rec["rccl_mapped_after"] if "rccl" in p]
+    assert len(libs) == 1 and libs == [p for p in rec["rccl_mapped_before"] if "rccl" in p], rec
