@@ -101,24 +101,20 @@ __device__ __forceinline__ void refcos_epilogue(double4v (&acc)[4][4], RowInfo *
                                                 const double *__restrict__ tgtNorm, const double *__restrict__ dist,
                                                 double defaultDist, unsigned long long *__restrict__ thr,
                                                 uint32_t *__restrict__ hdr, PairEntry *__restrict__ list, uint32_t cap,
-                                                double *__restrict__ dotOut, uint32_t kTop)
+                                                double *__restrict__ dotOut, uint32_t kTop, bool plain)
 {
     // ---- epilogue: dots -> key intervals -> thresholds and list 1 ------------------------------------------
-    // D[4 i + lane / 16][lane % 16]: this lane holds, per block pair (a, b), source rows 4 i + lg and target column lr
-    // per-segment values of the tile into LDS (the staging buffers are free now: the loop's last barrier is behind us)
-    {
-        const bool isS = tid < kMT;
-        const uint32_t g = isS ? sTile + tid : tTile + (tid - kMT);
-        const uint32_t n = isS ? nSrc : nTgt;
-        const double *nr = isS ? srcNorm : tgtNorm;
-        RowInfo r;
-        r.norm = g < n ? nr[g] : 0.0;
-        r.sq = g < n ? nr[n + g] : 0.0;
-        r.inv = g < n ? nr[2 * (size_t)n + g] : 0.0;
-        r.dist = (!isS && dist && g < n) ? dist[g] : defaultDist;
-        info[tid] = r;
+    // D[4 i + lane / 16][lane % 16]: this lane holds, per block pair (a, b), source rows 4 i + lg and target column lr.
+    // `info` (per-segment values of the tile) was written before the main loop: no load and no barrier stands between
+    // the last MFMA and the first interval.  The thresholds seen so far are fetched NOW and used after pass 1 (any
+    // earlier value of a threshold is a valid, looser one: thresholds only fall), so the epilogue's chain of memory
+    // round trips is one -- the reservation in list 1 -- instead of nine (round 3).
+    unsigned long long seenBits[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const uint32_t t = tTile + wn * 64 + b * 16 + lr;
+        seenBits[b] = t < nTgt ? __hip_atomic_load(&thr[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kInfBitsU;
     }
-    __syncthreads();
     const double INF = __builtin_inf();
     const double cUnit = 1.1102230246251565e-16 * 1.02;
     // (segments beyond the sets' ends carry norm 0 in `info`: their pairs come out as [+inf, +inf] without a test)
@@ -135,32 +131,71 @@ __device__ __forceinline__ void refcos_epilogue(double4v (&acc)[4][4], RowInfo *
         colMin[b] = INF;
     }
     double khis[TOPK ? 4 : 1][TOPK ? 4 : 1][TOPK ? 4 : 1];
+    if (!WRITE_SIMS && plain) {
+        // Every segment of this wave's 64 rows and 64 columns is PLAIN (inside the sets, norm in [1e-139, 1e139], hence
+        // all its values finite; a finite distance): none of refcos_key_interval's tests can fire -- nrm and inv are
+        // products of two factors within 1e+-139, every dot is finite -- and what is left is the arithmetic, with the
+        // factors that belong to a row or a column alone taken out of the pair (rq = sq * inv, the length factor:
+        // (3 min(la, lb) + 16) = min over the two; the roundings this moves are paid from the 1.0001 * 1.02 of slack
+        // the bound carries for exactly that).  16 operations per pair instead of ~45 with their selects.
+        const double u = 1.1102230246251565e-16;
+        double cq[4], cLb[4], dabs9[4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = wm * 64 + a * 16 + 4 * i + lg;
-            const RowInfo ri = info[row];
-            const unsigned la = sLen[row];
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const unsigned len = la < lb[b] ? la : lb[b];               // src/sound.rs:24-28
-                const double nrm = __dmul_rn(ri.norm, ci[b].norm);          // src/sound.rs:30
-                double klo, khi;
-                refcos_key_interval(acc[a][b][i], ri.sq * ci[b].sq, ri.inv * ci[b].inv, nrm, (3.0 * (double)len + 16.0) * cUnit,
-                                    ci[b].dist, klo, khi);
-                if (WRITE_SIMS) {
-                    const uint32_t s = sTile + row, t = tTile + wn * 64 + b * 16 + lr;
-                    if (s < nSrc && t < nTgt)
-                        dotOut[(size_t)s * nTgt + t] = __ddiv_rn(acc[a][b][i], nrm);
-                }
-                acc[a][b][i] = klo;
-                if (TOPK)
-                    khis[b][a][i] = khi;
-                else
-                    colMin[b] = fmin(colMin[b], khi);
-            }
+        for (int b = 0; b < 4; ++b) {
+            cq[b] = ci[b].sq * ci[b].inv;
+            cLb[b] = 1.0001 * ((3.0 * (double)lb[b] + 16.0) * cUnit);
+            dabs9[b] = fabs(ci[b].dist);
         }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = wm * 64 + a * 16 + 4 * i + lg;
+                const RowInfo ri = info[row];
+                const double rq = ri.sq * ri.inv;
+                const double cLa = 1.0001 * ((3.0 * (double)sLen[row] + 16.0) * cUnit);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const double sv = acc[a][b][i] * (ri.inv * ci[b].inv);
+                    const double z = fabs(sv - ci[b].dist);
+                    const double R = __fma_rn(9.0 * u, fabs(sv) + dabs9[b], fmin(cLa, cLb[b]) * (rq * cq[b])) + 1e-290;
+                    acc[a][b][i] = fmax((z - R) * (1.0 - 4.0 * u), 0.0);
+                    const double khi = (z + R) * (1.0 + 4.0 * u);
+                    if (TOPK)
+                        khis[b][a][i] = khi;
+                    else
+                        colMin[b] = fmin(colMin[b], khi);
+                }
+            }
+    } else {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = wm * 64 + a * 16 + 4 * i + lg;
+                const RowInfo ri = info[row];
+                const unsigned la = sLen[row];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const unsigned len = la < lb[b] ? la : lb[b];               // src/sound.rs:24-28
+                    const double nrm = __dmul_rn(ri.norm, ci[b].norm);          // src/sound.rs:30
+                    double klo, khi;
+                    refcos_key_interval(acc[a][b][i], ri.sq * ci[b].sq, ri.inv * ci[b].inv, nrm,
+                                        (3.0 * (double)len + 16.0) * cUnit, ci[b].dist, klo, khi);
+                    if (WRITE_SIMS) {
+                        const uint32_t s = sTile + row, t = tTile + wn * 64 + b * 16 + lr;
+                        if (s < nSrc && t < nTgt)
+                            dotOut[(size_t)s * nTgt + t] = __ddiv_rn(acc[a][b][i], nrm);
+                    }
+                    acc[a][b][i] = klo;
+                    if (TOPK)
+                        khis[b][a][i] = khi;
+                    else
+                        colMin[b] = fmin(colMin[b], khi);
+                }
+            }
+    }
+    double cur[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         const int col = wn * 64 + b * 16 + lr;
@@ -186,48 +221,53 @@ __device__ __forceinline__ void refcos_epilogue(double4v (&acc)[4][4], RowInfo *
             cmin = fmin(cmin, __shfl_xor(cmin, 16));
             cmin = fmin(cmin, __shfl_xor(cmin, 32));
         }
-        unsigned long long seen = kInfBitsU;
-        if (lg == 0 && t < nTgt)
-            seen = atomicMin(&thr[t], (unsigned long long)__double_as_longlong(cmin));    // keys are >= 0: bits order like values
-        seen = __shfl(seen, lr);
-        const double cur = fmin(cmin, __longlong_as_double((long long)seen));
-        // list 1: pairs the threshold known so far does not exclude (the final threshold can only be smaller).  A lane
-        // counts its own, one prefix sum over the wave and ONE atomic reserve the room, then every lane writes its entries.
-        unsigned mine = 0;
+        if (lg == 0 && t < nTgt && cmin < INF)                            // nothing waits for this one
+            atomicMin(&thr[t], (unsigned long long)__double_as_longlong(cmin));           // keys are >= 0: bits order like values
+        // list 1: pairs the threshold known so far does not exclude (the final threshold can only be smaller); capped at
+        // the largest finite value, so that "key_lo <= cur" also says "key_lo is finite" (+inf: a pair that cannot win)
+        cur[b] = fmin(fmin(cmin, __longlong_as_double((long long)seenBits[b])), 1.7976931348623157e308);
+    }
+    // Count, reserve, write: the count is a sum of wave-wide ballots (scalar), ONE atomic reserves the room, and the write
+    // pass skips a register slot none of the 64 lanes has an entry in with a scalar branch; a lane's position inside a
+    // slot is the number of entries below its lane (mbcnt) -- no prefix sum, no per-entry branch on the common path.
+    unsigned total = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                mine += (acc[a][b][i] <= cur && acc[a][b][i] < INF) ? 1u : 0u;
-        unsigned incl = mine;                                             // inclusive prefix sum over the 64 lanes
+                total += (unsigned)__popcll(__ballot(acc[a][b][i] <= cur[b]));
+    if (total) {                                                          // wave-uniform
+        uint32_t base = 0;
+        if (lane == 0)
+            base = atomicAdd(&hdr[0], total);
+        base = __builtin_amdgcn_readfirstlane(base);
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned up = __shfl_up(incl, o);
-            incl += lane >= o ? up : 0u;
-        }
-        const unsigned total = __shfl(incl, 63);
-        if (total) {                                                      // wave-uniform
-            uint32_t base = 0;
-            if (lane == 0)
-                base = atomicAdd(&hdr[0], total);
-            uint32_t pos = __shfl(base, 0) + incl - mine;
+        for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (acc[a][b][i] <= cur && acc[a][b][i] < INF) {
-                        if (pos < cap) {
-                            PairEntry e;
-                            e.s = sTile + wm * 64 + a * 16 + 4 * i + lg;
-                            e.t = t;
-                            e.key_lo = acc[a][b][i];
-                            list[pos] = e;
-                        } else {
-                            hdr[1] = 1;
+                for (int i = 0; i < 4; ++i) {
+                    const bool in = acc[a][b][i] <= cur[b];
+                    const unsigned long long m = __ballot(in);
+                    if (m) {                                              // wave-uniform
+                        const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
+                                                                              __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                        if (in) {
+                            if (pos < cap) {
+                                PairEntry e;
+                                e.s = sTile + wm * 64 + a * 16 + 4 * i + lg;
+                                e.t = tTile + wn * 64 + b * 16 + lr;
+                                e.key_lo = acc[a][b][i];
+                                list[pos] = e;
+                            } else {
+                                hdr[1] = 1;
+                            }
                         }
-                        ++pos;
+                        base += (unsigned)__popcll(m);
                     }
-        }
+                }
     }
 }
 
@@ -255,6 +295,8 @@ __global__ __launch_bounds__(256, 2) void refcos_mfma_kernel(
     __shared__ unsigned long long sBase[kMT + kNT];
     __shared__ unsigned sLen[kMT + kNT];
     __shared__ unsigned sMaxLen[2];
+    __shared__ unsigned sPlain[4];                         // rows 0..63, 64..127, columns 0..63, 64..127: all plain?
+    __shared__ RowInfo sInfo[kMT + kNT];                   // the epilogue's per-segment values, fetched up front
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -263,6 +305,8 @@ __global__ __launch_bounds__(256, 2) void refcos_mfma_kernel(
 
     if (tid < 2)
         sMaxLen[tid] = 0;
+    if (tid < 4)
+        sPlain[tid] = 1;
     __syncthreads();
     {
         const bool isS = tid < kMT;
@@ -278,6 +322,18 @@ __global__ __launch_bounds__(256, 2) void refcos_mfma_kernel(
         sBase[tid] = base;
         sLen[tid] = len;
         atomicMax(&sMaxLen[isS ? 0 : 1], len);
+        // (segments beyond the sets' ends carry norm 0: their pairs come out as [+inf, +inf] without a test)
+        const double *nr = isS ? srcNorm : tgtNorm;
+        RowInfo r;
+        r.norm = g < n ? nr[g] : 0.0;
+        r.sq = g < n ? nr[n + g] : 0.0;
+        r.inv = g < n ? nr[2 * (size_t)n + g] : 0.0;
+        r.dist = (!isS && dist && g < n) ? dist[g] : defaultDist;
+        sInfo[tid] = r;
+        // plain: what the epilogue's short form may assume of a segment (refcos_epilogue)
+        const bool ok = g < n && r.norm >= 1e-139 && r.norm <= 1e139 && fabs(r.dist) <= 1e300;
+        if (!ok)
+            atomicAnd(&sPlain[tid >> 6], 0u);
     }
     __syncthreads();
     const unsigned kMax = min(sMaxLen[0], sMaxLen[1]);    // beyond it every product of the tile is zero
@@ -410,8 +466,9 @@ __global__ __launch_bounds__(256, 2) void refcos_mfma_kernel(
         return;
     }
 #endif
-    refcos_epilogue<WRITE_SIMS, TOPK>(acc, reinterpret_cast<RowInfo *>(&sA0[0]), sLen, tid, lane, wm, wn, lr, lg, sTile, tTile,
-                                      nSrc, nTgt, srcNorm, tgtNorm, dist, defaultDist, thr, hdr, list, cap, dotOut, kTop);
+    refcos_epilogue<WRITE_SIMS, TOPK>(acc, sInfo, sLen, tid, lane, wm, wn, lr, lg, sTile, tTile,
+                                      nSrc, nTgt, srcNorm, tgtNorm, dist, defaultDist, thr, hdr, list, cap, dotOut, kTop,
+                                      (sPlain[wm] & sPlain[2 + wn]) != 0);
 }
 
 // list 1 against the final thresholds -> list 2 (pairs only)

@@ -185,6 +185,45 @@ def test_refcos_mfma_search_is_bit_exact(oracle, n, m, fmin, fmax, dim):
     e.close()
 
 
+def test_refcos_mfma_segments_outside_the_plain_range_take_the_long_epilogue(oracle):
+    """The epilogue has a short form for waves whose 64 + 64 segments are all plain (norm in [1e-139, 1e139], finite
+    distance) and the full refcos_key_interval for the rest: tiny, huge, infinite and NaN segments are spread over the
+    quadrants of the 128 x 128 tiles so that both forms run inside one workgroup, and every index and value must
+    still be the oracle's bit for bit."""
+    n = m = 384
+    dim = 12
+    src, tgt = _refcos_sets(0x5EED7A00, n, m, 90, 128, dim)
+    src[70] = src[70] * 1e-80                     # norm ~1e-157: 1 / norm finite, products with huge partners fine
+    src[140] = src[140] * 1e80                    # norm ~1e163
+    src[141] = src[141] * 1e-160                  # norm underflows to 0 (or a subnormal)
+    src[300][3, 2] = np.inf
+    tgt[66] = tgt[66] * 1e-75
+    tgt[130][0, 0] = np.nan
+    tgt[200][5, 1] = -np.inf
+    tgt[260] = tgt[260] * 1e78
+    tgt[10] = src[20].copy()                      # (plain near-duplicates elsewhere)
+    tgt[333] = src[350].copy()
+    sf, so = pack_segments(src, dim)
+    tf, to = pack_segments(tgt, dim)
+    e = Engine(metric="refcos", dtype="f64")
+    d, q = e.dictionary(sf, so, dim), e.queries(tf, to, dim)
+    with np.errstate(all="ignore"):
+        want_idx, want_val = oracle.refcos_match_all(sf, so, tf, to, dim)
+    idx, val = e.match(d, q)
+    assert e.timings()["used_filter"] == 1
+    assert np.array_equal(idx, want_idx) and np.array_equal(val, want_val, equal_nan=True)
+    assert idx[10] == 20 and idx[333] == 350
+    dist = np.linspace(-0.5, 1.5, m)
+    dist[77] = np.nan
+    dist[150] = np.inf
+    dist[290] = 1e301
+    with np.errstate(all="ignore"):
+        w_idx, w_val = oracle.refcos_match_all(sf, so, tf, to, dim, distance=dist)
+    idx2, val2 = e.match(d, q, distance=dist)
+    assert np.array_equal(idx2, w_idx) and np.array_equal(val2, w_val, equal_nan=True)
+    e.close()
+
+
 def nat_pair_matrix(e, d, q, mode):
     import ctypes
     from soundsym_amd import _native as nat

@@ -78,6 +78,28 @@ def key_interval(dotm, na, nb, length, d):
     return klo, khi
 
 
+def key_interval_plain(dotm, na, nb, length, d):
+    """The epilogue's short form for PLAIN segments (norms in [1e-139, 1e139], finite distance: refcos_epilogue): the
+    same bound with the factors of a row or a column alone taken out of the pair, one fused multiply-add, max for the
+    select -- same operations in the same order as the kernel."""
+    f64 = np.float64
+    sa = float(np.sqrt(f64(na))) * (1.0 + 4.5e-16)
+    sb = float(np.sqrt(f64(nb))) * (1.0 + 4.5e-16)
+    ia, ib = float(f64(1.0) / f64(na)), float(f64(1.0) / f64(nb))
+    rq, cq = float(f64(sa) * f64(ia)), float(f64(sb) * f64(ib))
+    cl = float(f64(1.0001) * ((f64(3.0) * f64(length) + f64(16.0)) * f64(U * 1.02)))       # min(cLa, cLb): equal lengths here
+    sv = float(f64(dotm) * (f64(ia) * f64(ib)))
+    z = abs(float(f64(sv) - f64(d)))
+    R = float(f64(fma(9.0 * U, float(abs(f64(sv)) + abs(f64(d))), float(f64(cl) * (f64(rq) * f64(cq))))) + f64(1e-290))
+    klo = max(float(f64(z - R) * f64(1.0 - 4.0 * U)), 0.0)
+    khi = float(f64(z + R) * f64(1.0 + 4.0 * U))
+    return klo, khi
+
+
+def is_plain(na, nb, d):
+    return 1e-139 <= na <= 1e139 and 1e-139 <= nb <= 1e139 and abs(d) <= 1e300
+
+
 @pytest.mark.parametrize("length", [1, 7, 8, 9, 100, 1536])
 @pytest.mark.parametrize("scale", [1e-120, 1e-3, 1.0, 3e4, 1e100])
 def test_reference_key_lies_inside_the_interval_for_any_order(length, scale):
@@ -110,5 +132,9 @@ def test_reference_key_lies_inside_the_interval_for_any_order(length, scale):
                     assert klo == np.inf                            # the reference's key is NaN / inf: never a winner
                     continue
                 assert klo <= k_ref <= khi, (length, scale, trial, d, dotm, d_ref, klo, k_ref, khi)
+                if is_plain(na, nb, d):                             # the short form holds the same key, about as tightly
+                    plo, phi = key_interval_plain(dotm, na, nb, length, d)
+                    assert plo <= k_ref <= phi, (length, scale, trial, d, dotm, d_ref, plo, k_ref, phi)
+                    assert abs(plo - klo) <= 1e-3 * (khi - klo) and abs(phi - khi) <= 1e-3 * (khi - klo)
                 if scale == 1.0 and np.isfinite(khi):               # and it is an interval worth having
                     assert khi - klo <= 1e-9 * (abs(d_ref / nrm) + abs(d)) + 1e-11 * length / np.sqrt(nrm)
