@@ -106,15 +106,9 @@ __device__ __forceinline__ void refcos_epilogue(double4v (&acc)[4][4], RowInfo *
     // ---- epilogue: dots -> key intervals -> thresholds and list 1 ------------------------------------------
     // D[4 i + lane / 16][lane % 16]: this lane holds, per block pair (a, b), source rows 4 i + lg and target column lr.
     // `info` (per-segment values of the tile) was written before the main loop: no load and no barrier stands between
-    // the last MFMA and the first interval.  The thresholds seen so far are fetched NOW and used after pass 1 (any
-    // earlier value of a threshold is a valid, looser one: thresholds only fall), so the epilogue's chain of memory
-    // round trips is one -- the reservation in list 1 -- instead of nine (round 3).
-    unsigned long long seenBits[4];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        const uint32_t t = tTile + wn * 64 + b * 16 + lr;
-        seenBits[b] = t < nTgt ? __hip_atomic_load(&thr[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kInfBitsU;
-    }
+    // the last MFMA and the first interval.  The four column blocks' thresholds travel as four atomics issued back to
+    // back (their return values are the freshest thresholds there are) and the room in list 1 is reserved once per wave:
+    // two memory round trips per epilogue instead of nine (round 3).
     const double INF = __builtin_inf();
     const double cUnit = 1.1102230246251565e-16 * 1.02;
     // (segments beyond the sets' ends carry norm 0 in `info`: their pairs come out as [+inf, +inf] without a test)
@@ -198,8 +192,6 @@ __device__ __forceinline__ void refcos_epilogue(double4v (&acc)[4][4], RowInfo *
     double cur[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-        const int col = wn * 64 + b * 16 + lr;
-        const uint32_t t = tTile + col;
         double cmin = colMin[b];
         // smallest key_hi of the wave's 64 rows in this column (TOPK: the kTop-th smallest distinct one), then against
         // the threshold every tile works on
@@ -221,11 +213,22 @@ __device__ __forceinline__ void refcos_epilogue(double4v (&acc)[4][4], RowInfo *
             cmin = fmin(cmin, __shfl_xor(cmin, 16));
             cmin = fmin(cmin, __shfl_xor(cmin, 32));
         }
-        if (lg == 0 && t < nTgt && cmin < INF)                            // nothing waits for this one
-            atomicMin(&thr[t], (unsigned long long)__double_as_longlong(cmin));           // keys are >= 0: bits order like values
+        cur[b] = cmin;
+    }
+    unsigned long long seenBits[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const uint32_t t = tTile + wn * 64 + b * 16 + lr;
+        seenBits[b] = kInfBitsU;
+        if (lg == 0 && t < nTgt)
+            seenBits[b] = atomicMin(&thr[t], (unsigned long long)__double_as_longlong(cur[b]));
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        seenBits[b] = __shfl(seenBits[b], lr);
         // list 1: pairs the threshold known so far does not exclude (the final threshold can only be smaller); capped at
         // the largest finite value, so that "key_lo <= cur" also says "key_lo is finite" (+inf: a pair that cannot win)
-        cur[b] = fmin(fmin(cmin, __longlong_as_double((long long)seenBits[b])), 1.7976931348623157e308);
+        cur[b] = fmin(fmin(cur[b], __longlong_as_double((long long)seenBits[b])), 1.7976931348623157e308);
     }
     // Count, reserve, write: the count is a sum of wave-wide ballots (scalar), ONE atomic reserves the room, and the write
     // pass skips a register slot none of the 64 lanes has an entry in with a scalar branch; a lane's position inside a
@@ -294,17 +297,23 @@ __global__ __launch_bounds__(256, 2) void refcos_mfma_kernel(
     __shared__ __attribute__((aligned(16))) double sB0[kNT * kLdk], sB1[kNT * kLdk];
     __shared__ unsigned long long sBase[kMT + kNT];
     __shared__ unsigned sLen[kMT + kNT];
-    __shared__ unsigned sMaxLen[2];
+    __shared__ unsigned sMaxLen[2], sMinLen[2], sOdd;
+    __shared__ unsigned long long sEnd[2];                 // one past the last value of the tile's segments, per side
     __shared__ unsigned sPlain[4];                         // rows 0..63, 64..127, columns 0..63, 64..127: all plain?
     __shared__ RowInfo sInfo[kMT + kNT];                   // the epilogue's per-segment values, fetched up front
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // (scalar: LDS bases of the DMAs)
     const int wm = wave >> 1, wn = wave & 1;              // this wave's 64 x 64 quadrant
     const uint32_t sTile = blockIdx.y * kMT, tTile = blockIdx.x * kNT;
 
-    if (tid < 2)
+    if (tid < 2) {
         sMaxLen[tid] = 0;
+        sMinLen[tid] = 0xffffffffu;
+        sEnd[tid] = 0;
+    }
+    if (tid == 2)
+        sOdd = 0;
     if (tid < 4)
         sPlain[tid] = 1;
     __syncthreads();
@@ -322,6 +331,10 @@ __global__ __launch_bounds__(256, 2) void refcos_mfma_kernel(
         sBase[tid] = base;
         sLen[tid] = len;
         atomicMax(&sMaxLen[isS ? 0 : 1], len);
+        atomicMin(&sMinLen[isS ? 0 : 1], len);
+        atomicMax(&sEnd[isS ? 0 : 1], base + len);
+        if (len & 1)
+            atomicOr(&sOdd, 1u);
         // (segments beyond the sets' ends carry norm 0: their pairs come out as [+inf, +inf] without a test)
         const double *nr = isS ? srcNorm : tgtNorm;
         RowInfo r;
@@ -356,8 +369,21 @@ __global__ __launch_bounds__(256, 2) void refcos_mfma_kernel(
     // after it has landed.
     const int sr = tid >> 3;                               // row of sweep 0 (32 rows per sweep, 4 sweeps)
     const int se = 2 * ((tid & 7) ^ ((sr >> 1) & 7));      // the two elements of the piece this lane's position holds
-    const unsigned long long tbA = min(sBase[0], srcVals - 1), tbB = min(sBase[kMT], tgtVals - 1);
+    auto uniform64 = [](unsigned long long v) {            // a value every lane holds, moved to scalar registers
+        return (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)v) |
+               ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) << 32);
+    };
+    const unsigned long long tbA = uniform64(min(sBase[0], srcVals - 1)), tbB = uniform64(min(sBase[kMT], tgtVals - 1));
     const double *const tileA = srcRaw + tbA, *const tileB = tgtRaw + tbB;
+    // The SHORT form of a chunk's fetch (round 3): while a chunk lies inside EVERY segment of the tile -- all of them on
+    // equal-length sets, all but the tail on ragged ones -- nothing has to be selected per lane, and a row's address is
+    // (tile base + 128 bytes per chunk) in scalar registers plus a 32-bit byte offset per lane that never changes: the
+    // eight DMAs of a chunk cost no vector instruction at all.  (Vector instructions issued beside the f64 MFMAs are
+    // what the staging cost: ~130 per two chunks took 14 % of the kernel with the barrier and the misses free, 5.5.)
+    const unsigned long long spanA = uniform64(sEnd[0]) - tbA, spanB = uniform64(sEnd[1]) - tbB;
+    const bool spanOk = sEnd[0] >= tbA && sEnd[1] >= tbB && spanA < (1ull << 29) && spanB < (1ull << 29);
+    const unsigned fastLen = spanOk ? (unsigned)__builtin_amdgcn_readfirstlane(min(sMinLen[0], sMinLen[1])) : 0u;
+    const bool tileOdd = __builtin_amdgcn_readfirstlane(sOdd) != 0;
     unsigned relA[4], relB[4], lenA[4], lenB[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -367,10 +393,30 @@ __global__ __launch_bounds__(256, 2) void refcos_mfma_kernel(
         relA[p] = lenA[p] ? (unsigned)(sBase[row] - tbA) : 0u;
         relB[p] = lenB[p] ? (unsigned)(sBase[kMT + row] - tbB) : 0u;
     }
-    unsigned stE = 0;
+    unsigned offA[4], offB[4];                             // byte offsets of this lane's pieces from the tile's chunk base
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        offA[p] = (relA[p] + (unsigned)se) * 8u;
+        offB[p] = (relB[p] + (unsigned)se) * 8u;
+    }
     auto fetch = [&](unsigned c, auto BUF) {               // DMAs only: nothing here waits for them
         double *const dA = decltype(BUF)::value ? sA1 : sA0, *const dB = decltype(BUF)::value ? sB1 : sB0;
-        stE = c * kKC + se;
+        if ((c + 1) * kKC <= fastLen) {                    // (scalar)
+            const char *ua = (const char *)(tileA + (size_t)c * kKC), *ub = (const char *)(tileB + (size_t)c * kKC);
+            // (opaque to the optimiser: it would otherwise fold the chunk's base into 64-bit vector additions per row
+            // instead of the scalar-base + 32-bit-offset form of the instruction)
+            asm volatile("" : "+s"(ua), "+s"(ub));
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                asm volatile("" : "+v"(offA[p]), "+v"(offB[p]));      // (the zero-extension stays here, inside the instruction)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ua + offA[p]),
+                                                 (__attribute__((address_space(3))) void *)&dA[(32 * p + 8 * wave) * kLdk], 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ub + offB[p]),
+                                                 (__attribute__((address_space(3))) void *)&dB[(32 * p + 8 * wave) * kLdk], 16, 0, 0);
+            }
+            return;
+        }
+        const unsigned stE = c * kKC + se;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const double *ga = stE < lenA[p] ? tileA + relA[p] + stE : zeros;
@@ -382,10 +428,13 @@ __global__ __launch_bounds__(256, 2) void refcos_mfma_kernel(
                                              (__attribute__((address_space(3))) void *)&dB[(32 * p + 8 * wave) * kLdk], 16, 0, 0);
         }
     };
-    auto stash = [&](auto BUF) {                           // once the DMAs have landed: the straddling pieces
+    auto stash = [&](unsigned c, auto BUF) {               // once the DMAs have landed: the straddling pieces
         double *const dA = decltype(BUF)::value ? sA1 : sA0, *const dB = decltype(BUF)::value ? sB1 : sB0;
         __builtin_amdgcn_s_waitcnt(rm_wait_vmcnt(0));
         asm volatile("" ::: "memory");
+        if (!tileOdd)                                      // (scalar: no segment of the tile has an odd length)
+            return;
+        const unsigned stE = c * kKC + se;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int row = sr + 32 * p;
@@ -410,7 +459,7 @@ __global__ __launch_bounds__(256, 2) void refcos_mfma_kernel(
         constexpr bool kOdd = decltype(BUF)::value;
         using Other = std::integral_constant<bool, !kOdd>;
         const double *const rA = kOdd ? sA1 : sA0, *const rB = kOdd ? sB1 : sB0;
-#ifndef SSYM_RM_NOFETCH   // (tools only: without it the MFMAs run on the first chunk over and over)
+#if !defined(SSYM_RM_NOFETCH) && !defined(SSYM_RM_NODMA)   // (tools only: without it the MFMAs run on the first chunk over and over)
         if (c + 1 < nChunks)
             fetch(c + 1, Other{});                         // in flight under the MFMAs (DMA: straight into the other buffer,
                                                            // which nobody has read since the barrier that ended chunk c - 1)
@@ -436,15 +485,17 @@ __global__ __launch_bounds__(256, 2) void refcos_mfma_kernel(
 #ifndef SSYM_RM_NOFETCH
 #endif
         }
-#ifndef SSYM_RM_NOFETCH
+#if !defined(SSYM_RM_NOFETCH) && !defined(SSYM_RM_NODMA)
         if (c + 1 < nChunks)
-            stash(Other{});                                // the DMAs were issued 64 MFMAs ago: this wait is a formality
+            stash(c + 1, Other{});                         // the DMAs were issued 64 MFMAs ago: this wait is a formality
+#endif
+#if !defined(SSYM_RM_NOFETCH) && !defined(SSYM_RM_NOBAR)   // (tools only: timing without the barrier / without the DMAs)
         __syncthreads();
 #endif
     };
     if (nChunks > 0) {
         fetch(0, std::false_type{});
-        stash(std::false_type{});
+        stash(0, std::false_type{});
     }
     __syncthreads();
     for (unsigned c = 0; c < nChunks; c += 2) {

@@ -16,7 +16,8 @@ q = e.queries(g.targets.astype(np.float64).reshape(-1) * 0.02, off, d)
 for _ in range(3):
     e.match(dd, q)
 tm = e.timings()
-print("4096x4096x128f x12d refcos: sims %.3f ms, total %.3f ms (%.3g pairs/s)" % (tm["main_ms"], tm["total_ms"], n * m / tm["total_ms"] * 1e3), flush=True)
+print("4096x4096x128f x12d refcos: sims %.3f ms, total %.3f ms (%.3g pairs/s); list 1 / list 2: %d / %d pairs" % (
+    tm["main_ms"], tm["total_ms"], n * m / tm["total_ms"] * 1e3, tm.get("n_candidates", -1), tm.get("n_refined", -1)), flush=True)
 src, tgt = synth.make_ragged(2048, 2048, 4, 160, d, 0x5EED0A77)
 sf2, so2 = pack_segments([x * 0.02 for x in src], d, np.float64)
 tf2, to2 = pack_segments([x * 0.02 for x in tgt], d, np.float64)
