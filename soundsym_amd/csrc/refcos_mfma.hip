@@ -305,7 +305,23 @@ __global__ __launch_bounds__(256, 2) void refcos_mfma_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // (scalar: LDS bases of the DMAs)
     const int wm = wave >> 1, wn = wave & 1;              // this wave's 64 x 64 quadrant
-    const uint32_t sTile = blockIdx.y * kMT, tTile = blockIdx.x * kNT;
+    // Tile of this workgroup.  Workgroups go to the eight XCDs round robin (id % 8), each XCD with its own L2: XCD k takes
+    // the k-th eighth of the tiles in an order that walks panels of eight tile columns row by row, so the 64 workgroups
+    // an XCD runs at a time cover 8 x 8 tiles -- 16 operand stripes for 64 tiles (identity order: 4 + 16 for 64).
+    uint32_t bx = blockIdx.x, by = blockIdx.y;
+#ifndef SSYM_RM_NOXCD
+    {
+        const uint32_t nx = gridDim.x, ny = gridDim.y, total = nx * ny;
+        if ((nx & 7u) == 0 && (total & 7u) == 0) {
+            const uint32_t lin = bx + nx * by;
+            const uint32_t q = (lin & 7u) * (total >> 3) + (lin >> 3);
+            const uint32_t r = q % (8u * ny);
+            bx = 8u * (q / (8u * ny)) + (r & 7u);
+            by = r >> 3;
+        }
+    }
+#endif
+    const uint32_t sTile = by * kMT, tTile = bx * kNT;
 
     if (tid < 2) {
         sMaxLen[tid] = 0;
@@ -430,7 +446,9 @@ __global__ __launch_bounds__(256, 2) void refcos_mfma_kernel(
     };
     auto stash = [&](unsigned c, auto BUF) {               // once the DMAs have landed: the straddling pieces
         double *const dA = decltype(BUF)::value ? sA1 : sA0, *const dB = decltype(BUF)::value ? sB1 : sB0;
+#ifndef SSYM_RM_NOWAIT    // (tools only: what does waiting for the DMAs cost?)
         __builtin_amdgcn_s_waitcnt(rm_wait_vmcnt(0));
+#endif
         asm volatile("" ::: "memory");
         if (!tileOdd)                                      // (scalar: no segment of the tile has an odd length)
             return;
