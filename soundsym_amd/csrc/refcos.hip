@@ -326,7 +326,17 @@ __global__ __launch_bounds__(256) void refcos_match_one_kernel(
     }
     const uint32_t qb = len / 8, rem = len % 8;
     double p = 0.0;                                 // running sum p_i of rulinalg's dot
-    for (uint32_t k = 0; k < qb; ++k)
+    uint32_t k = 0;
+    for (; k + 16 <= qb; k += 16) {                          // (sixteen blocks' loads in flight, then the chain of sums)
+        double av[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            av[u] = srcRaw[base + 8 * (k + u) + i8];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            p = __dadd_rn(p, __dmul_rn(av[u], sq[8 * (k + u) + i8]));
+    }
+    for (; k < qb; ++k)
         p = __dadd_rn(p, __dmul_rn(srcRaw[base + 8 * k + i8], sq[8 * k + i8]));
     const int g0 = (tid & 63) & ~7;                 // first lane of this entry's group of eight
     const double p0 = __shfl(p, g0 + 0), p1 = __shfl(p, g0 + 1), p2 = __shfl(p, g0 + 2), p3 = __shfl(p, g0 + 3);

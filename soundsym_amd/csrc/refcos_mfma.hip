@@ -590,8 +590,22 @@ __global__ __launch_bounds__(256) void refcos_pairs_kernel(
             len = la < lb ? la : lb;                                   // src/sound.rs:24-28
         }
         const uint32_t qb = len / 8, rem = len % 8;
+        // (the sum is a chain, the loads are not: sixteen blocks' operands are requested before the first is added --
+        // one load pair per trip made the kernel wait out a memory round trip per block of eight elements)
         double p = 0.0;
-        for (uint32_t j = 0; j < qb; ++j)
+        uint32_t j = 0;
+        for (; j + 16 <= qb; j += 16) {
+            double av[16], bv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                av[u] = srcRaw[ba + 8 * (j + u) + i8];
+                bv[u] = tgtRaw[bb + 8 * (j + u) + i8];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                p = __dadd_rn(p, __dmul_rn(av[u], bv[u]));
+        }
+        for (; j < qb; ++j)
             p = __dadd_rn(p, __dmul_rn(srcRaw[ba + 8 * j + i8], tgtRaw[bb + 8 * j + i8]));
         const double p0 = __shfl(p, g0 + 0), p1 = __shfl(p, g0 + 1), p2 = __shfl(p, g0 + 2), p3 = __shfl(p, g0 + 3);
         const double p4 = __shfl(p, g0 + 4), p5 = __shfl(p, g0 + 5), p6 = __shfl(p, g0 + 6), p7 = __shfl(p, g0 + 7);
