@@ -262,6 +262,7 @@ void free_segments(ssym_ctx *ctx, SegmentSet &set)
     dev_free(ctx, set.perm);
     dev_free(ctx, set.centroid);
     dev_free(ctx, set.len_order);
+    refcos_q8_release(ctx, set);
     set = SegmentSet{};
 }
 
@@ -277,6 +278,7 @@ static int32_t build_derived(ssym_ctx *ctx, SegmentSet &set)
     dev_free(ctx, set.perm); set.perm = nullptr;
     dev_free(ctx, set.centroid); set.centroid = nullptr; set.centroid_n = 0;
     dev_free(ctx, set.len_order); set.len_order = nullptr; set.len_order_n = 0;
+    refcos_q8_release(ctx, set);
 
     set.max_frames = 0;
     for (uint32_t i = 0; i < n; ++i)

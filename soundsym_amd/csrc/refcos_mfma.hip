@@ -35,6 +35,7 @@
 // The true first minimum w has key(w) <= key(s) <= key_hi(s) for all s, so key_lo(w) <= threshold: it is
 // among the candidates, and the fold over exact keys in index order returns what the reference returns.
 #include "ssym_internal.hpp"
+#include "refcos_filter.hpp"
 #include "ssym_rulinalg.h"
 
 #include <algorithm>
@@ -49,43 +50,8 @@ constexpr int kMT = 128;            // sources per workgroup tile
 constexpr int kNT = 128;            // targets per workgroup tile
 constexpr int kKC = 16;             // elements per staged chunk (one 128-byte line per segment)
 constexpr int kLdk = kKC;           // LDS row stride in doubles: rows are 128 bytes, their 16-byte pieces XOR-swizzled (below)
-constexpr int rm_wait_vmcnt(int n) { return 0x0F70 | (n & 15) | ((n >> 4) << 14); }   // s_waitcnt vmcnt(n), nothing else
 typedef double double4v __attribute__((ext_vector_type(4)));
 typedef double double2v __attribute__((ext_vector_type(2)));
-
-constexpr unsigned long long kInfBitsU = 0x7ff0000000000000ull;
-
-struct PairEntry {                  // list 1: a pair that may hold its target's first minimum
-    uint32_t s, t;
-    double key_lo;
-};
-
-struct RowInfo {                   // per segment of the tile, written to LDS once the main loop is done with it
-    double sq;                      // >= sqrt(norm)
-    double inv;                     // fl(1 / norm)
-    double norm;
-    double dist;                    // targets: the distance |sim - dist| is taken to
-};
-
-__device__ __forceinline__ void refcos_key_interval(double dotm, double sasb, double inv, double nrm, double cL, double d,
-                                                    double &klo, double &khi)
-{
-    const double INF = __builtin_inf();
-    const double u = 1.1102230246251565e-16;
-    const double s = dotm * inv;
-    const double z = fabs(s - d);
-    const double R = 1.0001 * (cL * sasb) * inv + 9.0 * u * (fabs(s) + fabs(d)) + 1e-290;
-    klo = z > R ? (z - R) * (1.0 - 4.0 * u) : 0.0;
-    khi = (z + R) * (1.0 + 4.0 * u);
-    // something is not finite (or NaN), or the norms are so large or small that 1 / nrm or single products leave the
-    // normal range (the relative bounds above need it): the pair stays in, bounds nothing
-    if (!(khi < INF) || !(inv > 1e-280 && inv < 1e280)) {
-        klo = 0.0;
-        khi = INF;
-    }
-    if (nrm == 0.0 || nrm != nrm || d != d)        // the reference's key is NaN or +inf: never a winner
-        klo = khi = INF;
-}
 
 // Epilogue shared by the two main loops: dots -> key intervals -> thresholds and list 1.  `info` is LDS no wave reads
 // any more (the caller has passed its last barrier); sLen holds the tile's segment lengths.
@@ -750,7 +716,13 @@ int32_t launch_refcos_match_mfma(ssym_ctx *ctx, const SegmentSet &src, const Seg
 
     refcos_init_kernel<<<(M + 255) / 256, 256, 0, st>>>(thr, bestKey, bestIdx, M, hdr1, hdr2);
     dim3 grid((M + kNT - 1) / kNT, (N + kMT - 1) / kMT);
-    if (k_top > 1)
+    // the integer filter (refcos_q8.hip) where both sets have its records, the f64 matrix pipe otherwise: both leave
+    // thresholds and list 1 in the same form
+    if (refcos_q8_ready(ctx, src, tgt)) {
+        rc = launch_refcos_q8_kernel(ctx, src, tgt, dist_dev, thr, hdr1, list1, (uint32_t)cap, k_top, nullptr);
+        if (rc != SSYM_OK)
+            return rc;
+    } else if (k_top > 1)
         refcos_mfma_kernel<false, true><<<grid, 256, 0, st>>>(src.raw, src.off, src.norm, tgt.raw, tgt.off, tgt.norm, N, M, src.dim,
                                                  (unsigned long long)src.total_frames * src.dim,
                                                  (unsigned long long)tgt.total_frames * tgt.dim, dist_dev, 1.0, thr, hdr1,

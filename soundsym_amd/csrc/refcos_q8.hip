@@ -1,0 +1,542 @@
+// refcos_q8.hip -- the refcos search's filter on the i8 matrix pipe: every pair's dot as EXACT integer arithmetic on
+// 8-bit digits, v_mfma_i32_32x32x32_i8 (64 x the multiply-adds per clock of the f64 form refcos_mfma.hip uses).
+//
+// Role on the path: the same as refcos_mfma_kernel's -- SoundDictionary::at_distance (src/sound.rs:351-370) needs, per
+// target, the dictionary entry with the smallest |cosine_sim - distance| (src/sound.rs:22-33, 359); this kernel gives
+// every pair a rigorous interval for that key, and only the pairs whose interval reaches down to a target's smallest
+// upper bound are keyed in the reference's own arithmetic (refcos_pairs_kernel).  Same bits out.
+//
+// Fixed point.  Segment a (length La) gets E_a with max |a_i| 2^E_a in [2^21, 2^22); n_i = rint(a_i 2^E_a) is an integer
+// of at most 23 bits, written in balanced base 256: n = 2^16 q1 + 2^8 q2 + q3, q2, q3 in [-128, 127], |q1| <= 65.
+// With m_i, r1..r3, E_b the same for segment b and L = min(La, Lb) (src/sound.rs:24-28):
+//     a_i 2^E_a = n_i + alpha_i, |alpha_i| <= 1/2       b_i 2^E_b = m_i + beta_i, |beta_i| <= 1/2
+//     D 2^(E_a + E_b) = sum (n_i + alpha_i)(m_i + beta_i)          (D: the exact dot over the common prefix)
+//     | D 2^(E_a+E_b) - G | <= S_m / 2 + S_n / 2 + L / 4,          G = sum n_i m_i,  S_n = sum |n_i|, S_m = sum |m_i|
+//     G = 2^32 T11 + 2^24 (T12 + T21) + 2^16 (T13 + T22 + T31) + 2^8 (T23 + T32) + T33,      Tkl = sum q_k,i r_l,i
+// The kernel forms K0 = T11, K1 = T12 + T21, K2 = T13 + T22 + T31 -- six integer GEMMs, exact in 32 bits for
+// L <= 32768 -- and leaves out 2^8 (T23 + T32) + T33, which is at most 2^15 (sum |q2_i| + sum |r2_i|) + 2^14 L in
+// magnitude (|q3|, |r3| <= 128).  So with Gk = 2^32 K0 + 2^24 K1 + 2^16 K2 (exact in a double: a multiple of 2^16 below
+// 2^60) and dq = Gk 2^-(E_a + E_b):
+//     | D - dq | <= ( Eseg_a + Eseg_b + 16384.25 L ) 2^-(E_a + E_b),        Eseg = S / 2 + 2^15 sum |q2_i|   (per segment)
+// and the reference's own floating-point dot is within gamma_(2L+8) sum |a_i b_i| of D (top of refcos_mfma.hip): the
+// f64 filter's bound with this one added.  In the units of a similarity (times ia ib, the reciprocal norms):
+//     extra = A1 B2 + A2 B1 + A3 B3,    A1 = Eseg_a A2,  A2 = 2^-E_a ia,  A3 = sqrt(16384.25 La) A2   (L <= sqrt(La Lb))
+// -- three multiply-adds per pair on per-segment numbers.  For Gaussian-like data the bound is ~1e-5 of a similarity's
+// scale: a target keeps its winner and what lies within that of it.
+//
+// Sets this filter does not take (the f64 matrix pipe does): a value that is not finite, max |a_i| outside
+// [2^-120, 2^120], a segment longer than 32768 values, record memory beyond the budget below.  Segments of norm 0
+// (empty or all zeros) are rows of zeros here and are dropped by the reference's rule (nrm = 0: src/sound.rs:362).
+#include "ssym_internal.hpp"
+#include "refcos_filter.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <type_traits>
+
+namespace ssym {
+
+namespace {
+
+constexpr int kQT = 128;             // segments per side of a workgroup tile
+constexpr int kQG = 32;              // elements per group (one 128-byte line of a row: three digit planes + 32 bytes of zeros)
+constexpr uint32_t kQMaxLen = 32768;
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+// ---- records ------------------------------------------------------------------------------------------------------
+// One workgroup per row.  info[row] = { A1' = Eseg 2^-E (times ia in the kernel), 2^-E, sqrt(16384.25 len) 2^-E, 0 }.
+__global__ __launch_bounds__(256) void refcos_q8_records_kernel(const double *__restrict__ raw, const uint64_t *__restrict__ off,
+                                                                uint32_t n, uint32_t dim, uint32_t groups,
+                                                                int8_t *__restrict__ q8, double *__restrict__ info,
+                                                                unsigned *__restrict__ bad)
+{
+    __shared__ double sMax[256];
+    __shared__ unsigned long long sSum[256], sSum2[256];
+    __shared__ int sNonFinite;
+    const uint32_t g = blockIdx.x;
+    const int tid = threadIdx.x;
+    int8_t *row = q8 + (size_t)g * groups * 128;
+    if (g >= n) {                                    // (rows beyond the set: the buffer was zeroed)
+        if (tid < 4)
+            info[4 * (size_t)g + tid] = 0.0;
+        return;
+    }
+    const unsigned long long base = off[g] * dim;
+    const unsigned long long len64 = (off[g + 1] - off[g]) * dim;
+    const uint32_t len = (uint32_t)std::min<unsigned long long>(len64, 0xffffffffull);
+    if (tid == 0)
+        sNonFinite = 0;
+    __syncthreads();
+    double amax = 0.0;
+    for (uint32_t i = tid; i < len; i += 256) {
+        const double a = fabs(raw[base + i]);
+        if (!(a < __builtin_inf()))
+            sNonFinite = 1;
+        amax = fmax(amax, a);
+    }
+    sMax[tid] = amax;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o)
+            sMax[tid] = fmax(sMax[tid], sMax[tid + o]);
+        __syncthreads();
+    }
+    amax = sMax[0];
+    const bool outside = sNonFinite || len64 > kQMaxLen || (amax != 0.0 && !(amax >= 0x1p-120 && amax <= 0x1p120));
+    if (outside || amax == 0.0) {                    // zeros stay zeros; `outside` makes the whole set take the f64 filter
+        if (outside && tid == 0)
+            atomicOr(bad, 1u);
+        if (tid < 4)
+            info[4 * (size_t)g + tid] = tid == 1 ? 1.0 : 0.0;
+        return;
+    }
+    int e;
+    (void)frexp(amax, &e);                           // amax = f 2^e, f in [0.5, 1)
+    const int E = 22 - e;                            // amax 2^E in [2^21, 2^22)
+    unsigned long long sN = 0, s2 = 0;
+    for (uint32_t i = tid; i < len; i += 256) {
+        const long long nI = (long long)rint(ldexp(raw[base + i], E));      // |nI| <= 2^22; the scaling is exact
+        const int q3 = (int)(((nI + 128) & 255) - 128);
+        const long long n1 = (nI - q3) >> 8;
+        const int q2 = (int)(((n1 + 128) & 255) - 128);
+        const int q1 = (int)((n1 - q2) >> 8);
+        int8_t *grp = row + (size_t)(i / kQG) * 128 + (i % kQG);
+        grp[0] = (int8_t)q1;
+        grp[32] = (int8_t)q2;
+        grp[64] = (int8_t)q3;
+        sN += (unsigned long long)(nI < 0 ? -nI : nI);
+        s2 += (unsigned)(q2 < 0 ? -q2 : q2);
+    }
+    sSum[tid] = sN;
+    sSum2[tid] = s2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            sSum[tid] += sSum[tid + o];
+            sSum2[tid] += sSum2[tid + o];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double scl = ldexp(1.0, -E);
+        const double eseg = 0.5 * (double)sSum[0] + 32768.0 * (double)sSum2[0];      // exact: integers below 2^53
+        info[4 * (size_t)g + 0] = eseg * scl;                                         // (a power of two: exact)
+        info[4 * (size_t)g + 1] = scl;
+        info[4 * (size_t)g + 2] = sqrt(16384.25 * (double)len) * (1.0 + 0x1p-50) * scl;
+        info[4 * (size_t)g + 3] = 0.0;
+    }
+}
+
+struct QInfo {                       // per segment of a tile, in LDS
+    double sq, inv, norm, dist;      // as RowInfo
+    double a1, a2, a3, a4;           // error mass, 2^-E ia, length term (all times ia), the reference-rounding term's factor
+    double scl;                      // 2^-E
+    double cl;                       // (3 len + 16) u 1.02
+};
+
+// ---- main kernel ----------------------------------------------------------------------------------------------------
+// 128 x 128 pairs per workgroup, four waves of 64 x 64 (2 x 2 MFMA blocks of 32 x 32, three accumulators each: the digit
+// products of weight 2^32, 2^24, 2^16), one workgroup per CU (192 accumulator registers per lane).  A chunk is one group
+// of 32 elements of every row: 128 bytes per row (a full line), global -> LDS by DMA, the 16-byte pieces of a row
+// XOR-swizzled as in refcos_mfma.hip (piece q of row r sits at position q ^ ((r >> 1) & 7): the operand reads of 32 rows
+// at one piece are conflict-free), FOUR chunks in flight: every row is padded with zeros to the sets' common length, so
+// a DMA's address is a scalar base plus a constant per lane and nothing is selected.
+template <bool WRITE_SIMS, bool TOPK>
+__global__ __launch_bounds__(256, 1) void refcos_q8_kernel(
+    const int8_t *__restrict__ srcQ, const double *__restrict__ srcQInfo, const uint64_t *__restrict__ srcOff,
+    const double *__restrict__ srcNorm, const int8_t *__restrict__ tgtQ, const double *__restrict__ tgtQInfo,
+    const uint64_t *__restrict__ tgtOff, const double *__restrict__ tgtNorm, uint32_t nSrc, uint32_t nTgt, uint32_t dim,
+    uint32_t srcGroups, uint32_t tgtGroups, const double *__restrict__ dist, double defaultDist,
+    unsigned long long *__restrict__ thr, uint32_t *__restrict__ hdr, PairEntry *__restrict__ list, uint32_t cap,
+    double *__restrict__ simOut, uint32_t kTop)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char sA0[kQT * 128], sA1[kQT * 128], sA2[kQT * 128], sA3[kQT * 128];
+    __shared__ __attribute__((aligned(16))) unsigned char sB0[kQT * 128], sB1[kQT * 128], sB2[kQT * 128], sB3[kQT * 128];
+    __shared__ QInfo sInfo[2 * kQT];
+    __shared__ unsigned sLen[2 * kQT];
+    __shared__ unsigned sMaxLen[2];
+    __shared__ unsigned sPlain[4];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    // (XCD-aware tile order: refcos_mfma.hip)
+    uint32_t bx = blockIdx.x, by = blockIdx.y;
+    {
+        const uint32_t nx = gridDim.x, ny = gridDim.y, total = nx * ny;
+        if ((nx & 7u) == 0 && (total & 7u) == 0) {
+            const uint32_t lin = bx + nx * by;
+            const uint32_t q = (lin & 7u) * (total >> 3) + (lin >> 3);
+            const uint32_t r = q % (8u * ny);
+            bx = 8u * (q / (8u * ny)) + (r & 7u);
+            by = r >> 3;
+        }
+    }
+    const uint32_t sTile = by * kQT, tTile = bx * kQT;
+
+    if (tid < 2)
+        sMaxLen[tid] = 0;
+    if (tid < 4)
+        sPlain[tid] = 1;
+    __syncthreads();
+    {
+        const bool isS = tid < kQT;
+        const uint32_t g = isS ? sTile + tid : tTile + (tid - kQT);
+        const uint32_t n = isS ? nSrc : nTgt;
+        const uint64_t *off = isS ? srcOff : tgtOff;
+        const double *nr = isS ? srcNorm : tgtNorm;
+        const double *qi = isS ? srcQInfo : tgtQInfo;
+        unsigned len = 0;
+        QInfo r;
+        r.norm = r.sq = r.inv = 0.0;                 // (segments beyond the sets' ends: norm 0, dropped like an empty segment)
+        r.a1 = r.a3 = 0.0;
+        r.scl = 1.0;
+        if (g < n) {
+            len = (unsigned)((off[g + 1] - off[g]) * dim);
+            r.norm = nr[g];
+            r.sq = nr[n + g];
+            r.inv = nr[2 * (size_t)n + g];
+            r.a1 = qi[4 * (size_t)g + 0];
+            r.scl = qi[4 * (size_t)g + 1];
+            r.a3 = qi[4 * (size_t)g + 2];
+        }
+        r.dist = (!isS && dist && g < n) ? dist[g] : defaultDist;
+        r.a2 = r.scl * r.inv;
+        r.a1 = r.a1 * r.inv;
+        r.a3 = r.a3 * r.inv;
+        r.cl = (3.0 * (double)len + 16.0) * (1.1102230246251565e-16 * 1.02);
+        r.a4 = sqrt(r.cl) * (1.0 + 0x1p-50) * (r.sq * r.inv);   // cL(min) sa sb ia ib <= a4(a) a4(b): min(x, y) <= sqrt(x y)
+        sInfo[tid] = r;
+        sLen[tid] = len;
+        atomicMax(&sMaxLen[isS ? 0 : 1], len);
+        const bool ok = g < n && r.norm >= 1e-139 && r.norm <= 1e139 && fabs(r.dist) <= 1e300;
+        if (!ok)
+            atomicAnd(&sPlain[tid >> 6], 0u);
+    }
+    __syncthreads();
+    const unsigned kMax = __builtin_amdgcn_readfirstlane(min(sMaxLen[0], sMaxLen[1]));
+    const unsigned nChunks = (kMax + kQG - 1) / kQG;
+
+    // staging: thread -> (row = tid / 8 + 32 p, position tid & 7) for p = 0..3 on both sides; the piece it fetches is
+    // position ^ swizzle(row).  Per-lane byte offsets are constants, the chunk's base is scalar.
+    const int sr = tid >> 3;
+    unsigned offA[4], offB[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int row = sr + 32 * p;
+        const unsigned piece = (unsigned)((tid & 7) ^ ((row >> 1) & 7));
+        offA[p] = (unsigned)row * srcGroups * 128u + piece * 16u;
+        offB[p] = (unsigned)row * tgtGroups * 128u + piece * 16u;
+    }
+    const unsigned char *const tileA = (const unsigned char *)srcQ + (size_t)sTile * srcGroups * 128;
+    const unsigned char *const tileB = (const unsigned char *)tgtQ + (size_t)tTile * tgtGroups * 128;
+    auto stageA = [&](auto S) -> unsigned char * {
+        constexpr int s = decltype(S)::value;
+        return s == 0 ? sA0 : s == 1 ? sA1 : s == 2 ? sA2 : sA3;
+    };
+    auto stageB = [&](auto S) -> unsigned char * {
+        constexpr int s = decltype(S)::value;
+        return s == 0 ? sB0 : s == 1 ? sB1 : s == 2 ? sB2 : sB3;
+    };
+    auto fetch = [&](unsigned c, auto S) {                // eight DMAs, nothing waits here
+        unsigned char *const dA = stageA(S), *const dB = stageB(S);
+        const unsigned char *ua = tileA + (size_t)c * 128, *ub = tileB + (size_t)c * 128;
+        asm volatile("" : "+s"(ua), "+s"(ub));            // (scalar base + 32-bit lane offset: refcos_mfma.hip)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            asm volatile("" : "+v"(offA[p]), "+v"(offB[p]));
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ua + offA[p]),
+                                             (__attribute__((address_space(3))) void *)&dA[(32 * p + 8 * wave) * 128], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ub + offB[p]),
+                                             (__attribute__((address_space(3))) void *)&dB[(32 * p + 8 * wave) * 128], 16, 0, 0);
+        }
+    };
+
+    v16i acc[3][2][2];
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int g = 0; g < 16; ++g)
+                    acc[l][a][b][g] = 0;
+
+    // operand reads: lane (r = lane & 31, h = lane >> 5) takes, of row (block row 32 blk + r) and digit plane p, the 16
+    // bytes k = 16 h .. 16 h + 15 of the group: piece 2 p + h, at position (2 p + h) ^ swizzle(row)
+    const int lr = lane & 31, lh = lane >> 5;
+    auto chunk = [&](unsigned c, auto S) {
+        constexpr int s = decltype(S)::value;
+        using Next = std::integral_constant<int, (s + 3) & 3>;
+        // chunk c has landed (the DMAs of c + 1 and c + 2 may still be in flight: eight each) and every wave is done
+        // with chunk c - 1, whose buffer takes chunk c + 3
+        if (c + 2 < nChunks)
+            __builtin_amdgcn_s_waitcnt(rm_wait_vmcnt(16));
+        else if (c + 1 < nChunks)
+            __builtin_amdgcn_s_waitcnt(rm_wait_vmcnt(8));
+        else
+            __builtin_amdgcn_s_waitcnt(rm_wait_vmcnt(0));
+        __syncthreads();
+        if (c + 3 < nChunks)
+            fetch(c + 3, Next{});
+        const unsigned char *const rA = stageA(S), *const rB = stageB(S);
+        v4i av[3][2], bv[3][2];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const int rowA = wm * 64 + blk * 32 + lr, rowB = wn * 64 + blk * 32 + lr;
+                av[p][blk] = *reinterpret_cast<const v4i *>(&rA[rowA * 128 + (((2 * p + lh) ^ ((rowA >> 1) & 7)) << 4)]);
+                bv[p][blk] = *reinterpret_cast<const v4i *>(&rB[rowB * 128 + (((2 * p + lh) ^ ((rowB >> 1) & 7)) << 4)]);
+            }
+#pragma unroll
+        for (int pa = 0; pa < 3; ++pa)
+#pragma unroll
+            for (int pb = 0; pb + pa < 3; ++pb)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        acc[pa + pb][a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[pa][a], bv[pb][b], acc[pa + pb][a][b], 0, 0, 0);
+    };
+    if (nChunks > 0)
+        fetch(0, std::integral_constant<int, 0>{});
+    if (nChunks > 1)
+        fetch(1, std::integral_constant<int, 1>{});
+    if (nChunks > 2)
+        fetch(2, std::integral_constant<int, 2>{});
+    for (unsigned c = 0; c < nChunks; c += 4) {
+        chunk(c, std::integral_constant<int, 0>{});
+        if (c + 1 < nChunks)
+            chunk(c + 1, std::integral_constant<int, 1>{});
+        if (c + 2 < nChunks)
+            chunk(c + 2, std::integral_constant<int, 2>{});
+        if (c + 3 < nChunks)
+            chunk(c + 3, std::integral_constant<int, 3>{});
+    }
+
+    // ---- epilogue: integer dots -> key intervals -> thresholds and list 1 (the steps of refcos_mfma.hip's) -----------
+    // D layout of the 32 x 32 forms: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+    const double INF = __builtin_inf();
+    const double u = 1.1102230246251565e-16;
+    const bool plain = !WRITE_SIMS && (sPlain[wm] & sPlain[2 + wn]) != 0;
+    QInfo ci[2];
+    double colMin[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        ci[b] = sInfo[kQT + wn * 64 + b * 32 + lr];
+        colMin[b] = INF;
+    }
+    double klo[2][2][16];                                  // [column block][row block][register]
+    double khis[TOPK ? 2 : 1][TOPK ? 2 : 1][TOPK ? 16 : 1];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int row = wm * 64 + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
+            const QInfo ri = sInfo[row];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                // the kept part of the integer dot, exactly: a multiple of 2^16 below 2^60
+                const double gk = __fma_rn(0x1p32, (double)acc[0][a][b][g],
+                                           __fma_rn(0x1p24, (double)acc[1][a][b][g], 0x1p16 * (double)acc[2][a][b][g]));
+                const double extra = __fma_rn(ri.a1, ci[b].a2, __fma_rn(ri.a2, ci[b].a1, ri.a3 * ci[b].a3));
+                double lo, hi;
+                if (plain) {
+                    // (the short form of refcos_mfma.hip's epilogue: nothing of refcos_key_interval's tests can fire)
+                    const double sv = gk * (ri.a2 * ci[b].a2);
+                    const double z = fabs(sv - ci[b].dist);
+                    const double R = __fma_rn(9.0 * u, fabs(sv) + fabs(ci[b].dist), 1.0001 * __fma_rn(ri.a4, ci[b].a4, extra)) + 1e-290;
+                    lo = fmax((z - R) * (1.0 - 4.0 * u), 0.0);
+                    hi = (z + R) * (1.0 + 4.0 * u);
+                } else {
+                    const unsigned la = sLen[row], lb = sLen[kQT + wn * 64 + b * 32 + lr];
+                    const unsigned len = la < lb ? la : lb;
+                    const double nrm = __dmul_rn(ri.norm, ci[b].norm);
+                    const double dotm = gk * (ri.scl * ci[b].scl);
+                    refcos_key_interval(dotm, ri.sq * ci[b].sq, ri.inv * ci[b].inv, nrm,
+                                        (3.0 * (double)len + 16.0) * (u * 1.02), ci[b].dist, lo, hi, extra);
+                    if (WRITE_SIMS) {
+                        const uint32_t s = sTile + row, t = tTile + wn * 64 + b * 32 + lr;
+                        if (s < nSrc && t < nTgt)
+                            simOut[(size_t)s * nTgt + t] = __ddiv_rn(dotm, nrm);
+                    }
+                }
+                klo[b][a][g] = lo;
+                if (TOPK)
+                    khis[b][a][g] = hi;
+                else
+                    colMin[b] = fmin(colMin[b], hi);
+            }
+        }
+    double cur[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        double cmin = colMin[b];
+        if (TOPK) {
+            double prev = -1.0;
+            for (uint32_t r = 0; r < kTop; ++r) {
+                double m = INF;
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int g = 0; g < 16; ++g)
+                        m = (khis[b][a][g] > prev && khis[b][a][g] < m) ? khis[b][a][g] : m;
+                m = fmin(m, __shfl_xor(m, 32));
+                prev = m;
+            }
+            cmin = prev;
+        } else {
+            cmin = fmin(cmin, __shfl_xor(cmin, 32));
+        }
+        cur[b] = cmin;
+    }
+    unsigned long long seenBits[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const uint32_t t = tTile + wn * 64 + b * 32 + lr;
+        seenBits[b] = kInfBitsU;
+        if (lh == 0 && t < nTgt)
+            seenBits[b] = atomicMin(&thr[t], (unsigned long long)__double_as_longlong(cur[b]));
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        seenBits[b] = __shfl(seenBits[b], lr);
+        cur[b] = fmin(fmin(cur[b], __longlong_as_double((long long)seenBits[b])), 1.7976931348623157e308);
+    }
+    unsigned total = 0;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int g = 0; g < 16; ++g)
+                total += (unsigned)__popcll(__ballot(klo[b][a][g] <= cur[b]));
+    if (total) {
+        uint32_t base = 0;
+        if (lane == 0)
+            base = atomicAdd(&hdr[0], total);
+        base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const bool in = klo[b][a][g] <= cur[b];
+                    const unsigned long long m = __ballot(in);
+                    if (m) {
+                        const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
+                                                                              __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                        if (in) {
+                            if (pos < cap) {
+                                PairEntry e;
+                                e.s = sTile + wm * 64 + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
+                                e.t = tTile + wn * 64 + b * 32 + lr;
+                                e.key_lo = klo[b][a][g];
+                                list[pos] = e;
+                            } else {
+                                hdr[1] = 1;
+                            }
+                        }
+                        base += (unsigned)__popcll(m);
+                    }
+                }
+    }
+}
+
+}  // namespace
+
+// ---- host side ------------------------------------------------------------------------------------------------------
+void refcos_q8_release(ssym_ctx *ctx, const SegmentSet &set)
+{
+    dev_free(ctx, set.q8);
+    dev_free(ctx, set.q8_info);
+    set.q8 = nullptr;
+    set.q8_info = nullptr;
+    set.q8_rows = set.q8_groups = 0;
+    set.q8_state = 0;
+}
+
+int32_t refcos_q8_ensure(ssym_ctx *ctx, const SegmentSet &set)
+{
+    if (set.q8_state != 0)
+        return SSYM_OK;
+    set.q8_state = -1;
+    const uint64_t maxLen = (uint64_t)set.max_frames * set.dim;
+    if (set.n == 0 || maxLen == 0 || maxLen > kQMaxLen || !(set.max_abs < __builtin_inf()))
+        return SSYM_OK;
+    const uint32_t rows = (set.n + kQT - 1) / kQT * kQT;
+    const uint32_t groups = (uint32_t)((maxLen + kQG - 1) / kQG);
+    const uint64_t bytes = (uint64_t)rows * groups * 128;
+    // every row is as long as the longest: a set of many short segments and one long one would pay for it
+    const uint64_t rawBytes = set.total_frames * set.dim * sizeof(double);
+    if (bytes > 2 * rawBytes + (64ull << 20) || (uint64_t)kQT * groups * 128 >= (1ull << 32))
+        return SSYM_OK;
+    int32_t rc = dev_alloc(ctx, (void **)&set.q8, bytes);
+    if (rc == SSYM_OK)
+        rc = dev_alloc(ctx, (void **)&set.q8_info, sizeof(double) * (4 * (size_t)rows + 1));      // (+ one word: "outside")
+    if (rc != SSYM_OK) {
+        refcos_q8_release(ctx, set);
+        set.q8_state = -1;
+        return rc == SSYM_E_NOMEM ? SSYM_OK : rc;      // (no room for the records: the f64 filter)
+    }
+    unsigned *bad = (unsigned *)(set.q8_info + 4 * (size_t)rows);
+    SSYM_HIP_CHECK(ctx, hipMemsetAsync(set.q8, 0, bytes, ctx->stream));
+    SSYM_HIP_CHECK(ctx, hipMemsetAsync(bad, 0, sizeof(unsigned), ctx->stream));
+    refcos_q8_records_kernel<<<rows, 256, 0, ctx->stream>>>(set.raw, set.off, set.n, set.dim, groups, set.q8, set.q8_info, bad);
+    SSYM_HIP_CHECK(ctx, hipGetLastError());
+    unsigned hbad = 0;
+    SSYM_HIP_CHECK(ctx, hipMemcpyAsync(&hbad, bad, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    SSYM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    set.q8_rows = rows;
+    set.q8_groups = groups;
+    if (hbad) {
+        refcos_q8_release(ctx, set);
+        set.q8_state = -1;
+        return SSYM_OK;
+    }
+    set.q8_state = 1;
+    return SSYM_OK;
+}
+
+bool refcos_q8_ready(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt)
+{
+    static const bool off = getenv("SSYM_REFCOS_Q8") && atoi(getenv("SSYM_REFCOS_Q8")) == 0;
+    if (off || ctx->metric != SSYM_METRIC_REFCOS || src.dim != tgt.dim)
+        return false;
+    if (ctx->stream_only && (src.q8_state == 0 || tgt.q8_state == 0))
+        return false;                                  // (building the records synchronises: not inside a stream-only step)
+    if (refcos_q8_ensure(ctx, src) != SSYM_OK || refcos_q8_ensure(ctx, tgt) != SSYM_OK)
+        return false;
+    return src.q8_state == 1 && tgt.q8_state == 1;
+}
+
+int32_t launch_refcos_q8_kernel(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, const double *dist_dev,
+                                unsigned long long *thr, uint32_t *hdr1, void *list1, uint32_t cap, uint32_t k_top,
+                                double *sims)
+{
+    const uint32_t N = src.n, M = tgt.n;
+    dim3 grid((M + kQT - 1) / kQT, (N + kQT - 1) / kQT);
+    hipStream_t st = ctx->stream;
+    if (sims)
+        refcos_q8_kernel<true, false><<<grid, 256, 0, st>>>(src.q8, src.q8_info, src.off, src.norm, tgt.q8, tgt.q8_info, tgt.off,
+                                                            tgt.norm, N, M, src.dim, src.q8_groups, tgt.q8_groups, dist_dev, 1.0,
+                                                            thr, hdr1, (PairEntry *)list1, cap, sims, 1);
+    else if (k_top > 1)
+        refcos_q8_kernel<false, true><<<grid, 256, 0, st>>>(src.q8, src.q8_info, src.off, src.norm, tgt.q8, tgt.q8_info, tgt.off,
+                                                            tgt.norm, N, M, src.dim, src.q8_groups, tgt.q8_groups, dist_dev, 1.0,
+                                                            thr, hdr1, (PairEntry *)list1, cap, nullptr, k_top);
+    else
+        refcos_q8_kernel<false, false><<<grid, 256, 0, st>>>(src.q8, src.q8_info, src.off, src.norm, tgt.q8, tgt.q8_info, tgt.off,
+                                                             tgt.norm, N, M, src.dim, src.q8_groups, tgt.q8_groups, dist_dev, 1.0,
+                                                             thr, hdr1, (PairEntry *)list1, cap, nullptr, 1);
+    SSYM_HIP_CHECK(ctx, hipGetLastError());
+    return SSYM_OK;
+}
+
+}  // namespace ssym

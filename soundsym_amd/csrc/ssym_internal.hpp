@@ -94,6 +94,14 @@ struct SegmentSet {
     // accumulates then end within a few blocks of each other); results stay in the caller's order
     mutable uint32_t *len_order = nullptr;
     mutable uint32_t len_order_n = 0;
+    // refcos integer filter (refcos_q8.hip): every value as three signed bytes of a 23-bit fixed-point number scaled per
+    // segment, rows padded with zeros to a common length, built on first use.  Row g, group k of 32 elements: 128 bytes =
+    // [digit 1: 32 bytes][digit 2][digit 3][32 bytes of zeros].
+    mutable int8_t *q8 = nullptr;         // [q8_rows][q8_groups][128]
+    mutable double *q8_info = nullptr;    // [q8_rows][4]: error mass A1, scale 2^-E, length term A3, 0 (refcos_q8.hip)
+    mutable uint32_t q8_rows = 0;         // n rounded up to the 128 segments of a tile (rows beyond n: zeros)
+    mutable uint32_t q8_groups = 0;
+    mutable int q8_state = 0;             // 0: not tried, 1: built, -1: this set cannot take the integer filter
 };
 
 }  // namespace ssym
@@ -353,6 +361,14 @@ int32_t launch_dtw_match_few(ssym_ctx *ctx, const SegmentSet &src, const void *q
                              uint32_t n_queries, const double *distances, double *out_cost, uint32_t *out_idx);
 // refcos_mfma.hip: the search through the f64 matrix pipe (filter) + exact keys of the candidates; bit-exact results
 bool refcos_mfma_supported(const ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt);
+// the int8 records of a set (built on first use); true when BOTH sets have them and the pair of sets fits the kernel
+int32_t refcos_q8_ensure(ssym_ctx *ctx, const SegmentSet &set);
+bool refcos_q8_ready(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt);
+void refcos_q8_release(ssym_ctx *ctx, const SegmentSet &set);
+// the integer filter's main kernel: thresholds and list 1 in the layout of refcos_mfma.hip (sims: ssym_pair_matrix(exact = 3))
+int32_t launch_refcos_q8_kernel(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, const double *dist_dev,
+                                unsigned long long *thr, uint32_t *hdr1, void *list1, uint32_t cap, uint32_t k_top,
+                                double *sims);
 int32_t launch_refcos_match_mfma(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, const double *dist_dev,
                                  uint32_t index_base, uint32_t *out_idx_dev, double *out_cost_dev,
                                  const uint32_t **list1_hdr, const uint32_t **list2_hdr, uint32_t k_top = 1);
