@@ -70,7 +70,7 @@ pub struct SsymTimings {
     pub collective_ms: f32,
     pub attempts: i32,
     pub exact_redone: i32,
-    pub reserved: i32,
+    pub refcos_filter: i32,
 }
 
 extern "C" {

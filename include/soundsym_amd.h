@@ -122,7 +122,9 @@ typedef struct ssym_timings {
     int32_t exact_redone;  /* dtw: launches of the exact kernel whose wave-pipelined variant gave up
                               waiting and whose list was scored again by the plain variant (0 in any
                               healthy run; results are correct either way)                          */
-    int32_t reserved;
+    int32_t refcos_filter; /* refcos searches: 0 = the exact tile kernel on every pair, 1 = the f64 matrix-pipe
+                              filter, 2 = the integer (i8 matrix-pipe) filter; exact keys on the candidates
+                              either way (this word was `reserved` before: same size and place)        */
 } ssym_timings;
 
 SSYM_API int32_t ssym_abi_version(void);
@@ -220,6 +222,9 @@ SSYM_API int32_t ssym_chain(ssym_ctx *ctx, ssym_dict *dict, const void *start_fe
  *   refcos: cosine_sim(source, target) (src/sound.rs:22-33), bit for bit (exact = 0 or 1); exact = 2 -> the
  *           similarities the f64 matrix pipe's dots give (the filter of the refcos search: FMA chains in another
  *           summation order, within (3 L + 16) 2^-53 sqrt(norm(me) norm(you)) / nrm of the reference's);
+ *           exact = 3 -> the similarities of the integer filter (the refcos search's default filter: every value as a
+ *           23-bit fixed-point number per segment, exact integer products; SSYM_E_UNSUPPORTED where that filter does
+ *           not take the sets, e.g. values that are not finite);
  *   dtw:    exact = 0 -> the f32 MFMA filter's costs (frames wider than 42 values: of their first 42
  *           values only; a Sakoe-Chiba band beyond the banded kernel, r > 47: the unbanded cost --
  *           either way a lower bound of every pair's cost); exact = 1 -> the exact f64 costs. */

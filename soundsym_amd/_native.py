@@ -99,7 +99,7 @@ class Timings(ctypes.Structure):
         ("collective_ms", ctypes.c_float),
         ("attempts", ctypes.c_int32),
         ("exact_redone", ctypes.c_int32),
-        ("reserved", ctypes.c_int32),
+        ("refcos_filter", ctypes.c_int32),
     ]
 
     def as_dict(self):

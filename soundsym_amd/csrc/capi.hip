@@ -424,6 +424,7 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
             rc = launch_refcos_match_mfma(ctx, src, tgt, distDev, index_base, idxDev, costDev, &h1dev, &h2dev, k_top);
             if (rc != SSYM_OK)
                 return rc;
+            tm.refcos_filter = (src.q8_state == 1 && tgt.q8_state == 1 && refcos_q8_ready(ctx, src, tgt)) ? 2 : 1;
             SSYM_HIP_CHECK(ctx, hipEventRecord(ev[2], st));
             if (ctx->stream_only) {              // ssym_match_sharded reads the headers after the step's one synchronisation
                 ctx->so_hdr1 = h1dev;
@@ -438,8 +439,10 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
             SSYM_HIP_CHECK(ctx, hipMemcpyAsync(h1, h1dev, sizeof(h1), hipMemcpyDeviceToHost, st));
             SSYM_HIP_CHECK(ctx, hipMemcpyAsync(h2, h2dev, sizeof(h2), hipMemcpyDeviceToHost, st));
             SSYM_HIP_CHECK(ctx, hipStreamSynchronize(st));
-            if (h1[1])
+            if (h1[1]) {
                 viaMfma = false;             // more near-ties than the list holds: the exact kernel on every pair
+                tm.refcos_filter = 0;
+            }
             else {
                 tm.used_filter = 1;
                 tm.n_refined = h2[0];
@@ -1106,7 +1109,12 @@ int32_t ssym_pair_matrix(ssym_ctx *ctx, const ssym_dict *dict, const ssym_querie
         return rc;
     double *mat = (double *)ctx->part.ptr;
     if (ctx->metric == SSYM_METRIC_REFCOS) {
-        rc = exact == 2 ? launch_refcos_mfma_sims(ctx, src, tgt, mat) : launch_refcos_sims(ctx, src, tgt, mat);
+        if (exact == 3 && !refcos_q8_ready(ctx, src, tgt)) {
+            ctx->err = "the integer filter does not take these sets (a value that is not finite or far out of range, a "
+                       "segment of more than 32768 values, SSYM_REFCOS_Q8=0): ask for exact = 2";
+            return SSYM_E_UNSUPPORTED;
+        }
+        rc = exact >= 2 ? launch_refcos_mfma_sims(ctx, src, tgt, mat, exact == 3) : launch_refcos_sims(ctx, src, tgt, mat);
     } else if (exact) {
         rc = launch_dtw_exact(ctx, src, tgt, nullptr, nullptr, 0, mat);
     } else {

@@ -758,7 +758,7 @@ int32_t launch_refcos_match_mfma(ssym_ctx *ctx, const SegmentSet &src, const Seg
 
 // ssym_pair_matrix(exact = 2): the similarities the matrix pipe's dots give (FMA chains; within the bound above of the
 // reference's), for tests and for looking at the filter
-int32_t launch_refcos_mfma_sims(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, double *sims)
+int32_t launch_refcos_mfma_sims(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, double *sims, bool integer_filter)
 {
     const uint32_t N = src.n, M = tgt.n;
     hipStream_t st = ctx->stream;
@@ -779,6 +779,9 @@ int32_t launch_refcos_mfma_sims(ssym_ctx *ctx, const SegmentSet &src, const Segm
     unsigned long long *bestKey = (unsigned long long *)ctx->best.ptr;
     refcos_init_kernel<<<(M + 255) / 256, 256, 0, st>>>((unsigned long long *)ctx->tmin.ptr, bestKey, (uint32_t *)(bestKey + M), M,
                                                        hdr1, (uint32_t *)ctx->cand2.ptr);
+    if (integer_filter)              // exact = 3: what refcos_q8.hip's integer dots give (the caller has checked refcos_q8_ready)
+        return launch_refcos_q8_kernel(ctx, src, tgt, nullptr, (unsigned long long *)ctx->tmin.ptr, hdr1, hdr1 + 4, (uint32_t)cap,
+                                       1, sims);
     dim3 grid((M + kNT - 1) / kNT, (N + kMT - 1) / kMT);
     refcos_mfma_kernel<true, false><<<grid, 256, 0, st>>>(src.raw, src.off, src.norm, tgt.raw, tgt.off, tgt.norm, N, M, src.dim,
                                              (unsigned long long)src.total_frames * src.dim,

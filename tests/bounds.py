@@ -36,3 +36,46 @@ def worst_case_bound(src, tgt, dim_used, fa, fb):
     E = 256 * u * (na + nb) + 2.0 ** -12 / s ** 2
     cell = math.sqrt(E) + 1.001 * (in_a * math.sqrt(na) + in_b * math.sqrt(nb)) + 2.0 ** -20 / s
     return 1.02 * (fa + fb - 1) * cell, s
+
+
+# ---- the refcos integer filter (csrc/refcos_q8.hip), restated --------------------------------------------------------
+def q8_quantise(a):
+    """A segment's values as 23-bit fixed point in three balanced base-256 digits (refcos_q8_records_kernel).
+    Returns (q1, q2, q3 as int64 arrays, E, Eseg = sum|n| / 2 + 2^15 sum|q2|); None where the kernel says `outside`."""
+    a = np.asarray(a, dtype=np.float64).reshape(-1)
+    if a.size > 32768 or not np.isfinite(a).all():
+        return None
+    amax = float(np.abs(a).max()) if a.size else 0.0
+    if amax == 0.0:
+        z = np.zeros(a.size, dtype=np.int64)
+        return z, z, z, 0, 0.0
+    if not (2.0 ** -120 <= amax <= 2.0 ** 120):
+        return None
+    e = math.frexp(amax)[1]
+    E = 22 - e
+    n = np.rint(np.ldexp(a, E)).astype(np.int64)
+    q3 = ((n + 128) & 255) - 128
+    n1 = (n - q3) >> 8
+    q2 = ((n1 + 128) & 255) - 128
+    q1 = (n1 - q2) >> 8
+    assert (np.abs(q1) <= 65).all() and (q1 * 65536 + q2 * 256 + q3 == n).all()
+    eseg = 0.5 * float(np.abs(n).sum()) + 32768.0 * float(np.abs(q2).sum())
+    return q1, q2, q3, E, eseg
+
+
+def q8_dot_and_extra(qa, qb, la, lb, ia, ib):
+    """(dq, extra): the integer filter's dot of a pair and its error term in similarity units, as the kernel forms them."""
+    q1, q2, q3, Ea, esa = qa
+    r1, r2, r3, Eb, esb = qb
+    L = min(la, lb)
+    k0 = int((q1[:L] * r1[:L]).sum())
+    k1 = int((q1[:L] * r2[:L]).sum() + (q2[:L] * r1[:L]).sum())
+    k2 = int((q1[:L] * r3[:L]).sum() + (q2[:L] * r2[:L]).sum() + (q3[:L] * r1[:L]).sum())
+    assert max(abs(k0), abs(k1), abs(k2)) < 2 ** 31
+    gk = float(k0) * 2.0 ** 32 + float(k1) * 2.0 ** 24 + float(k2) * 2.0 ** 16
+    sa, sb = 2.0 ** -Ea, 2.0 ** -Eb
+    a2, b2 = sa * ia, sb * ib
+    a1, b1 = esa * sa * ia, esb * sb * ib
+    a3 = math.sqrt(16384.25 * la) * (1.0 + 2.0 ** -50) * sa * ia
+    b3 = math.sqrt(16384.25 * lb) * (1.0 + 2.0 ** -50) * sb * ib
+    return gk * (sa * sb), gk, a2 * b2, a1 * b2 + a2 * b1 + a3 * b3

@@ -161,6 +161,7 @@ def test_refcos_mfma_search_is_bit_exact(oracle, n, m, fmin, fmax, dim):
     idx, val = e.match(d, q)
     tm = e.timings()
     assert tm["used_filter"] == 1, "the search should have gone through the matrix pipe"
+    assert tm["refcos_filter"] == 2, "finite values of ordinary size: the integer filter (csrc/refcos_q8.hip)"
     want_idx, want_val = oracle.refcos_match_all(sf, so, tf, to, dim)
     assert np.array_equal(idx, want_idx) and np.array_equal(val, want_val)
     assert tm["n_refined"] < 8 * m + 64, tm            # a handful of candidates per target, not the matrix
@@ -182,6 +183,24 @@ def test_refcos_mfma_search_is_bit_exact(oracle, n, m, fmin, fmax, dim):
     ok = nrm > 0
     assert np.array_equal(np.isnan(filt[~ok]), np.isnan(exact[~ok]))
     assert (np.abs(filt[ok] - exact[ok]) <= bound[ok]).all(), float((np.abs(filt[ok] - exact[ok]) / bound[ok]).max())
+    # the integer filter's similarities (exact = 3) inside ITS bound, on a sample of pairs: records and error term
+    # restated in tests/bounds.py; and they are the integer dots themselves -- the number the host forms from the digits
+    import bounds
+    qfilt = nat_pair_matrix(e, d, q, 3)
+    rng = np.random.default_rng(n)
+    picks = [(7, 0), (11, 0), (3, 1), (5, 4), (6, 2), (9, 5), (8, 3)] + [(int(rng.integers(n)), int(rng.integers(m))) for _ in range(120)]
+    qs = {i: bounds.q8_quantise(src[i]) for i, _ in picks}
+    qt = {j: bounds.q8_quantise(tgt[j]) for _, j in picks}
+    for i, j in picks:
+        if not nrm[i, j] > 0:
+            assert np.isnan(qfilt[i, j]) == np.isnan(exact[i, j])
+            continue
+        with np.errstate(all="ignore"):
+            ia, ib = float(np.float64(1.0) / np.float64(na[i])), float(np.float64(1.0) / np.float64(nb[j]))
+        dq, gk, a2b2, extra = bounds.q8_dot_and_extra(qs[i], qt[j], src[i].size, tgt[j].size, ia, ib)
+        # (to 12 digits: this test's norms are numpy sums, the library's the reference's sequential fold)
+        assert abs(qfilt[i, j] - dq / nrm[i, j]) <= 1e-12 * abs(dq / nrm[i, j]), (i, j, qfilt[i, j], dq / nrm[i, j])
+        assert abs(qfilt[i, j] - exact[i, j]) <= 1.0001 * extra + bound[i, j], (i, j, qfilt[i, j], exact[i, j], extra)
     e.close()
 
 
@@ -211,6 +230,7 @@ def test_refcos_mfma_segments_outside_the_plain_range_take_the_long_epilogue(ora
         want_idx, want_val = oracle.refcos_match_all(sf, so, tf, to, dim)
     idx, val = e.match(d, q)
     assert e.timings()["used_filter"] == 1
+    assert e.timings()["refcos_filter"] == 1, "values that are not finite: the f64 matrix pipe, not the integer filter"
     assert np.array_equal(idx, want_idx) and np.array_equal(val, want_val, equal_nan=True)
     assert idx[10] == 20 and idx[333] == 350
     dist = np.linspace(-0.5, 1.5, m)
@@ -255,6 +275,7 @@ def test_refcos_topk_through_the_matrix_pipe_is_bit_exact(oracle, k):
         # (a wave offers the k-th smallest bound of ITS 64 rows, which loosens with k: up to k = 8 the call goes through
         #  the matrix pipe, above that the exact tile kernel keys every pair)
         assert tm["used_filter"] == (1 if k <= 8 else 0), tm
+        assert tm["refcos_filter"] == (2 if k <= 8 else 0), tm      # (finite values: the integer filter's thresholds)
         if k <= 8:
             assert tm["n_refined"] < n * m // 2, tm                   # candidates, not the matrix
         want_idx, want_key = oracle.topk(oracle.refcos_matrix(sf, so, tf, to, dim), k, distance=dd)

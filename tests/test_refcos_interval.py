@@ -55,8 +55,9 @@ def dot_pairwise(a, b):
     return v[0] if v else 0.0
 
 
-def key_interval(dotm, na, nb, length, d):
-    """refcos_key_interval + the per-segment values of pack.hip, same operations in the same order."""
+def key_interval(dotm, na, nb, length, d, extra=0.0):
+    """refcos_key_interval (csrc/refcos_filter.hpp) + the per-segment values of pack.hip, same operations in the same
+    order; `extra`: a filter's further error in similarity units (the integer filter's quantisation bound)."""
     sa = float(np.sqrt(np.float64(na))) * (1.0 + 4.5e-16)
     sb = float(np.sqrt(np.float64(nb))) * (1.0 + 4.5e-16)
     with np.errstate(all="ignore"):
@@ -67,7 +68,7 @@ def key_interval(dotm, na, nb, length, d):
         inv = float(np.float64(ia) * np.float64(ib))
         s = float(np.float64(dotm) * np.float64(inv))
         z = abs(float(np.float64(s) - np.float64(d)))
-        R = float(np.float64(1.0001) * (np.float64(cL) * (np.float64(sa) * np.float64(sb))) * np.float64(inv)
+        R = float(np.float64(1.0001) * ((np.float64(cL) * (np.float64(sa) * np.float64(sb))) * np.float64(inv) + np.float64(extra))
                   + np.float64(9.0 * U) * (abs(np.float64(s)) + abs(np.float64(d))) + np.float64(1e-290))
     klo = (z - R) * (1.0 - 4.0 * U) if z > R else 0.0
     khi = (z + R) * (1.0 + 4.0 * U)
@@ -138,3 +139,46 @@ def test_reference_key_lies_inside_the_interval_for_any_order(length, scale):
                     assert abs(plo - klo) <= 1e-3 * (khi - klo) and abs(phi - khi) <= 1e-3 * (khi - klo)
                 if scale == 1.0 and np.isfinite(khi):               # and it is an interval worth having
                     assert khi - klo <= 1e-9 * (abs(d_ref / nrm) + abs(d)) + 1e-11 * length / np.sqrt(nrm)
+
+
+@pytest.mark.parametrize("length", [1, 7, 33, 100, 1536])
+@pytest.mark.parametrize("scale", [1e-30, 1e-3, 1.0, 3e4, 1e25])
+def test_reference_key_lies_inside_the_integer_filters_interval(length, scale):
+    """csrc/refcos_q8.hip: 23-bit fixed point per segment, six exact integer digit products, the three cheapest left
+    out -- the bound it adds to the interval (tests/bounds.py restates records and kernel) must hold the reference's
+    key for parallel, orthogonal and wildly mixed segments, and be worth having on ordinary ones."""
+    import bounds
+    rng = np.random.default_rng(length * 77 + int(np.log10(scale)) + 900)
+    for trial in range(5):
+        la = length
+        lb = length if trial != 4 else max(1, length // 2)          # unequal lengths: the common prefix (src/sound.rs:24-28)
+        a = rng.standard_normal(la) * scale
+        b = rng.standard_normal(lb) * scale
+        if trial == 1:
+            b = a[:lb] * (1 + 1e-9 * rng.standard_normal(lb))
+        if trial == 2 and lb > 1:
+            b = b - a[:lb] * (a[:lb] @ b) / (a[:lb] @ a[:lb])
+        if trial == 3:
+            a[::2] *= 1e6                                           # a crest factor of 1e6: half the digits carry nothing
+        na = 0.0
+        for x in a:
+            na = float(np.float64(x) * np.float64(x) + np.float64(na))
+        nb = 0.0
+        for x in b:
+            nb = float(np.float64(x) * np.float64(x) + np.float64(nb))
+        L = min(la, lb)
+        d_ref = dot_reference(a[:L], b[:L])
+        nrm = na * nb
+        qa, qb = bounds.q8_quantise(a), bounds.q8_quantise(b)
+        assert qa is not None and qb is not None
+        ia, ib = float(np.float64(1.0) / np.float64(na)), float(np.float64(1.0) / np.float64(nb))
+        dq, gk, a2b2, extra = bounds.q8_dot_and_extra(qa, qb, la, lb, ia, ib)
+        exact = sum(Fraction(float(x)) * Fraction(float(y)) for x, y in zip(a[:L], b[:L]))
+        # the bound on the dot itself, before anything of the key: |D - dq| <= extra / (ia ib)
+        assert abs(exact - Fraction(dq)) <= Fraction(extra) / (Fraction(ia) * Fraction(ib)) * Fraction(1 + 1e-12)
+        for d in (1.0, 0.0, 0.37):
+            k_ref = abs(float(np.float64(d_ref) / np.float64(nrm)) - d)
+            klo, khi = key_interval(dq, na, nb, L, d, extra)
+            assert klo <= k_ref <= khi, (length, scale, trial, d, dq, d_ref, klo, k_ref, khi)
+        if trial == 0 and length >= 100:                            # ~1e-5 of a similarity's scale on ordinary data
+            assert extra * np.sqrt(nrm) <= 2e-5, extra * np.sqrt(nrm)
