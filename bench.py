@@ -111,29 +111,51 @@ def secondary_metrics(device: int) -> dict:
     e = Engine(metric="refcos", dtype="f64", device=device)
     d = e.dictionary(g.sources.astype(np.float64).reshape(-1), off, dd)
     q = e.queries(g.targets.astype(np.float64).reshape(-1), off, dd)
-    e.match(d, q)
-    t0 = time.perf_counter()
-    kms = []
-    for _ in range(5):
+    def leg():
         e.match(d, q)
-        kms.append(e.timings()["main_ms"])
-    dt = (time.perf_counter() - t0) / 5
-    k_s = float(np.mean(kms)) * 1e-3
+        t0 = time.perf_counter()
+        kms = []
+        for _ in range(5):
+            e.match(d, q)
+            kms.append(e.timings()["main_ms"])
+        return (time.perf_counter() - t0) / 5, float(np.mean(kms)) * 1e-3, e.timings()
+
+    # The search's filter is the integer one (csrc/refcos_q8.hip: six exact int8 GEMMs on v_mfma_i32_32x32x32_i8) where
+    # the sets' values allow it, the f64 matrix pipe (csrc/refcos_mfma.hip) otherwise; both are timed, the default first.
+    dt, k_s, tmr = leg()
+    os.environ["SSYM_REFCOS_Q8"] = "0"
+    dt64, k64, tm64 = leg()
+    del os.environ["SSYM_REFCOS_Q8"]
     # algorithmic work of the reference's metric: 2 L f64 flops per pair, L = F d, as one zero-padded GEMM.
-    # The dominant kernel runs it on v_mfma_f64_16x16x4_f64: 64 cycles per instruction on MI355X (measured:
-    # profiles/r02_refcos_1gpu.md), i.e. 2048 flops / 64 cycles x 1024 SIMDs x 2.4 GHz = 78.6 TFLOP/s, the f64 matrix peak
+    # f64 filter: v_mfma_f64_16x16x4_f64, 64 cycles per instruction on MI355X (measured: profiles/r02_refcos_1gpu.md), i.e.
+    # 2048 flops / 64 cycles x 1024 SIMDs x 2.4 GHz = 78.6 TFLOP/s.  Integer filter: the same dot as SIX int8 GEMMs (digit
+    # products of three 8-bit digits per value), 12 L integer operations per pair, on v_mfma_i32_32x32x32_i8: 65536
+    # operations / 32 cycles x 1024 SIMDs x 2.4 GHz = 5033 TOP/s dense.
     flops = 2.0 * n * n * f * dd
-    tmr = e.timings()
+    roof64 = {"bound": "mfma", "kernel": "refcos_mfma_kernel" if tm64["used_filter"] else "refcos_sims8_kernel",
+              "kernel_ms": k64 * 1e3, "achieved": flops / k64 / 1e12, "peak": 78.6, "unit": "TFLOP/s",
+              "frac": flops / k64 / 1e12 / 78.6,
+              "model": "2*F*d f64 flops per pair (SURVEY.md 8(d)) over the main kernel's time (HIP events); "
+                       "peak = dense f64 MFMA rate, v_mfma_f64_16x16x4_f64 at 64 cycles per instruction"}
+    if tmr["refcos_filter"] == 2:
+        roof = {"bound": "mfma", "kernel": "refcos_q8_kernel", "kernel_ms": k_s * 1e3, "achieved": 6.0 * flops / k_s / 1e12,
+                "peak": 5033.0, "unit": "TFLOP/s", "frac": 6.0 * flops / k_s / 1e12 / 5033.0,
+                "model": "six int8 GEMMs (12*F*d integer operations per pair) over the main kernel's time (HIP events); "
+                         "peak = dense i8 MFMA rate, v_mfma_i32_32x32x32_i8 at 32 cycles per instruction; what binds the "
+                         "kernel is operand delivery, not the pipe (DESIGN.md 5.5)"}
+    else:
+        roof = roof64
     out["refcos"] = {"value": n * n / dt, "unit": "segment-pairs/s", "ms_per_step": dt * 1e3,
                      "workload": f"{n}x{n} segments, {f} frames x {dd} dims, f64, reference metric "
                                  "(cosine_sim + at_distance, bit-exact)",
                      "phase_ms": {k: round(float(v), 3) for k, v in tmr.items() if k.endswith("_ms")},
-                     "through_matrix_pipe": bool(tmr["used_filter"]), "pairs_rescored_exactly": int(tmr["n_refined"]),
-                     "roofline": {"bound": "mfma", "kernel": "refcos_mfma_kernel" if tmr["used_filter"] else "refcos_sims_kernel",
-                                  "kernel_ms": k_s * 1e3, "achieved": flops / k_s / 1e12, "peak": 78.6, "unit": "TFLOP/s",
-                                  "frac": flops / k_s / 1e12 / 78.6,
-                                  "model": "2*F*d f64 flops per pair (SURVEY.md 8(d)) over the main kernel's time (HIP events); "
-                                           "peak = dense f64 MFMA rate, v_mfma_f64_16x16x4_f64 at 64 cycles per instruction"}}
+                     "through_matrix_pipe": bool(tmr["used_filter"]),
+                     "filter": {0: "none (exact tile kernel)", 1: "f64 matrix pipe", 2: "int8 matrix pipe"}[int(tmr["refcos_filter"])],
+                     "pairs_rescored_exactly": int(tmr["n_refined"]), "roofline": roof,
+                     "f64_filter": {"value": n * n / dt64, "unit": "segment-pairs/s", "ms_per_step": dt64 * 1e3,
+                                    "pairs_rescored_exactly": int(tm64["n_refined"]), "roofline": roof64,
+                                    "note": "the same search with SSYM_REFCOS_Q8=0: what sets with values the integer "
+                                            "records cannot hold (not finite, far out of range) take"}}
     dist_ = np.linspace(0.2, 1.2, 256)
     e.chain(d, g.targets[0].astype(np.float64).reshape(-1), dist_[:2])
     t0 = time.perf_counter()

@@ -581,6 +581,10 @@ int32_t match_sharded_step(ssym_ctx *ctx, ssym_comm *comm, const ssym_dict *dict
         userCost = (double *)ctx->out_cost.ptr;
     }
 
+    // refcos: the integer filter's records of the two sets are built HERE, on their first sharded step (it synchronises
+    // once; inside the stream-only phases nothing may) -- where they cannot be built the step takes the f64 matrix pipe
+    if (refcos && dict->set.n && dict->set.dim == q->set.dim)
+        (void)refcos_q8_ready(ctx, dict->set, q->set);
     StageScope stageScope(ctx);
     StreamOnly streamOnly(ctx);
     hipEvent_t *cev = comm->ev;

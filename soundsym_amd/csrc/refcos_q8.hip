@@ -177,6 +177,50 @@ __global__ __launch_bounds__(256, 1) void refcos_q8_kernel(
     }
     const uint32_t sTile = by * kQT, tTile = bx * kQT;
 
+    // staging: thread -> (row = tid / 8 + 32 p, position tid & 7) for p = 0..3 on both sides; the piece it fetches is
+    // position ^ swizzle(row).  Per-lane byte offsets are constants, the chunk's base is scalar.
+    const int sr = tid >> 3;
+    unsigned offA[4], offB[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int row = sr + 32 * p;
+        const unsigned piece = (unsigned)((tid & 7) ^ ((row >> 1) & 7));
+        offA[p] = (unsigned)row * srcGroups * 128u + piece * 16u;
+        offB[p] = (unsigned)row * tgtGroups * 128u + piece * 16u;
+    }
+    const unsigned char *const tileA = (const unsigned char *)srcQ + (size_t)sTile * srcGroups * 128;
+    const unsigned char *const tileB = (const unsigned char *)tgtQ + (size_t)tTile * tgtGroups * 128;
+    auto stageA = [&](auto S) -> unsigned char * {
+        constexpr int s = decltype(S)::value;
+        return s == 0 ? sA0 : s == 1 ? sA1 : s == 2 ? sA2 : sA3;
+    };
+    auto stageB = [&](auto S) -> unsigned char * {
+        constexpr int s = decltype(S)::value;
+        return s == 0 ? sB0 : s == 1 ? sB1 : s == 2 ? sB2 : sB3;
+    };
+    auto fetch = [&](unsigned c, auto S) {                // eight DMAs, nothing waits here
+        unsigned char *const dA = stageA(S), *const dB = stageB(S);
+        const unsigned char *ua = tileA + (size_t)c * 128, *ub = tileB + (size_t)c * 128;
+        asm volatile("" : "+s"(ua), "+s"(ub));            // (scalar base + 32-bit lane offset: refcos_mfma.hip)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            asm volatile("" : "+v"(offA[p]), "+v"(offB[p]));
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ua + offA[p]),
+                                             (__attribute__((address_space(3))) void *)&dA[(32 * p + 8 * wave) * 128], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ub + offB[p]),
+                                             (__attribute__((address_space(3))) void *)&dB[(32 * p + 8 * wave) * 128], 16, 0, 0);
+        }
+    };
+
+    // The first three chunks are requested before anything is known about the tile's segments (their rows exist and are
+    // zero beyond a segment's end whatever its length): the per-segment values below are fetched under them.
+    const unsigned nGroupsMin = min(srcGroups, tgtGroups);
+    if (nGroupsMin > 0)
+        fetch(0, std::integral_constant<int, 0>{});
+    if (nGroupsMin > 1)
+        fetch(1, std::integral_constant<int, 1>{});
+    if (nGroupsMin > 2)
+        fetch(2, std::integral_constant<int, 2>{});
     if (tid < 2)
         sMaxLen[tid] = 0;
     if (tid < 4)
@@ -219,41 +263,6 @@ __global__ __launch_bounds__(256, 1) void refcos_q8_kernel(
     __syncthreads();
     const unsigned kMax = __builtin_amdgcn_readfirstlane(min(sMaxLen[0], sMaxLen[1]));
     const unsigned nChunks = (kMax + kQG - 1) / kQG;
-
-    // staging: thread -> (row = tid / 8 + 32 p, position tid & 7) for p = 0..3 on both sides; the piece it fetches is
-    // position ^ swizzle(row).  Per-lane byte offsets are constants, the chunk's base is scalar.
-    const int sr = tid >> 3;
-    unsigned offA[4], offB[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int row = sr + 32 * p;
-        const unsigned piece = (unsigned)((tid & 7) ^ ((row >> 1) & 7));
-        offA[p] = (unsigned)row * srcGroups * 128u + piece * 16u;
-        offB[p] = (unsigned)row * tgtGroups * 128u + piece * 16u;
-    }
-    const unsigned char *const tileA = (const unsigned char *)srcQ + (size_t)sTile * srcGroups * 128;
-    const unsigned char *const tileB = (const unsigned char *)tgtQ + (size_t)tTile * tgtGroups * 128;
-    auto stageA = [&](auto S) -> unsigned char * {
-        constexpr int s = decltype(S)::value;
-        return s == 0 ? sA0 : s == 1 ? sA1 : s == 2 ? sA2 : sA3;
-    };
-    auto stageB = [&](auto S) -> unsigned char * {
-        constexpr int s = decltype(S)::value;
-        return s == 0 ? sB0 : s == 1 ? sB1 : s == 2 ? sB2 : sB3;
-    };
-    auto fetch = [&](unsigned c, auto S) {                // eight DMAs, nothing waits here
-        unsigned char *const dA = stageA(S), *const dB = stageB(S);
-        const unsigned char *ua = tileA + (size_t)c * 128, *ub = tileB + (size_t)c * 128;
-        asm volatile("" : "+s"(ua), "+s"(ub));            // (scalar base + 32-bit lane offset: refcos_mfma.hip)
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            asm volatile("" : "+v"(offA[p]), "+v"(offB[p]));
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ua + offA[p]),
-                                             (__attribute__((address_space(3))) void *)&dA[(32 * p + 8 * wave) * 128], 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ub + offB[p]),
-                                             (__attribute__((address_space(3))) void *)&dB[(32 * p + 8 * wave) * 128], 16, 0, 0);
-        }
-    };
 
     v16i acc[3][2][2];
 #pragma unroll
@@ -303,12 +312,6 @@ __global__ __launch_bounds__(256, 1) void refcos_q8_kernel(
                     for (int b = 0; b < 2; ++b)
                         acc[pa + pb][a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[pa][a], bv[pb][b], acc[pa + pb][a][b], 0, 0, 0);
     };
-    if (nChunks > 0)
-        fetch(0, std::integral_constant<int, 0>{});
-    if (nChunks > 1)
-        fetch(1, std::integral_constant<int, 1>{});
-    if (nChunks > 2)
-        fetch(2, std::integral_constant<int, 2>{});
     for (unsigned c = 0; c < nChunks; c += 4) {
         chunk(c, std::integral_constant<int, 0>{});
         if (c + 1 < nChunks)
@@ -506,7 +509,9 @@ int32_t refcos_q8_ensure(ssym_ctx *ctx, const SegmentSet &set)
 
 bool refcos_q8_ready(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt)
 {
-    static const bool off = getenv("SSYM_REFCOS_Q8") && atoi(getenv("SSYM_REFCOS_Q8")) == 0;
+    // (read per call, not once: bench.py and the tests time and check both filters in one process)
+    const char *knob = getenv("SSYM_REFCOS_Q8");
+    const bool off = knob && atoi(knob) == 0;
     if (off || ctx->metric != SSYM_METRIC_REFCOS || src.dim != tgt.dim)
         return false;
     if (ctx->stream_only && (src.q8_state == 0 || tgt.q8_state == 0))

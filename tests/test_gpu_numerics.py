@@ -244,6 +244,36 @@ def test_refcos_mfma_segments_outside_the_plain_range_take_the_long_epilogue(ora
     e.close()
 
 
+def test_refcos_both_filters_give_the_same_search(oracle, monkeypatch):
+    """SSYM_REFCOS_Q8=0 (read per call) sends the search through the f64 matrix pipe instead of the integer filter:
+    the two candidate lists differ, indices and values may not -- here against each other and against the oracle, on
+    near-ties closer than either filter resolves."""
+    n, m, dim = 384, 256, 12
+    src, tgt = _refcos_sets(0x5EED7B00, n, m, 60, 128, dim)
+    for j in range(0, m, 8):                       # targets that are copies of a source; every third with a last-place change
+        tgt[j] = src[(5 * j) % n].copy()
+        if j % 3 == 0:
+            tgt[j][0, 0] = np.nextafter(tgt[j][0, 0], np.inf)
+    for i in range(0, n, 16):                      # duplicated sources: the lower index must win
+        src[(i + 200) % n] = src[i].copy()
+    sf, so = pack_segments(src, dim)
+    tf, to = pack_segments(tgt, dim)
+    e = Engine(metric="refcos", dtype="f64")
+    d, q = e.dictionary(sf, so, dim), e.queries(tf, to, dim)
+    want_idx, want_val = oracle.refcos_match_all(sf, so, tf, to, dim)
+    got = {}
+    for knob in ("1", "0"):
+        monkeypatch.setenv("SSYM_REFCOS_Q8", knob)
+        idx, val = e.match(d, q)
+        tm = e.timings()
+        assert tm["refcos_filter"] == (2 if knob == "1" else 1), tm
+        assert np.array_equal(idx, want_idx) and np.array_equal(val, want_val)
+        got[knob] = tm["n_refined"]
+    assert got["1"] >= got["0"] >= m               # the integer filter keeps a little more, both at least a winner per target
+    assert got["1"] < 4 * m, got
+    e.close()
+
+
 def nat_pair_matrix(e, d, q, mode):
     import ctypes
     from soundsym_amd import _native as nat
