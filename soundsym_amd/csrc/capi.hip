@@ -405,6 +405,7 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
     }
 
     hipEvent_t *ev = ctx->ev;
+    bool outputsStaged = false;          // host outputs already copied and synchronised (refcos filter path)
     if (ctx->metric == SSYM_METRIC_REFCOS) {
         // The plain first-minimum search goes through the f64 matrix pipe (refcos_mfma.hip): every pair's dot as a
         // GEMM, a rigorous interval per key, and the reference's own arithmetic only on the few pairs that can
@@ -438,10 +439,23 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
             }
             SSYM_HIP_CHECK(ctx, hipMemcpyAsync(h1, h1dev, sizeof(h1), hipMemcpyDeviceToHost, st));
             SSYM_HIP_CHECK(ctx, hipMemcpyAsync(h2, h2dev, sizeof(h2), hipMemcpyDeviceToHost, st));
+            // host outputs: their copies ride on the same synchronisation as the headers (a search of 0.26 ms does not
+            // want two); should the list have overflowed they are dropped and the exact kernel's results staged instead
+            const size_t pendingBefore = ctx->pending_d2h.size();
+            if (!outDev) {
+                rc = stage_d2h(ctx, out_idx, idxDev, sizeof(uint32_t) * (size_t)M * k_top);
+                if (rc == SSYM_OK && out_cost)
+                    rc = stage_d2h(ctx, out_cost, costDev, sizeof(double) * (size_t)M * k_top);
+                if (rc != SSYM_OK)
+                    return rc;
+                outputsStaged = true;
+            }
             SSYM_HIP_CHECK(ctx, hipStreamSynchronize(st));
             if (h1[1]) {
                 viaMfma = false;             // more near-ties than the list holds: the exact kernel on every pair
                 tm.refcos_filter = 0;
+                ctx->pending_d2h.resize(pendingBefore);
+                outputsStaged = false;
             }
             else {
                 tm.used_filter = 1;
@@ -676,7 +690,7 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
         }
     }
 
-    if (!outDev) {
+    if (!outDev && !outputsStaged) {
         rc = stage_d2h(ctx, out_idx, idxDev, sizeof(uint32_t) * (size_t)M * k_top);
         if (rc == SSYM_OK && out_cost)
             rc = stage_d2h(ctx, out_cost, costDev, sizeof(double) * (size_t)M * k_top);
@@ -688,7 +702,7 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
         ctx->timings = tm;
         return SSYM_OK;
     }
-    if (!outDev || ctx->metric == SSYM_METRIC_REFCOS)
+    if ((!outDev || ctx->metric == SSYM_METRIC_REFCOS) && !outputsStaged)      // (staged: already synchronised above)
         SSYM_HIP_CHECK(ctx, hipStreamSynchronize(st));
     stage_finish(ctx);
     if (ctx->metric == SSYM_METRIC_REFCOS) {

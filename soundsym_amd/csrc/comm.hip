@@ -778,6 +778,7 @@ int32_t match_sharded_step(ssym_ctx *ctx, ssym_comm *comm, const ssym_dict *dict
             tm.n_refined = ownCount[0];
         } else if (finished && ctx->so_refcos) {       // refcos through the matrix pipe: main kernel | exact keys and fold
             tm.used_filter = 1;
+            tm.refcos_filter = ctx->timings.refcos_filter;     // (which filter the enqueueing call took: capi.hip)
             tm.main_launches = 1;
             tm.main_ms = ev_ms2(ctx->ev[0], ctx->ev[1]);
             red_ms += ev_ms2(ctx->ev[1], ctx->ev[2]);

@@ -260,6 +260,7 @@ def test_sharded_refcos_goes_through_the_matrix_pipe(oracle):
         got = sharding.match_sharded(r, comm, d, q, 0, distance=dd)
         tm = r.timings()
         assert tm["used_filter"] == 1 and tm["attempts"] == 1 and tm["n_refined"] < 8 * 260, tm
+        assert tm["refcos_filter"] == 2, tm           # (the integer filter: its records are built when the step starts)
         assert np.array_equal(got[0], want_idx) and np.array_equal(got[1], want_val)
     comm.close()
     r.close()
@@ -269,7 +270,7 @@ def test_sharded_refcos_goes_through_the_matrix_pipe(oracle):
         want_idx, want_val = oracle.refcos_match_all(sf, so, tf, to, 12, distance=dd)
         res = _run_ranks(2, "refcos", "f64", shards, 12, tf, to, [a for a, _ in cuts], distance=dd)
         for rk in range(2):
-            assert res[rk][2]["used_filter"] == 1 and res[rk][2]["attempts"] == 1
+            assert res[rk][2]["used_filter"] == 1 and res[rk][2]["attempts"] == 1 and res[rk][2]["refcos_filter"] == 2
             assert np.array_equal(res[rk][0], want_idx) and np.array_equal(res[rk][1], want_val), rk
     # rank 0's sources all identical: its list 1 overflows, both ranks repeat the tail, rank 0 on the exact tile kernel
     rng = np.random.default_rng(8)
