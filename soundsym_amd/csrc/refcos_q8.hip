@@ -212,15 +212,17 @@ __global__ __launch_bounds__(256, 1) void refcos_q8_kernel(
         }
     };
 
-    // The first three chunks are requested before anything is known about the tile's segments (their rows exist and are
+    // The first four chunks are requested before anything is known about the tile's segments (their rows exist and are
     // zero beyond a segment's end whatever its length): the per-segment values below are fetched under them.
     const unsigned nGroupsMin = min(srcGroups, tgtGroups);
-    if (nGroupsMin > 0)
+    // (always four groups of eight DMAs, a chunk index beyond the rows' end clamped to their last group: the waits below
+    //  count groups, and a group that is not needed lands in a stage nobody reads)
+    if (nGroupsMin > 0) {
         fetch(0, std::integral_constant<int, 0>{});
-    if (nGroupsMin > 1)
-        fetch(1, std::integral_constant<int, 1>{});
-    if (nGroupsMin > 2)
-        fetch(2, std::integral_constant<int, 2>{});
+        fetch(min(1u, nGroupsMin - 1), std::integral_constant<int, 1>{});
+        fetch(min(2u, nGroupsMin - 1), std::integral_constant<int, 2>{});
+        fetch(min(3u, nGroupsMin - 1), std::integral_constant<int, 3>{});
+    }
     if (tid < 2)
         sMaxLen[tid] = 0;
     if (tid < 4)
@@ -278,30 +280,28 @@ __global__ __launch_bounds__(256, 1) void refcos_q8_kernel(
     // operand reads: lane (r = lane & 31, h = lane >> 5) takes, of row (block row 32 blk + r) and digit plane p, the 16
     // bytes k = 16 h .. 16 h + 15 of the group: piece 2 p + h, at position (2 p + h) ^ swizzle(row)
     const int lr = lane & 31, lh = lane >> 5;
-    auto chunk = [&](unsigned c, auto S) {
-        constexpr int s = decltype(S)::value;
-        using Next = std::integral_constant<int, (s + 3) & 3>;
-        // chunk c has landed (the DMAs of c + 1 and c + 2 may still be in flight: eight each) and every wave is done
-        // with chunk c - 1, whose buffer takes chunk c + 3
-        if (c + 2 < nChunks)
-            __builtin_amdgcn_s_waitcnt(rm_wait_vmcnt(16));
-        else if (c + 1 < nChunks)
-            __builtin_amdgcn_s_waitcnt(rm_wait_vmcnt(8));
-        else
-            __builtin_amdgcn_s_waitcnt(rm_wait_vmcnt(0));
-        __syncthreads();
-        if (c + 3 < nChunks)
-            fetch(c + 3, Next{});
+    // Software pipeline with ONE wave per SIMD: nothing else hides what a wave waits for, so a chunk's operands are read
+    // from LDS into a second register set while the PREVIOUS chunk's MFMAs run.  Iteration c: [chunk c + 1 has landed
+    // (own DMAs) | own reads of chunk c are complete | barrier] -> chunk c's stage is free and chunk c + 1 is complete
+    // for everybody -> DMA of chunk c + 4 into the freed stage, operand reads of chunk c + 1 into the other register
+    // set, MFMAs of chunk c.  (Reads, DMA issue and barrier skew sat in front of every chunk's MFMAs before: 1600
+    // cycles per chunk for 768 of MFMAs.)  The barrier is the bare instruction, not __syncthreads(): that one is a fence
+    // too, and a fence after DMAs into LDS makes the compiler wait for ALL of them.
+    v4i av[2][3][2], bv[2][3][2];                          // [register set][digit plane][block]
+    auto readops = [&](auto S, auto SET) {
+        constexpr int set = decltype(SET)::value;
         const unsigned char *const rA = stageA(S), *const rB = stageB(S);
-        v4i av[3][2], bv[3][2];
 #pragma unroll
         for (int p = 0; p < 3; ++p)
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {
                 const int rowA = wm * 64 + blk * 32 + lr, rowB = wn * 64 + blk * 32 + lr;
-                av[p][blk] = *reinterpret_cast<const v4i *>(&rA[rowA * 128 + (((2 * p + lh) ^ ((rowA >> 1) & 7)) << 4)]);
-                bv[p][blk] = *reinterpret_cast<const v4i *>(&rB[rowB * 128 + (((2 * p + lh) ^ ((rowB >> 1) & 7)) << 4)]);
+                av[set][p][blk] = *reinterpret_cast<const v4i *>(&rA[rowA * 128 + (((2 * p + lh) ^ ((rowA >> 1) & 7)) << 4)]);
+                bv[set][p][blk] = *reinterpret_cast<const v4i *>(&rB[rowB * 128 + (((2 * p + lh) ^ ((rowB >> 1) & 7)) << 4)]);
             }
+    };
+    auto mfmas = [&](auto SET) {
+        constexpr int set = decltype(SET)::value;
 #pragma unroll
         for (int pa = 0; pa < 3; ++pa)
 #pragma unroll
@@ -310,18 +310,71 @@ __global__ __launch_bounds__(256, 1) void refcos_q8_kernel(
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
                     for (int b = 0; b < 2; ++b)
-                        acc[pa + pb][a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[pa][a], bv[pb][b], acc[pa + pb][a][b], 0, 0, 0);
+                        acc[pa + pb][a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[set][pa][a], bv[set][pb][b], acc[pa + pb][a][b], 0, 0, 0);
     };
+    auto step = [&](unsigned c, auto S) {
+        constexpr int s = decltype(S)::value;
+        using Set = std::integral_constant<int, s & 1>;
+        using OtherSet = std::integral_constant<int, (s & 1) ^ 1>;
+        using NextStage = std::integral_constant<int, (s + 1) & 3>;
+        // chunk c + 1 has landed (the groups of c + 2 and c + 3 may still be in flight: every step issues one group)
+        __builtin_amdgcn_s_waitcnt(rm_wait_vmcnt(16));
+        __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0): this wave's reads of chunk c are in its registers
+        asm volatile("s_barrier" ::: "memory");
+        // One basic block from here: 8 DMAs (chunk c + 4 into the stage just vacated), 12 operand reads (chunk c + 1 into
+        // the other register set), 24 MFMAs (chunk c) -- none of them conditional, so that the scheduler can be told
+        // to spread the memory instructions BETWEEN the MFMAs instead of in front of them (20 issue slots of 16 cycles
+        // and more with the matrix pipe idle, per chunk).  A chunk beyond the tile's last is a clamped, unused copy.
+#ifndef SSYM_Q8_NODMA        // (tools only: timing without the loop's DMAs -- the MFMAs then run on stale bytes)
+        fetch(min(c + 4, nGroupsMin - 1), S);
+#endif
+        readops(NextStage{}, OtherSet{});
+        mfmas(Set{});
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // VMEM read (the DMA)
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // DS read
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (i < 4)
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+    };
+    if (nChunks > 0) {
+        __builtin_amdgcn_s_waitcnt(rm_wait_vmcnt(24));
+        asm volatile("s_barrier" ::: "memory");
+        readops(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    }
     for (unsigned c = 0; c < nChunks; c += 4) {
-        chunk(c, std::integral_constant<int, 0>{});
+        step(c, std::integral_constant<int, 0>{});
         if (c + 1 < nChunks)
-            chunk(c + 1, std::integral_constant<int, 1>{});
+            step(c + 1, std::integral_constant<int, 1>{});
         if (c + 2 < nChunks)
-            chunk(c + 2, std::integral_constant<int, 2>{});
+            step(c + 2, std::integral_constant<int, 2>{});
         if (c + 3 < nChunks)
-            chunk(c + 3, std::integral_constant<int, 3>{});
+            step(c + 3, std::integral_constant<int, 3>{});
     }
 
+#ifdef SSYM_Q8_NOEPI         // (tools only: the main loop alone, every accumulator kept alive)
+    {
+        v16i t = acc[0][0][0];
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b2 = 0; b2 < 2; ++b2)
+                    t += acc[l][a][b2];
+        int x = 0;
+#pragma unroll
+        for (int g = 0; g < 16; ++g)
+            x ^= t[g];
+        if (x == 0x12345678 && hdr[0] == 77)
+            thr[0] = 1;
+        return;
+    }
+#endif
     // ---- epilogue: integer dots -> key intervals -> thresholds and list 1 (the steps of refcos_mfma.hip's) -----------
     // D layout of the 32 x 32 forms: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
     const double INF = __builtin_inf();
@@ -450,6 +503,8 @@ __global__ __launch_bounds__(256, 1) void refcos_q8_kernel(
                     }
                 }
     }
+    __builtin_amdgcn_s_waitcnt(rm_wait_vmcnt(0));          // (the last, unused DMA groups have long landed: the LDS they write
+                                                           //  into must still be this workgroup's when they do)
 }
 
 }  // namespace
