@@ -159,6 +159,7 @@ __global__ __launch_bounds__(256, 1) void refcos_q8_kernel(
     __shared__ unsigned sLen[2 * kQT];
     __shared__ unsigned sMaxLen[2];
     __shared__ unsigned sPlain[4];
+    __shared__ unsigned long long sRowMax[2][4];           // per half of the tile's rows: max of a1..a4 (bits: they are >= 0)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -227,6 +228,8 @@ __global__ __launch_bounds__(256, 1) void refcos_q8_kernel(
         sMaxLen[tid] = 0;
     if (tid < 4)
         sPlain[tid] = 1;
+    if (tid < 8)
+        sRowMax[tid >> 2][tid & 3] = 0;
     __syncthreads();
     {
         const bool isS = tid < kQT;
@@ -261,6 +264,12 @@ __global__ __launch_bounds__(256, 1) void refcos_q8_kernel(
         const bool ok = g < n && r.norm >= 1e-139 && r.norm <= 1e139 && fabs(r.dist) <= 1e300;
         if (!ok)
             atomicAnd(&sPlain[tid >> 6], 0u);
+        if (isS && ok) {                                   // (a half with a row that is not plain takes the general form)
+            atomicMax(&sRowMax[tid >> 6][0], (unsigned long long)__double_as_longlong(r.a1));
+            atomicMax(&sRowMax[tid >> 6][1], (unsigned long long)__double_as_longlong(r.a2));
+            atomicMax(&sRowMax[tid >> 6][2], (unsigned long long)__double_as_longlong(r.a3));
+            atomicMax(&sRowMax[tid >> 6][3], (unsigned long long)__double_as_longlong(r.a4));
+        }
     }
     __syncthreads();
     const unsigned kMax = __builtin_amdgcn_readfirstlane(min(sMaxLen[0], sMaxLen[1]));
@@ -389,31 +398,60 @@ __global__ __launch_bounds__(256, 1) void refcos_q8_kernel(
     }
     double klo[2][2][16];                                  // [column block][row block][register]
     double khis[TOPK ? 2 : 1][TOPK ? 2 : 1][TOPK ? 16 : 1];
+    // PLAIN waves (all 64 + 64 segments inside the sets, norms in [1e-139, 1e139], finite distances -- and, the records
+    // existing, all values finite): per pair only z = |s - dist| is formed, 10 operations; the half-width of the interval
+    // comes from per-COLUMN constants -- the column's own numbers against the largest a1..a4 among the wave's 64 rows,
+    // and |s| <= z + |dist| -- so R <= Rub(z) = c9 (z + 2 |dist|) + C, increasing in z: the column's threshold is the
+    // bound of its smallest z, and key_lo >= z (1 - c9) - K with K = 2 c9 |dist| + C, one multiply-add per pair after the
+    // thresholds are known.  (The general form below keeps every row's own numbers: ~27 operations per pair.)
+    const double c9 = 9.0 * u * 1.0000001;
+    double Cb[2], Kb[2];
+    if (plain) {
+        const double m1 = __longlong_as_double((long long)sRowMax[wm][0]), m2 = __longlong_as_double((long long)sRowMax[wm][1]);
+        const double m3 = __longlong_as_double((long long)sRowMax[wm][2]), m4 = __longlong_as_double((long long)sRowMax[wm][3]);
+        double zmin[2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b) {
+            Cb[b] = 1.0001 * __fma_rn(m4, ci[b].a4, __fma_rn(m1, ci[b].a2, __fma_rn(m2, ci[b].a1, m3 * ci[b].a3))) + 1e-290;
+            Kb[b] = __fma_rn(2.0 * c9, fabs(ci[b].dist), Cb[b]) * (1.0 + 4.0 * u);
+            zmin[b] = INF;
+        }
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            const int row = wm * 64 + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
-            const QInfo ri = sInfo[row];
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                // the kept part of the integer dot, exactly: a multiple of 2^16 below 2^60
-                const double gk = __fma_rn(0x1p32, (double)acc[0][a][b][g],
-                                           __fma_rn(0x1p24, (double)acc[1][a][b][g], 0x1p16 * (double)acc[2][a][b][g]));
-                const double extra = __fma_rn(ri.a1, ci[b].a2, __fma_rn(ri.a2, ci[b].a1, ri.a3 * ci[b].a3));
-                double lo, hi;
-                if (plain) {
-                    // (the short form of refcos_mfma.hip's epilogue: nothing of refcos_key_interval's tests can fire)
-                    const double sv = gk * (ri.a2 * ci[b].a2);
-                    const double z = fabs(sv - ci[b].dist);
-                    const double R = __fma_rn(9.0 * u, fabs(sv) + fabs(ci[b].dist), 1.0001 * __fma_rn(ri.a4, ci[b].a4, extra)) + 1e-290;
-                    lo = fmax((z - R) * (1.0 - 4.0 * u), 0.0);
-                    hi = (z + R) * (1.0 + 4.0 * u);
-                } else {
+            for (int g = 0; g < 16; ++g) {
+                const int row = wm * 64 + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
+                const double ra2 = sInfo[row].a2;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    // the kept part of the integer dot, exactly: a multiple of 2^16 below 2^60
+                    const double gk = __fma_rn(0x1p32, (double)acc[0][a][b][g],
+                                               __fma_rn(0x1p24, (double)acc[1][a][b][g], 0x1p16 * (double)acc[2][a][b][g]));
+                    const double z = fabs(gk * (ra2 * ci[b].a2) - ci[b].dist);
+                    klo[b][a][g] = z;                      // (becomes key_lo once the thresholds are known)
+                    zmin[b] = fmin(zmin[b], z);
+                }
+            }
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+            colMin[b] = (zmin[b] + __fma_rn(c9, zmin[b] + 2.0 * fabs(ci[b].dist), Cb[b])) * (1.0 + 4.0 * u);
+    } else {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int row = wm * 64 + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
+                const QInfo ri = sInfo[row];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const double gk = __fma_rn(0x1p32, (double)acc[0][a][b][g],
+                                               __fma_rn(0x1p24, (double)acc[1][a][b][g], 0x1p16 * (double)acc[2][a][b][g]));
+                    const double extra = __fma_rn(ri.a1, ci[b].a2, __fma_rn(ri.a2, ci[b].a1, ri.a3 * ci[b].a3));
                     const unsigned la = sLen[row], lb = sLen[kQT + wn * 64 + b * 32 + lr];
                     const unsigned len = la < lb ? la : lb;
                     const double nrm = __dmul_rn(ri.norm, ci[b].norm);
                     const double dotm = gk * (ri.scl * ci[b].scl);
+                    double lo, hi;
                     refcos_key_interval(dotm, ri.sq * ci[b].sq, ri.inv * ci[b].inv, nrm,
                                         (3.0 * (double)len + 16.0) * (u * 1.02), ci[b].dist, lo, hi, extra);
                     if (WRITE_SIMS) {
@@ -421,31 +459,35 @@ __global__ __launch_bounds__(256, 1) void refcos_q8_kernel(
                         if (s < nSrc && t < nTgt)
                             simOut[(size_t)s * nTgt + t] = __ddiv_rn(dotm, nrm);
                     }
+                    klo[b][a][g] = lo;
+                    if (TOPK)
+                        khis[b][a][g] = hi;
+                    else
+                        colMin[b] = fmin(colMin[b], hi);
                 }
-                klo[b][a][g] = lo;
-                if (TOPK)
-                    khis[b][a][g] = hi;
-                else
-                    colMin[b] = fmin(colMin[b], hi);
             }
-        }
+    }
     double cur[2];
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         double cmin = colMin[b];
         if (TOPK) {
+            // the kTop-th smallest DISTINCT upper bound among the wave's 64 rows (refcos_mfma.hip); in plain waves the
+            // upper bound increases with z, so the rounds run on the z themselves and the bound is formed once
             double prev = -1.0;
             for (uint32_t r = 0; r < kTop; ++r) {
                 double m = INF;
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
-                    for (int g = 0; g < 16; ++g)
-                        m = (khis[b][a][g] > prev && khis[b][a][g] < m) ? khis[b][a][g] : m;
+                    for (int g = 0; g < 16; ++g) {
+                        const double v = plain ? klo[b][a][g] : khis[b][a][g];
+                        m = (v > prev && v < m) ? v : m;
+                    }
                 m = fmin(m, __shfl_xor(m, 32));
                 prev = m;
             }
-            cmin = prev;
+            cmin = plain ? (prev + __fma_rn(c9, prev + 2.0 * fabs(ci[b].dist), Cb[b])) * (1.0 + 4.0 * u) : prev;
         } else {
             cmin = fmin(cmin, __shfl_xor(cmin, 32));
         }
@@ -463,6 +505,15 @@ __global__ __launch_bounds__(256, 1) void refcos_q8_kernel(
     for (int b = 0; b < 2; ++b) {
         seenBits[b] = __shfl(seenBits[b], lr);
         cur[b] = fmin(fmin(cur[b], __longlong_as_double((long long)seenBits[b])), 1.7976931348623157e308);
+    }
+    if (plain) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int g = 0; g < 16; ++g)
+                    klo[b][a][g] = fmax(__fma_rn(klo[b][a][g], 1.0 - c9, -Kb[b]) * (1.0 - 4.0 * u), 0.0);
     }
     unsigned total = 0;
 #pragma unroll
