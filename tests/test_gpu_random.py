@@ -187,9 +187,10 @@ _N_REFCOS_MFMA = max(16, _N_DTW // 6)
 
 @pytest.mark.parametrize("case", range(_N_REFCOS_MFMA))
 def test_refcos_matrix_pipe_random_shapes(oracle, case):
-    """The refcos search through the f64 matrix pipe (csrc/refcos_mfma.hip; from 65 536 pairs up): random ragged sets,
-    empty / all-zero segments, duplicates and prefixes, per-target distances, amplitudes from 1e-150 to 1e150 (the
-    interval's guards for norms that leave the normal range), f32 inputs -- index and value bit for bit the oracle's."""
+    """The refcos search through the matrix pipes (from 65 536 pairs up) -- the integer filter (csrc/refcos_q8.hip) where
+    the values allow it, the f64 filter (csrc/refcos_mfma.hip) at amplitudes 1e-150 and 1e150, whose values the fixed-point
+    records do not hold: random ragged sets, empty / all-zero segments, duplicates and prefixes, per-target distances,
+    f32 inputs -- index and value bit for bit the oracle's."""
     st = synth.Stream(0x5EED3000 + case)
     dim = int([1, 5, 12, 13, 40][st.integers(1, 5)[0]])
     hi = int([3, 20, 60, 130][st.integers(1, 4)[0]])
@@ -222,7 +223,8 @@ def test_refcos_matrix_pipe_random_shapes(oracle, case):
     tm = e.timings()
     want_idx, want_val = oracle.refcos_match_all(sf.astype(np.float64), so, tf.astype(np.float64), to, dim, distance=dist)
     info = dict(case=case, dim=dim, hi=hi, n=n, m=m, scale=scale, dtype=dtype, dist=use_dist, mfma=tm["used_filter"],
-                refined=tm["n_refined"])
+                filter=tm["refcos_filter"], refined=tm["n_refined"])
+    assert tm["refcos_filter"] == (1 if scale in (1e-150, 1e150) else 2), info
     assert np.array_equal(idx, want_idx), info
     assert np.array_equal(val, want_val), info
     e.close()
