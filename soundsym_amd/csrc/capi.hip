@@ -8,6 +8,15 @@
 
 using namespace ssym;
 
+// four header words of the refcos search's two lists next to its results (one copy back instead of three)
+__global__ void pack_headers_kernel(const uint32_t *__restrict__ h1, const uint32_t *__restrict__ h2, uint32_t *__restrict__ tail)
+{
+    if (threadIdx.x < 2)
+        tail[threadIdx.x] = h1[threadIdx.x];
+    else if (threadIdx.x < 4)
+        tail[threadIdx.x] = h2[threadIdx.x - 2];
+}
+
 static thread_local std::string g_create_err;
 
 extern "C" {
@@ -393,11 +402,22 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
     }
     uint32_t *idxDev = out_idx;
     double *costDev = out_cost;
-    if (!outDev) {
-        rc = ensure(ctx, ctx->out_idx, sizeof(uint32_t) * (size_t)M * k_top);
+    // refcos with host outputs: values, indices and four header words of the search's lists in ONE device block, so that
+    // one copy brings back everything the call synchronises for (a search of 0.23 ms notices four)
+    const size_t costBytes = sizeof(double) * (size_t)M * k_top, idxBytes = sizeof(uint32_t) * (size_t)M * k_top;
+    uint32_t *hdrTail = nullptr;
+    if (!outDev && ctx->metric == SSYM_METRIC_REFCOS) {
+        rc = ensure(ctx, ctx->out_cost, costBytes + idxBytes + 4 * sizeof(uint32_t));
         if (rc != SSYM_OK)
             return rc;
-        rc = ensure(ctx, ctx->out_cost, sizeof(double) * (size_t)M * k_top);
+        costDev = (double *)ctx->out_cost.ptr;
+        idxDev = (uint32_t *)((char *)ctx->out_cost.ptr + costBytes);
+        hdrTail = idxDev + (size_t)M * k_top;
+    } else if (!outDev) {
+        rc = ensure(ctx, ctx->out_idx, idxBytes);
+        if (rc != SSYM_OK)
+            return rc;
+        rc = ensure(ctx, ctx->out_cost, costBytes);
         if (rc != SSYM_OK)
             return rc;
         idxDev = (uint32_t *)ctx->out_idx.ptr;
@@ -437,20 +457,36 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
                 ctx->timings = tm;
                 return SSYM_OK;                  // (device outputs: the sharded step's send block)
             }
-            SSYM_HIP_CHECK(ctx, hipMemcpyAsync(h1, h1dev, sizeof(h1), hipMemcpyDeviceToHost, st));
-            SSYM_HIP_CHECK(ctx, hipMemcpyAsync(h2, h2dev, sizeof(h2), hipMemcpyDeviceToHost, st));
-            // host outputs: their copies ride on the same synchronisation as the headers (a search of 0.26 ms does not
-            // want two); should the list have overflowed they are dropped and the exact kernel's results staged instead
+            // host outputs: results and headers come back in one copy and under one synchronisation; should the list have
+            // overflowed the results are dropped and the exact kernel's staged instead
             const size_t pendingBefore = ctx->pending_d2h.size();
-            if (!outDev) {
-                rc = stage_d2h(ctx, out_idx, idxDev, sizeof(uint32_t) * (size_t)M * k_top);
-                if (rc == SSYM_OK && out_cost)
-                    rc = stage_d2h(ctx, out_cost, costDev, sizeof(double) * (size_t)M * k_top);
-                if (rc != SSYM_OK)
-                    return rc;
+            char *packed = (!outDev && hdrTail) ? stage_take(ctx, costBytes + idxBytes + 4 * sizeof(uint32_t)) : nullptr;
+            if (packed) {
+                pack_headers_kernel<<<1, 64, 0, st>>>(h1dev, h2dev, hdrTail);
+                SSYM_HIP_CHECK(ctx, hipGetLastError());
+                SSYM_HIP_CHECK(ctx, hipMemcpyAsync(packed, costDev, costBytes + idxBytes + 4 * sizeof(uint32_t),
+                                                   hipMemcpyDeviceToHost, st));
+                if (out_cost)
+                    ctx->pending_d2h.push_back({out_cost, packed, costBytes});
+                ctx->pending_d2h.push_back({out_idx, packed + costBytes, idxBytes});
                 outputsStaged = true;
+            } else {
+                SSYM_HIP_CHECK(ctx, hipMemcpyAsync(h1, h1dev, sizeof(h1), hipMemcpyDeviceToHost, st));
+                SSYM_HIP_CHECK(ctx, hipMemcpyAsync(h2, h2dev, sizeof(h2), hipMemcpyDeviceToHost, st));
+                if (!outDev) {
+                    rc = stage_d2h(ctx, out_idx, idxDev, idxBytes);
+                    if (rc == SSYM_OK && out_cost)
+                        rc = stage_d2h(ctx, out_cost, costDev, costBytes);
+                    if (rc != SSYM_OK)
+                        return rc;
+                    outputsStaged = true;
+                }
             }
             SSYM_HIP_CHECK(ctx, hipStreamSynchronize(st));
+            if (packed) {
+                const uint32_t *t = (const uint32_t *)(packed + costBytes + idxBytes);
+                h1[0] = t[0]; h1[1] = t[1]; h2[0] = t[2]; h2[1] = t[3];
+            }
             if (h1[1]) {
                 viaMfma = false;             // more near-ties than the list holds: the exact kernel on every pair
                 tm.refcos_filter = 0;
