@@ -438,14 +438,18 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
         // 3.1 / 6.9 ms against 4.5 / 4.6 / 4.8 / 5.3 ms on the exact tile kernel (tools/refcos_topk_timing.py).
         bool viaMfma = !(ctx->stream_only && (ctx->so_cap || k_top > 1)) && k_top <= 8 && refcos_mfma_supported(ctx, src, tgt);
         ctx->so_refcos = false;
-        if (viaMfma) {
+        // Which filter: the integer one where both sets have its records; should ITS list overflow -- values so close that
+        // 23 bits of fixed point cannot tell them apart -- the f64 filter gets the search before the exact tile kernel does
+        // (a sharded step repeats with the tile kernel at once: one agreed repeat per step).
+        bool q8 = viaMfma && refcos_q8_ready(ctx, src, tgt);
+        while (viaMfma) {
             const uint32_t *h1dev = nullptr, *h2dev = nullptr;
             uint32_t h1[2] = {0, 0}, h2[2] = {0, 0};
             SSYM_HIP_CHECK(ctx, hipEventRecord(ev[0], st));
-            rc = launch_refcos_match_mfma(ctx, src, tgt, distDev, index_base, idxDev, costDev, &h1dev, &h2dev, k_top);
+            rc = launch_refcos_match_mfma(ctx, src, tgt, distDev, index_base, idxDev, costDev, &h1dev, &h2dev, k_top, q8);
             if (rc != SSYM_OK)
                 return rc;
-            tm.refcos_filter = (src.q8_state == 1 && tgt.q8_state == 1 && refcos_q8_ready(ctx, src, tgt)) ? 2 : 1;
+            tm.refcos_filter = q8 ? 2 : 1;
             SSYM_HIP_CHECK(ctx, hipEventRecord(ev[2], st));
             if (ctx->stream_only) {              // ssym_match_sharded reads the headers after the step's one synchronisation
                 ctx->so_hdr1 = h1dev;
@@ -487,16 +491,20 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
                 const uint32_t *t = (const uint32_t *)(packed + costBytes + idxBytes);
                 h1[0] = t[0]; h1[1] = t[1]; h2[0] = t[2]; h2[1] = t[3];
             }
-            if (h1[1]) {
-                viaMfma = false;             // more near-ties than the list holds: the exact kernel on every pair
-                tm.refcos_filter = 0;
+            if (h1[1]) {                     // more near-ties than the list holds
                 ctx->pending_d2h.resize(pendingBefore);
                 outputsStaged = false;
-            }
-            else {
+                if (q8) {
+                    q8 = false;              // ... for the integer filter: the f64 filter next
+                    continue;
+                }
+                viaMfma = false;             // ... for the f64 filter too: the exact kernel on every pair
+                tm.refcos_filter = 0;
+            } else {
                 tm.used_filter = 1;
                 tm.n_refined = h2[0];
             }
+            break;
         }
         if (!viaMfma) {
         rc = ensure(ctx, ctx->cmat, sizeof(double) * (size_t)N * M);

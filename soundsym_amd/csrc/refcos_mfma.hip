@@ -686,7 +686,7 @@ size_t refcos_list_capacity(uint32_t n_src, uint32_t n_tgt)
 // overflow}) so that the caller can look at it after its synchronisation and fall back to the exact tile kernel.
 int32_t launch_refcos_match_mfma(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, const double *dist_dev,
                                  uint32_t index_base, uint32_t *out_idx_dev, double *out_cost_dev,
-                                 const uint32_t **list1_hdr, const uint32_t **list2_hdr, uint32_t k_top)
+                                 const uint32_t **list1_hdr, const uint32_t **list2_hdr, uint32_t k_top, bool integer_filter)
 {
     const uint32_t N = src.n, M = tgt.n;
     hipStream_t st = ctx->stream;
@@ -718,7 +718,7 @@ int32_t launch_refcos_match_mfma(ssym_ctx *ctx, const SegmentSet &src, const Seg
     dim3 grid((M + kNT - 1) / kNT, (N + kMT - 1) / kMT);
     // the integer filter (refcos_q8.hip) where both sets have its records, the f64 matrix pipe otherwise: both leave
     // thresholds and list 1 in the same form
-    if (refcos_q8_ready(ctx, src, tgt)) {
+    if (integer_filter) {                // (the caller has asked refcos_q8_ready)
         rc = launch_refcos_q8_kernel(ctx, src, tgt, dist_dev, thr, hdr1, list1, (uint32_t)cap, k_top, nullptr);
         if (rc != SSYM_OK)
             return rc;

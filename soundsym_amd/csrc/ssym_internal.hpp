@@ -371,7 +371,7 @@ int32_t launch_refcos_q8_kernel(ssym_ctx *ctx, const SegmentSet &src, const Segm
                                 double *sims);
 int32_t launch_refcos_match_mfma(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, const double *dist_dev,
                                  uint32_t index_base, uint32_t *out_idx_dev, double *out_cost_dev,
-                                 const uint32_t **list1_hdr, const uint32_t **list2_hdr, uint32_t k_top = 1);
+                                 const uint32_t **list1_hdr, const uint32_t **list2_hdr, uint32_t k_top = 1, bool integer_filter = false);
 int32_t launch_refcos_mfma_sims(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, double *sims,
                                 bool integer_filter = false);
 char *stage_take(ssym_ctx *ctx, size_t bytes);      // pack.hip: room in the call's pinned window (NULL: none)

@@ -332,7 +332,28 @@ def test_refcos_mfma_overflowing_list_falls_back_to_the_exact_kernel(oracle):
     tf, to = pack_segments(tgt, dim)
     e = Engine(metric="refcos", dtype="f64")
     idx, val = e.match(e.dictionary(sf, so, dim), e.queries(tf, to, dim))
-    assert e.timings()["used_filter"] == 0
+    assert e.timings()["used_filter"] == 0 and e.timings()["refcos_filter"] == 0      # (both filters' lists overflowed)
+    want_idx, want_val = oracle.refcos_match_all(sf, so, tf, to, dim)
+    assert np.array_equal(idx, want_idx) and np.array_equal(val, want_val)
+    e.close()
+
+
+def test_refcos_integer_filter_overflowing_hands_the_search_to_the_f64_filter(oracle):
+    """Sources that differ from one another by 1e-9 of their size: 23 bits of fixed point cannot tell them apart -- the
+    integer filter lists every pair and its list overflows --, f64 can: the f64 filter takes the search (not the exact
+    tile kernel on every pair), and the result is the oracle's."""
+    dim, f, n, m = 12, 6, 2200, 600
+    rng = np.random.default_rng(31)
+    one = rng.standard_normal((f, dim)) * 0.1
+    src = [one * (1.0 + 1e-9 * rng.standard_normal((f, dim))) for _ in range(n)]
+    tgt = [rng.standard_normal((f, dim)) * 0.1 for _ in range(m)]
+    tgt[5] = src[1234].copy()
+    sf, so = pack_segments(src, dim)
+    tf, to = pack_segments(tgt, dim)
+    e = Engine(metric="refcos", dtype="f64")
+    idx, val = e.match(e.dictionary(sf, so, dim), e.queries(tf, to, dim))
+    tm = e.timings()
+    assert tm["used_filter"] == 1 and tm["refcos_filter"] == 1, tm
     want_idx, want_val = oracle.refcos_match_all(sf, so, tf, to, dim)
     assert np.array_equal(idx, want_idx) and np.array_equal(val, want_val)
     e.close()
