@@ -130,6 +130,13 @@ __global__ __launch_bounds__(256) void refcos_q8_records_kernel(const double *__
     }
 }
 
+// x * 2^w as a double without a conversion instruction: the bits {hi, x ^ 0x80000000} are 2^(52+w) + (x + 2^31) 2^w
+__device__ __forceinline__ double q8_scaled(int x, unsigned hi, double bias)
+{
+    const unsigned long long bits = ((unsigned long long)hi << 32) | (unsigned)(x ^ 0x80000000);
+    return __longlong_as_double((long long)bits) - bias;
+}
+
 struct QInfo {                       // per segment of a tile, in LDS
     double sq, inv, norm, dist;      // as RowInfo
     double a1, a2, a3, a4;           // error mass, 2^-E ia, length term (all times ia), the reference-rounding term's factor
@@ -425,8 +432,10 @@ __global__ __launch_bounds__(256, 1) void refcos_q8_kernel(
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
                     // the kept part of the integer dot, exactly: a multiple of 2^16 below 2^60
-                    const double gk = __fma_rn(0x1p32, (double)acc[0][a][b][g],
-                                               __fma_rn(0x1p24, (double)acc[1][a][b][g], 0x1p16 * (double)acc[2][a][b][g]));
+                    // (through the exponent trick, not v_cvt_f64_i32: three conversions per pair were 2.5 % of the kernel)
+                    const double gk = q8_scaled(acc[0][a][b][g], 0x45300000u, 0x1p84 + 0x1p63) +
+                                      (q8_scaled(acc[1][a][b][g], 0x44b00000u, 0x1p76 + 0x1p55) +
+                                       q8_scaled(acc[2][a][b][g], 0x44300000u, 0x1p68 + 0x1p47));
                     const double z = fabs(gk * (ra2 * ci[b].a2) - ci[b].dist);
                     klo[b][a][g] = z;                      // (becomes key_lo once the thresholds are known)
                     zmin[b] = fmin(zmin[b], z);
