@@ -101,7 +101,10 @@ typedef struct ssym_config {
 } ssym_config;
 
 /* Per-phase device time of the LAST ssym_match_* call on the context, measured with HIP events
- * recorded on the context's stream (milliseconds; 0 when a phase did not run). */
+ * recorded on the context's stream (milliseconds; 0 when a phase did not run).  One exception: a refcos search
+ * through a filter (refcos_filter 1 or 2) outside ssym_match_sharded is timed by the device's wall clock, read by
+ * its first kernel, the first kernel after the main one and its last kernel -- an event record between two kernels
+ * costs several microseconds of gap on the stream, which a search of 0.2 ms notices. */
 typedef struct ssym_timings {
     float pack_ms;      /* target packing (only when the call packed targets itself)             */
     float main_ms;      /* dtw: MFMA filter kernel / refcos: similarity tile kernel              */

@@ -8,14 +8,24 @@
 
 using namespace ssym;
 
-// four header words of the refcos search's two lists next to its results (one copy back instead of three)
-__global__ void pack_headers_kernel(const uint32_t *__restrict__ h1, const uint32_t *__restrict__ h2, uint32_t *__restrict__ tail)
+// Behind the refcos search's results: four header words of its two lists and three device timestamps (start, main kernel
+// done, now) -- one copy back instead of three, and no event between the search's kernels (an event record costs ~7 us
+// of gap on the stream; a search is 0.2 ms).  tail: [h1 x 2][h2 x 2][stamp x 3 (8-byte aligned)].
+__global__ void pack_headers_kernel(const uint32_t *__restrict__ h1, const uint32_t *__restrict__ h2, uint32_t *__restrict__ tail,
+                                    unsigned long long *__restrict__ stamps)
 {
     if (threadIdx.x < 2)
         tail[threadIdx.x] = h1[threadIdx.x];
     else if (threadIdx.x < 4)
         tail[threadIdx.x] = h2[threadIdx.x - 2];
+    else if (threadIdx.x == 4 && stamps) {
+        unsigned long long *out = reinterpret_cast<unsigned long long *>(tail + 4);
+        out[0] = stamps[0];
+        out[1] = stamps[1];
+        out[2] = (unsigned long long)wall_clock64();
+    }
 }
+constexpr size_t kTailBytes = 4 * sizeof(uint32_t) + 3 * sizeof(unsigned long long);
 
 static thread_local std::string g_create_err;
 
@@ -79,6 +89,11 @@ int32_t ssym_ctx_create(const ssym_config *cfg, ssym_ctx **out)
     ctx->squared = cfg->dtw_squared ? 1 : 0;
     ctx->prune_default = cfg->dtw_prune != 0;
     ctx->num_cus = prop.multiProcessorCount;
+    {
+        int khz = 0;
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device) == hipSuccess && khz > 0)
+            ctx->wall_clock_khz = (double)khz;
+    }
     if (cfg->stream) {
         ctx->stream = (hipStream_t)cfg->stream;
     } else {
@@ -111,7 +126,7 @@ int32_t ssym_ctx_destroy(ssym_ctx *ctx)
     DeviceBuf *bufs[] = {&ctx->handoff, &ctx->cmat, &ctx->tmin, &ctx->cand, &ctx->cand2, &ctx->cand_xmin,
                          &ctx->cand_cost, &ctx->best, &ctx->selmask, &ctx->selcnt, &ctx->topk,
                          &ctx->abandon, &ctx->prune_pairs, &ctx->prune_cost, &ctx->one_ticket, &ctx->dist, &ctx->part, &ctx->out_idx, &ctx->out_cost,
-                         &ctx->pipe_flag, &ctx->tmin2, &ctx->zeros};
+                         &ctx->pipe_flag, &ctx->tmin2, &ctx->zeros, &ctx->stamps};
     for (DeviceBuf *b : bufs)
         if (b->ptr)
             (void)hipFree(b->ptr);
@@ -404,15 +419,16 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
     double *costDev = out_cost;
     // refcos with host outputs: values, indices and four header words of the search's lists in ONE device block, so that
     // one copy brings back everything the call synchronises for (a search of 0.23 ms notices four)
-    const size_t costBytes = sizeof(double) * (size_t)M * k_top, idxBytes = sizeof(uint32_t) * (size_t)M * k_top;
+    const size_t costBytes = sizeof(double) * (size_t)M * k_top;
+    const size_t idxBytes = (sizeof(uint32_t) * (size_t)M * k_top + 7) & ~(size_t)7;      // (the tail's stamps: 8-byte aligned)
     uint32_t *hdrTail = nullptr;
     if (!outDev && ctx->metric == SSYM_METRIC_REFCOS) {
-        rc = ensure(ctx, ctx->out_cost, costBytes + idxBytes + 4 * sizeof(uint32_t));
+        rc = ensure(ctx, ctx->out_cost, costBytes + idxBytes + kTailBytes);
         if (rc != SSYM_OK)
             return rc;
         costDev = (double *)ctx->out_cost.ptr;
         idxDev = (uint32_t *)((char *)ctx->out_cost.ptr + costBytes);
-        hdrTail = idxDev + (size_t)M * k_top;
+        hdrTail = (uint32_t *)((char *)idxDev + idxBytes);
     } else if (!outDev) {
         rc = ensure(ctx, ctx->out_idx, idxBytes);
         if (rc != SSYM_OK)
@@ -426,6 +442,8 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
 
     hipEvent_t *ev = ctx->ev;
     bool outputsStaged = false;          // host outputs already copied and synchronised (refcos filter path)
+    bool stampsValid = false;            // refcos filter path: phase times from device timestamps instead of events
+    float stampMs[2] = {0.f, 0.f};
     if (ctx->metric == SSYM_METRIC_REFCOS) {
         // The plain first-minimum search goes through the f64 matrix pipe (refcos_mfma.hip): every pair's dot as a
         // GEMM, a rigorous interval per key, and the reference's own arithmetic only on the few pairs that can
@@ -442,15 +460,28 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
         // 23 bits of fixed point cannot tell them apart -- the f64 filter gets the search before the exact tile kernel does
         // (a sharded step repeats with the tile kernel at once: one agreed repeat per step).
         bool q8 = viaMfma && refcos_q8_ready(ctx, src, tgt);
+        // Timing without events: an event record between two kernels costs ~7 us of gap on the stream, three of them a
+        // tenth of a search of 0.2 ms; the search's first kernel, the first one after the main kernel and the last one
+        // read the device's wall clock instead (a sharded step keeps the events: comm.hip reads them).
+        const bool useStamps = !ctx->stream_only && ctx->wall_clock_khz > 0;
+        unsigned long long *stampsDev = nullptr;
+        if (viaMfma && useStamps) {
+            rc = ensure(ctx, ctx->stamps, 128);
+            if (rc != SSYM_OK)
+                return rc;
+            stampsDev = (unsigned long long *)ctx->stamps.ptr;
+        }
         while (viaMfma) {
             const uint32_t *h1dev = nullptr, *h2dev = nullptr;
             uint32_t h1[2] = {0, 0}, h2[2] = {0, 0};
-            SSYM_HIP_CHECK(ctx, hipEventRecord(ev[0], st));
-            rc = launch_refcos_match_mfma(ctx, src, tgt, distDev, index_base, idxDev, costDev, &h1dev, &h2dev, k_top, q8);
+            if (!stampsDev)
+                SSYM_HIP_CHECK(ctx, hipEventRecord(ev[0], st));
+            rc = launch_refcos_match_mfma(ctx, src, tgt, distDev, index_base, idxDev, costDev, &h1dev, &h2dev, k_top, q8, stampsDev);
             if (rc != SSYM_OK)
                 return rc;
             tm.refcos_filter = q8 ? 2 : 1;
-            SSYM_HIP_CHECK(ctx, hipEventRecord(ev[2], st));
+            if (!stampsDev)
+                SSYM_HIP_CHECK(ctx, hipEventRecord(ev[2], st));
             if (ctx->stream_only) {              // ssym_match_sharded reads the headers after the step's one synchronisation
                 ctx->so_hdr1 = h1dev;
                 ctx->so_hdr2 = h2dev;
@@ -461,24 +492,40 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
                 ctx->timings = tm;
                 return SSYM_OK;                  // (device outputs: the sharded step's send block)
             }
-            // host outputs: results and headers come back in one copy and under one synchronisation; should the list have
-            // overflowed the results are dropped and the exact kernel's staged instead
+            // host outputs: results, headers and timestamps come back in one copy and under one synchronisation; should
+            // the list have overflowed the results are dropped and the exact kernel's staged instead
             const size_t pendingBefore = ctx->pending_d2h.size();
-            char *packed = (!outDev && hdrTail) ? stage_take(ctx, costBytes + idxBytes + 4 * sizeof(uint32_t)) : nullptr;
+            char *packed = (!outDev && hdrTail) ? stage_take(ctx, costBytes + idxBytes + kTailBytes) : nullptr;
+            unsigned long long tailHost[(kTailBytes + 7) / 8] = {0};
+            const unsigned char *tailAt = nullptr;
             if (packed) {
-                pack_headers_kernel<<<1, 64, 0, st>>>(h1dev, h2dev, hdrTail);
+                pack_headers_kernel<<<1, 64, 0, st>>>(h1dev, h2dev, hdrTail, stampsDev);
                 SSYM_HIP_CHECK(ctx, hipGetLastError());
-                SSYM_HIP_CHECK(ctx, hipMemcpyAsync(packed, costDev, costBytes + idxBytes + 4 * sizeof(uint32_t),
-                                                   hipMemcpyDeviceToHost, st));
+                SSYM_HIP_CHECK(ctx, hipMemcpyAsync(packed, costDev, costBytes + idxBytes + kTailBytes, hipMemcpyDeviceToHost, st));
                 if (out_cost)
                     ctx->pending_d2h.push_back({out_cost, packed, costBytes});
-                ctx->pending_d2h.push_back({out_idx, packed + costBytes, idxBytes});
+                ctx->pending_d2h.push_back({out_idx, packed + costBytes, sizeof(uint32_t) * (size_t)M * k_top});
                 outputsStaged = true;
+                tailAt = (const unsigned char *)packed + costBytes + idxBytes;
+            } else if (stampsDev) {              // device outputs (or no staging window): the tail alone comes back
+                uint32_t *tailDev = (uint32_t *)(stampsDev + 4);
+                pack_headers_kernel<<<1, 64, 0, st>>>(h1dev, h2dev, tailDev, stampsDev);
+                SSYM_HIP_CHECK(ctx, hipGetLastError());
+                SSYM_HIP_CHECK(ctx, hipMemcpyAsync(tailHost, tailDev, kTailBytes, hipMemcpyDeviceToHost, st));
+                tailAt = (const unsigned char *)tailHost;
+                if (!outDev) {
+                    rc = stage_d2h(ctx, out_idx, idxDev, sizeof(uint32_t) * (size_t)M * k_top);
+                    if (rc == SSYM_OK && out_cost)
+                        rc = stage_d2h(ctx, out_cost, costDev, costBytes);
+                    if (rc != SSYM_OK)
+                        return rc;
+                    outputsStaged = true;
+                }
             } else {
                 SSYM_HIP_CHECK(ctx, hipMemcpyAsync(h1, h1dev, sizeof(h1), hipMemcpyDeviceToHost, st));
                 SSYM_HIP_CHECK(ctx, hipMemcpyAsync(h2, h2dev, sizeof(h2), hipMemcpyDeviceToHost, st));
                 if (!outDev) {
-                    rc = stage_d2h(ctx, out_idx, idxDev, idxBytes);
+                    rc = stage_d2h(ctx, out_idx, idxDev, sizeof(uint32_t) * (size_t)M * k_top);
                     if (rc == SSYM_OK && out_cost)
                         rc = stage_d2h(ctx, out_cost, costDev, costBytes);
                     if (rc != SSYM_OK)
@@ -487,9 +534,16 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
                 }
             }
             SSYM_HIP_CHECK(ctx, hipStreamSynchronize(st));
-            if (packed) {
-                const uint32_t *t = (const uint32_t *)(packed + costBytes + idxBytes);
+            if (tailAt) {
+                const uint32_t *t = (const uint32_t *)tailAt;
                 h1[0] = t[0]; h1[1] = t[1]; h2[0] = t[2]; h2[1] = t[3];
+                if (stampsDev) {
+                    unsigned long long ts[3];
+                    memcpy(ts, tailAt + 4 * sizeof(uint32_t), sizeof(ts));
+                    stampMs[0] = (float)((double)(ts[1] - ts[0]) / ctx->wall_clock_khz);       // main kernel (+ its init)
+                    stampMs[1] = (float)((double)(ts[2] - ts[1]) / ctx->wall_clock_khz);       // selection, exact keys, fold
+                    stampsValid = true;
+                }
             }
             if (h1[1]) {                     // more near-ties than the list holds
                 ctx->pending_d2h.resize(pendingBefore);
@@ -500,6 +554,7 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
                 }
                 viaMfma = false;             // ... for the f64 filter too: the exact kernel on every pair
                 tm.refcos_filter = 0;
+                stampsValid = false;
             } else {
                 tm.used_filter = 1;
                 tm.n_refined = h2[0];
@@ -749,7 +804,11 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
     if ((!outDev || ctx->metric == SSYM_METRIC_REFCOS) && !outputsStaged)      // (staged: already synchronised above)
         SSYM_HIP_CHECK(ctx, hipStreamSynchronize(st));
     stage_finish(ctx);
-    if (ctx->metric == SSYM_METRIC_REFCOS) {
+    if (ctx->metric == SSYM_METRIC_REFCOS && stampsValid) {
+        tm.main_ms = stampMs[0];
+        tm.reduce_ms = stampMs[1];
+        tm.total_ms = stampMs[0] + stampMs[1];
+    } else if (ctx->metric == SSYM_METRIC_REFCOS) {
         tm.main_ms = ev_ms(ev[0], ev[1]);
         tm.reduce_ms = ev_ms(ev[1], ev[2]);
         tm.total_ms = ev_ms(ev[0], ev[2]);

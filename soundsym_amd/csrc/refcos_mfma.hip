@@ -509,10 +509,12 @@ __global__ __launch_bounds__(256, 2) void refcos_mfma_kernel(
 // list 1 against the final thresholds -> list 2 (pairs only)
 __global__ void refcos_keep_kernel(const uint32_t *__restrict__ hdr1, const PairEntry *__restrict__ list1, uint32_t cap,
                                    const unsigned long long *__restrict__ thr, uint32_t *__restrict__ hdr2,
-                                   uint2 *__restrict__ pairs)
+                                   uint2 *__restrict__ pairs, unsigned long long *stamps)
 {
     const uint32_t n = min(hdr1[0], cap);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && stamps)
+        stamps[1] = (unsigned long long)wall_clock64();    // the main kernel is done
     bool keep = false;
     PairEntry e{};
     if (i < n) {
@@ -627,9 +629,11 @@ __global__ void refcos_fold_out_kernel(const unsigned long long *__restrict__ be
 }
 
 __global__ void refcos_init_kernel(unsigned long long *thr, unsigned long long *bestKey, uint32_t *bestIdx, uint32_t nTgt,
-                                   uint32_t *hdr1, uint32_t *hdr2)
+                                   uint32_t *hdr1, uint32_t *hdr2, unsigned long long *stamps)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0 && stamps)
+        stamps[0] = (unsigned long long)wall_clock64();    // the search starts (device clock: no event between the kernels)
     if (t < nTgt) {
         thr[t] = kInfBitsU;
         bestKey[t] = 0x4000000000000000ull;              // 2.0: only smaller keys enter
@@ -686,7 +690,8 @@ size_t refcos_list_capacity(uint32_t n_src, uint32_t n_tgt)
 // overflow}) so that the caller can look at it after its synchronisation and fall back to the exact tile kernel.
 int32_t launch_refcos_match_mfma(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, const double *dist_dev,
                                  uint32_t index_base, uint32_t *out_idx_dev, double *out_cost_dev,
-                                 const uint32_t **list1_hdr, const uint32_t **list2_hdr, uint32_t k_top, bool integer_filter)
+                                 const uint32_t **list1_hdr, const uint32_t **list2_hdr, uint32_t k_top, bool integer_filter,
+                                 unsigned long long *stamps)
 {
     const uint32_t N = src.n, M = tgt.n;
     hipStream_t st = ctx->stream;
@@ -714,7 +719,7 @@ int32_t launch_refcos_match_mfma(ssym_ctx *ctx, const SegmentSet &src, const Seg
     uint32_t *bestIdx = (uint32_t *)(bestKey + M);
     double *keys = (double *)ctx->cand_cost.ptr;
 
-    refcos_init_kernel<<<(M + 255) / 256, 256, 0, st>>>(thr, bestKey, bestIdx, M, hdr1, hdr2);
+    refcos_init_kernel<<<(M + 255) / 256, 256, 0, st>>>(thr, bestKey, bestIdx, M, hdr1, hdr2, stamps);
     dim3 grid((M + kNT - 1) / kNT, (N + kMT - 1) / kMT);
     // the integer filter (refcos_q8.hip) where both sets have its records, the f64 matrix pipe otherwise: both leave
     // thresholds and list 1 in the same form
@@ -733,9 +738,10 @@ int32_t launch_refcos_match_mfma(ssym_ctx *ctx, const SegmentSet &src, const Seg
                                                  (unsigned long long)tgt.total_frames * tgt.dim, dist_dev, 1.0, thr, hdr1,
                                                  list1, (uint32_t)cap, nullptr, 1, zeros);
     SSYM_HIP_CHECK(ctx, hipGetLastError());
-    SSYM_HIP_CHECK(ctx, hipEventRecord(ctx->ev[1], st));          // main kernel | selection, exact keys, fold
+    if (!stamps)                         // (with device timestamps no event sits between the kernels: each costs ~7 us of gap)
+        SSYM_HIP_CHECK(ctx, hipEventRecord(ctx->ev[1], st));      // main kernel | selection, exact keys, fold
     const unsigned keepBlocks = (unsigned)std::min<size_t>((cap + 255) / 256, 65535u * 16u);
-    refcos_keep_kernel<<<keepBlocks, 256, 0, st>>>(hdr1, list1, (uint32_t)cap, thr, hdr2, pairs);
+    refcos_keep_kernel<<<keepBlocks, 256, 0, st>>>(hdr1, list1, (uint32_t)cap, thr, hdr2, pairs, stamps);
     refcos_pairs_kernel<<<std::min<unsigned>((unsigned)((cap + 31) / 32), (unsigned)ctx->num_cus * 16), 256, 0, st>>>(
         src.raw, src.off, src.norm, tgt.raw, tgt.off, tgt.norm, src.dim, dist_dev, 1.0, hdr2, pairs, keys,
         k_top > 1 ? nullptr : bestKey);
@@ -778,7 +784,7 @@ int32_t launch_refcos_mfma_sims(ssym_ctx *ctx, const SegmentSet &src, const Segm
     uint32_t *hdr1 = (uint32_t *)ctx->cand.ptr;
     unsigned long long *bestKey = (unsigned long long *)ctx->best.ptr;
     refcos_init_kernel<<<(M + 255) / 256, 256, 0, st>>>((unsigned long long *)ctx->tmin.ptr, bestKey, (uint32_t *)(bestKey + M), M,
-                                                       hdr1, (uint32_t *)ctx->cand2.ptr);
+                                                       hdr1, (uint32_t *)ctx->cand2.ptr, nullptr);
     if (integer_filter)              // exact = 3: what refcos_q8.hip's integer dots give (the caller has checked refcos_q8_ready)
         return launch_refcos_q8_kernel(ctx, src, tgt, nullptr, (unsigned long long *)ctx->tmin.ptr, hdr1, hdr1 + 4, (uint32_t)cap,
                                        1, sims);

@@ -138,6 +138,8 @@ struct ssym_ctx {
     ssym::DeviceBuf one_ticket; // refcos_match_one_kernel: the "last workgroup" counter (zero between calls)
     ssym::DeviceBuf out_idx, out_cost;  // staging for host outputs
     ssym::DeviceBuf zeros;      // 256 bytes of 0.0: what refcos_mfma_kernel's staging DMA reads beyond a segment's end
+    ssym::DeviceBuf stamps;     // refcos search: three device timestamps (start, main kernel done, all done) + header words
+    double wall_clock_khz = 0;  // rate of wall_clock64() on this device (hipDeviceAttributeWallClockRate)
     // dtw_exact_pipe_kernel: 8 give-up counters, one per launch (round robin); pipe_mask = the slots this API
     // call used, read back with the call's results into ssym_timings.exact_redone
     ssym::DeviceBuf pipe_flag;
@@ -371,7 +373,8 @@ int32_t launch_refcos_q8_kernel(ssym_ctx *ctx, const SegmentSet &src, const Segm
                                 double *sims);
 int32_t launch_refcos_match_mfma(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, const double *dist_dev,
                                  uint32_t index_base, uint32_t *out_idx_dev, double *out_cost_dev,
-                                 const uint32_t **list1_hdr, const uint32_t **list2_hdr, uint32_t k_top = 1, bool integer_filter = false);
+                                 const uint32_t **list1_hdr, const uint32_t **list2_hdr, uint32_t k_top = 1, bool integer_filter = false,
+                                 unsigned long long *stamps = nullptr);
 int32_t launch_refcos_mfma_sims(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, double *sims,
                                 bool integer_filter = false);
 char *stage_take(ssym_ctx *ctx, size_t bytes);      // pack.hip: room in the call's pinned window (NULL: none)
