@@ -338,6 +338,42 @@ def test_refcos_mfma_overflowing_list_falls_back_to_the_exact_kernel(oracle):
     e.close()
 
 
+def test_refcos_integer_filter_at_its_longest_segments(oracle):
+    """Segments of 32768 values -- the length up to which three digit products per value sum exactly in 32 bits, 1024
+    chunks through the kernel's ring --, values at full amplitude with alternating signs (digits near their bounds):
+    the integer filter takes the search and the result is the oracle's; one value more per segment and the sets go to
+    the f64 filter."""
+    n = m = 256
+    dim, f = 128, 256
+    rng = np.random.default_rng(77)
+    def seg():
+        x = rng.uniform(0.97, 1.0, (f, dim)) * rng.choice([-1.0, 1.0], (f, dim))
+        return x * 3.7
+    src = [seg() for _ in range(n)]
+    tgt = [seg() for _ in range(m)]
+    tgt[3] = src[200].copy()
+    tgt[9] = -src[17]
+    sf, so = pack_segments(src, dim)
+    tf, to = pack_segments(tgt, dim)
+    e = Engine(metric="refcos", dtype="f64")
+    d, q = e.dictionary(sf, so, dim), e.queries(tf, to, dim)
+    idx, val = e.match(d, q)
+    assert e.timings()["refcos_filter"] == 2, e.timings()
+    want_idx, want_val = oracle.refcos_match_all(sf, so, tf, to, dim)
+    assert np.array_equal(idx, want_idx) and np.array_equal(val, want_val)
+    assert idx[3] == 200
+    d.close(); q.close()
+    src[5] = np.concatenate([src[5], np.ones((1, dim))])            # 32896 values: beyond the records
+    sf, so = pack_segments(src, dim)
+    d = e.dictionary(sf, so, dim)
+    q = e.queries(tf, to, dim)
+    idx, val = e.match(d, q)
+    assert e.timings()["refcos_filter"] == 1, e.timings()
+    want_idx, want_val = oracle.refcos_match_all(sf, so, tf, to, dim)
+    assert np.array_equal(idx, want_idx) and np.array_equal(val, want_val)
+    e.close()
+
+
 def test_refcos_integer_filter_overflowing_hands_the_search_to_the_f64_filter(oracle):
     """Sources that differ from one another by 1e-9 of their size: 23 bits of fixed point cannot tell them apart -- the
     integer filter lists every pair and its list overflows --, f64 can: the f64 filter takes the search (not the exact
