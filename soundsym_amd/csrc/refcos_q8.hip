@@ -151,8 +151,8 @@ struct QInfo {                       // per segment of a tile, in LDS
 // XOR-swizzled as in refcos_mfma.hip (piece q of row r sits at position q ^ ((r >> 1) & 7): the operand reads of 32 rows
 // at one piece are conflict-free), FOUR chunks in flight: every row is padded with zeros to the sets' common length, so
 // a DMA's address is a scalar base plus a constant per lane and nothing is selected.
-template <bool WRITE_SIMS, bool TOPK>
-__global__ __launch_bounds__(256, 1) void refcos_q8_kernel(
+template <bool WRITE_SIMS, bool TOPK, int CB>
+__global__ __launch_bounds__(CB == 2 ? 256 : 512, 1) void refcos_q8_kernel(
     const int8_t *__restrict__ srcQ, const double *__restrict__ srcQInfo, const uint64_t *__restrict__ srcOff,
     const double *__restrict__ srcNorm, const int8_t *__restrict__ tgtQ, const double *__restrict__ tgtQInfo,
     const uint64_t *__restrict__ tgtOff, const double *__restrict__ tgtNorm, uint32_t nSrc, uint32_t nTgt, uint32_t dim,
@@ -165,12 +165,16 @@ __global__ __launch_bounds__(256, 1) void refcos_q8_kernel(
     __shared__ QInfo sInfo[2 * kQT];
     __shared__ unsigned sLen[2 * kQT];
     __shared__ unsigned sMaxLen[2];
-    __shared__ unsigned sPlain[4];
+    __shared__ unsigned sPlain[6];                         // rows 0..63, 64..127; columns in four groups of 32: all plain?
     __shared__ unsigned long long sRowMax[2][4];           // per half of the tile's rows: max of a1..a4 (bits: they are >= 0)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    // CB = 2: four waves of 64 x 64 (one per SIMD).  CB = 1: EIGHT waves of 64 x 32, two per SIMD -- half the accumulators
+    // per wave (96 registers), so that a second wave runs on every SIMD while the first one waits (LDS, barrier, the
+    // epilogue's memory round trips), at 1.5 x the operand reads per MFMA.
+    constexpr int kWN = CB == 2 ? 2 : 4, kNT = 64 * 2 * kWN, kSweep = kNT / 8, kP = kQT / kSweep;
+    const int wm = wave / kWN, wn = wave % kWN;
     // (XCD-aware tile order: refcos_mfma.hip)
     uint32_t bx = blockIdx.x, by = blockIdx.y;
     {
@@ -188,10 +192,10 @@ __global__ __launch_bounds__(256, 1) void refcos_q8_kernel(
     // staging: thread -> (row = tid / 8 + 32 p, position tid & 7) for p = 0..3 on both sides; the piece it fetches is
     // position ^ swizzle(row).  Per-lane byte offsets are constants, the chunk's base is scalar.
     const int sr = tid >> 3;
-    unsigned offA[4], offB[4];
+    unsigned offA[kP], offB[kP];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int row = sr + 32 * p;
+    for (int p = 0; p < kP; ++p) {
+        const int row = sr + kSweep * p;
         const unsigned piece = (unsigned)((tid & 7) ^ ((row >> 1) & 7));
         offA[p] = (unsigned)row * srcGroups * 128u + piece * 16u;
         offB[p] = (unsigned)row * tgtGroups * 128u + piece * 16u;
@@ -211,12 +215,12 @@ __global__ __launch_bounds__(256, 1) void refcos_q8_kernel(
         const unsigned char *ua = tileA + (size_t)c * 128, *ub = tileB + (size_t)c * 128;
         asm volatile("" : "+s"(ua), "+s"(ub));            // (scalar base + 32-bit lane offset: refcos_mfma.hip)
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < kP; ++p) {
             asm volatile("" : "+v"(offA[p]), "+v"(offB[p]));
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ua + offA[p]),
-                                             (__attribute__((address_space(3))) void *)&dA[(32 * p + 8 * wave) * 128], 16, 0, 0);
+                                             (__attribute__((address_space(3))) void *)&dA[(kSweep * p + 8 * wave) * 128], 16, 0, 0);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ub + offB[p]),
-                                             (__attribute__((address_space(3))) void *)&dB[(32 * p + 8 * wave) * 128], 16, 0, 0);
+                                             (__attribute__((address_space(3))) void *)&dB[(kSweep * p + 8 * wave) * 128], 16, 0, 0);
         }
     };
 
@@ -233,12 +237,12 @@ __global__ __launch_bounds__(256, 1) void refcos_q8_kernel(
     }
     if (tid < 2)
         sMaxLen[tid] = 0;
-    if (tid < 4)
+    if (tid < 6)
         sPlain[tid] = 1;
     if (tid < 8)
         sRowMax[tid >> 2][tid & 3] = 0;
     __syncthreads();
-    {
+    if (tid < 2 * kQT) {
         const bool isS = tid < kQT;
         const uint32_t g = isS ? sTile + tid : tTile + (tid - kQT);
         const uint32_t n = isS ? nSrc : nTgt;
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(256, 1) void refcos_q8_kernel(
         atomicMax(&sMaxLen[isS ? 0 : 1], len);
         const bool ok = g < n && r.norm >= 1e-139 && r.norm <= 1e139 && fabs(r.dist) <= 1e300;
         if (!ok)
-            atomicAnd(&sPlain[tid >> 6], 0u);
+            atomicAnd(&sPlain[isS ? tid >> 6 : 2 + ((tid - kQT) >> 5)], 0u);
         if (isS && ok) {                                   // (a half with a row that is not plain takes the general form)
             atomicMax(&sRowMax[tid >> 6][0], (unsigned long long)__double_as_longlong(r.a1));
             atomicMax(&sRowMax[tid >> 6][1], (unsigned long long)__double_as_longlong(r.a2));
@@ -282,13 +286,13 @@ __global__ __launch_bounds__(256, 1) void refcos_q8_kernel(
     const unsigned kMax = __builtin_amdgcn_readfirstlane(min(sMaxLen[0], sMaxLen[1]));
     const unsigned nChunks = (kMax + kQG - 1) / kQG;
 
-    v16i acc[3][2][2];
+    v16i acc[3][2][CB];
 #pragma unroll
     for (int l = 0; l < 3; ++l)
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+            for (int b = 0; b < CB; ++b)
 #pragma unroll
                 for (int g = 0; g < 16; ++g)
                     acc[l][a][b][g] = 0;
@@ -303,7 +307,7 @@ __global__ __launch_bounds__(256, 1) void refcos_q8_kernel(
     // set, MFMAs of chunk c.  (Reads, DMA issue and barrier skew sat in front of every chunk's MFMAs before: 1600
     // cycles per chunk for 768 of MFMAs.)  The barrier is the bare instruction, not __syncthreads(): that one is a fence
     // too, and a fence after DMAs into LDS makes the compiler wait for ALL of them.
-    v4i av[2][3][2], bv[2][3][2];                          // [register set][digit plane][block]
+    v4i av[2][3][2], bv[2][3][CB];                         // [register set][digit plane][block]
     auto readops = [&](auto S, auto SET) {
         constexpr int set = decltype(SET)::value;
         const unsigned char *const rA = stageA(S), *const rB = stageB(S);
@@ -311,9 +315,12 @@ __global__ __launch_bounds__(256, 1) void refcos_q8_kernel(
         for (int p = 0; p < 3; ++p)
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {
-                const int rowA = wm * 64 + blk * 32 + lr, rowB = wn * 64 + blk * 32 + lr;
+                const int rowA = wm * 64 + blk * 32 + lr;
                 av[set][p][blk] = *reinterpret_cast<const v4i *>(&rA[rowA * 128 + (((2 * p + lh) ^ ((rowA >> 1) & 7)) << 4)]);
-                bv[set][p][blk] = *reinterpret_cast<const v4i *>(&rB[rowB * 128 + (((2 * p + lh) ^ ((rowB >> 1) & 7)) << 4)]);
+                if (blk < CB) {
+                    const int rowB = wn * 32 * CB + blk * 32 + lr;
+                    bv[set][p][blk] = *reinterpret_cast<const v4i *>(&rB[rowB * 128 + (((2 * p + lh) ^ ((rowB >> 1) & 7)) << 4)]);
+                }
             }
     };
     auto mfmas = [&](auto SET) {
@@ -325,7 +332,7 @@ __global__ __launch_bounds__(256, 1) void refcos_q8_kernel(
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
-                    for (int b = 0; b < 2; ++b)
+                    for (int b = 0; b < CB; ++b)
                         acc[pa + pb][a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[set][pa][a], bv[set][pb][b], acc[pa + pb][a][b], 0, 0, 0);
     };
     auto step = [&](unsigned c, auto S) {
@@ -334,7 +341,7 @@ __global__ __launch_bounds__(256, 1) void refcos_q8_kernel(
         using OtherSet = std::integral_constant<int, (s & 1) ^ 1>;
         using NextStage = std::integral_constant<int, (s + 1) & 3>;
         // chunk c + 1 has landed (the groups of c + 2 and c + 3 may still be in flight: every step issues one group)
-        __builtin_amdgcn_s_waitcnt(rm_wait_vmcnt(16));
+        __builtin_amdgcn_s_waitcnt(rm_wait_vmcnt(4 * kP));
         __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0): this wave's reads of chunk c are in its registers
         asm volatile("s_barrier" ::: "memory");
         // One basic block from here: 8 DMAs (chunk c + 4 into the stage just vacated), 12 operand reads (chunk c + 1 into
@@ -347,18 +354,17 @@ __global__ __launch_bounds__(256, 1) void refcos_q8_kernel(
         readops(NextStage{}, OtherSet{});
         mfmas(Set{});
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 4 * CB; ++i) {                 // (2 kP DMAs, 6 + 3 CB reads, 12 CB MFMAs)
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // VMEM read (the DMA)
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // DS read
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (i < 4)
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
     };
     if (nChunks > 0) {
-        __builtin_amdgcn_s_waitcnt(rm_wait_vmcnt(24));
+        __builtin_amdgcn_s_waitcnt(rm_wait_vmcnt(6 * kP));
         asm volatile("s_barrier" ::: "memory");
         readops(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
     }
@@ -380,7 +386,7 @@ __global__ __launch_bounds__(256, 1) void refcos_q8_kernel(
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int b2 = 0; b2 < 2; ++b2)
+                for (int b2 = 0; b2 < CB; ++b2)
                     t += acc[l][a][b2];
         int x = 0;
 #pragma unroll
@@ -395,16 +401,16 @@ __global__ __launch_bounds__(256, 1) void refcos_q8_kernel(
     // D layout of the 32 x 32 forms: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
     const double INF = __builtin_inf();
     const double u = 1.1102230246251565e-16;
-    const bool plain = !WRITE_SIMS && (sPlain[wm] & sPlain[2 + wn]) != 0;
-    QInfo ci[2];
-    double colMin[2];
+    const bool plain = !WRITE_SIMS && (sPlain[wm] & sPlain[2 + wn * CB] & sPlain[2 + wn * CB + CB - 1]) != 0;
+    QInfo ci[CB];
+    double colMin[CB];
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        ci[b] = sInfo[kQT + wn * 64 + b * 32 + lr];
+    for (int b = 0; b < CB; ++b) {
+        ci[b] = sInfo[kQT + wn * 32 * CB + b * 32 + lr];
         colMin[b] = INF;
     }
-    double klo[2][2][16];                                  // [column block][row block][register]
-    double khis[TOPK ? 2 : 1][TOPK ? 2 : 1][TOPK ? 16 : 1];
+    double klo[CB][2][16];                                 // [column block][row block][register]
+    double khis[TOPK ? CB : 1][TOPK ? 2 : 1][TOPK ? 16 : 1];
     // PLAIN waves (all 64 + 64 segments inside the sets, norms in [1e-139, 1e139], finite distances -- and, the records
     // existing, all values finite): per pair only z = |s - dist| is formed, 10 operations; the half-width of the interval
     // comes from per-COLUMN constants -- the column's own numbers against the largest a1..a4 among the wave's 64 rows,
@@ -412,13 +418,13 @@ __global__ __launch_bounds__(256, 1) void refcos_q8_kernel(
     // bound of its smallest z, and key_lo >= z (1 - c9) - K with K = 2 c9 |dist| + C, one multiply-add per pair after the
     // thresholds are known.  (The general form below keeps every row's own numbers: ~27 operations per pair.)
     const double c9 = 9.0 * u * 1.0000001;
-    double Cb[2], Kb[2];
+    double Cb[CB], Kb[CB];
     if (plain) {
         const double m1 = __longlong_as_double((long long)sRowMax[wm][0]), m2 = __longlong_as_double((long long)sRowMax[wm][1]);
         const double m3 = __longlong_as_double((long long)sRowMax[wm][2]), m4 = __longlong_as_double((long long)sRowMax[wm][3]);
-        double zmin[2];
+        double zmin[CB];
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
+        for (int b = 0; b < CB; ++b) {
             Cb[b] = 1.0001 * __fma_rn(m4, ci[b].a4, __fma_rn(m1, ci[b].a2, __fma_rn(m2, ci[b].a1, m3 * ci[b].a3))) + 1e-290;
             Kb[b] = __fma_rn(2.0 * c9, fabs(ci[b].dist), Cb[b]) * (1.0 + 4.0 * u);
             zmin[b] = INF;
@@ -430,7 +436,7 @@ __global__ __launch_bounds__(256, 1) void refcos_q8_kernel(
                 const int row = wm * 64 + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
                 const double ra2 = sInfo[row].a2;
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
+                for (int b = 0; b < CB; ++b) {
                     // the kept part of the integer dot, exactly: a multiple of 2^16 below 2^60
                     // (through the exponent trick, not v_cvt_f64_i32: three conversions per pair were 2.5 % of the kernel)
                     const double gk = q8_scaled(acc[0][a][b][g], 0x45300000u, 0x1p84 + 0x1p63) +
@@ -442,7 +448,7 @@ __global__ __launch_bounds__(256, 1) void refcos_q8_kernel(
                 }
             }
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < CB; ++b)
             colMin[b] = (zmin[b] + __fma_rn(c9, zmin[b] + 2.0 * fabs(ci[b].dist), Cb[b])) * (1.0 + 4.0 * u);
     } else {
 #pragma unroll
@@ -452,11 +458,11 @@ __global__ __launch_bounds__(256, 1) void refcos_q8_kernel(
                 const int row = wm * 64 + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
                 const QInfo ri = sInfo[row];
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
+                for (int b = 0; b < CB; ++b) {
                     const double gk = __fma_rn(0x1p32, (double)acc[0][a][b][g],
                                                __fma_rn(0x1p24, (double)acc[1][a][b][g], 0x1p16 * (double)acc[2][a][b][g]));
                     const double extra = __fma_rn(ri.a1, ci[b].a2, __fma_rn(ri.a2, ci[b].a1, ri.a3 * ci[b].a3));
-                    const unsigned la = sLen[row], lb = sLen[kQT + wn * 64 + b * 32 + lr];
+                    const unsigned la = sLen[row], lb = sLen[kQT + wn * 32 * CB + b * 32 + lr];
                     const unsigned len = la < lb ? la : lb;
                     const double nrm = __dmul_rn(ri.norm, ci[b].norm);
                     const double dotm = gk * (ri.scl * ci[b].scl);
@@ -464,7 +470,7 @@ __global__ __launch_bounds__(256, 1) void refcos_q8_kernel(
                     refcos_key_interval(dotm, ri.sq * ci[b].sq, ri.inv * ci[b].inv, nrm,
                                         (3.0 * (double)len + 16.0) * (u * 1.02), ci[b].dist, lo, hi, extra);
                     if (WRITE_SIMS) {
-                        const uint32_t s = sTile + row, t = tTile + wn * 64 + b * 32 + lr;
+                        const uint32_t s = sTile + row, t = tTile + wn * 32 * CB + b * 32 + lr;
                         if (s < nSrc && t < nTgt)
                             simOut[(size_t)s * nTgt + t] = __ddiv_rn(dotm, nrm);
                     }
@@ -476,9 +482,9 @@ __global__ __launch_bounds__(256, 1) void refcos_q8_kernel(
                 }
             }
     }
-    double cur[2];
+    double cur[CB];
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < CB; ++b) {
         double cmin = colMin[b];
         if (TOPK) {
             // the kTop-th smallest DISTINCT upper bound among the wave's 64 rows (refcos_mfma.hip); in plain waves the
@@ -502,22 +508,22 @@ __global__ __launch_bounds__(256, 1) void refcos_q8_kernel(
         }
         cur[b] = cmin;
     }
-    unsigned long long seenBits[2];
+    unsigned long long seenBits[CB];
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const uint32_t t = tTile + wn * 64 + b * 32 + lr;
+    for (int b = 0; b < CB; ++b) {
+        const uint32_t t = tTile + wn * 32 * CB + b * 32 + lr;
         seenBits[b] = kInfBitsU;
         if (lh == 0 && t < nTgt)
             seenBits[b] = atomicMin(&thr[t], (unsigned long long)__double_as_longlong(cur[b]));
     }
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < CB; ++b) {
         seenBits[b] = __shfl(seenBits[b], lr);
         cur[b] = fmin(fmin(cur[b], __longlong_as_double((long long)seenBits[b])), 1.7976931348623157e308);
     }
     if (plain) {
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < CB; ++b)
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -526,7 +532,7 @@ __global__ __launch_bounds__(256, 1) void refcos_q8_kernel(
     }
     unsigned total = 0;
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < CB; ++b)
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -538,7 +544,7 @@ __global__ __launch_bounds__(256, 1) void refcos_q8_kernel(
             base = atomicAdd(&hdr[0], total);
         base = __builtin_amdgcn_readfirstlane(base);
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < CB; ++b)
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -552,7 +558,7 @@ __global__ __launch_bounds__(256, 1) void refcos_q8_kernel(
                             if (pos < cap) {
                                 PairEntry e;
                                 e.s = sTile + wm * 64 + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
-                                e.t = tTile + wn * 64 + b * 32 + lr;
+                                e.t = tTile + wn * 32 * CB + b * 32 + lr;
                                 e.key_lo = klo[b][a][g];
                                 list[pos] = e;
                             } else {
@@ -643,18 +649,30 @@ int32_t launch_refcos_q8_kernel(ssym_ctx *ctx, const SegmentSet &src, const Segm
     const uint32_t N = src.n, M = tgt.n;
     dim3 grid((M + kQT - 1) / kQT, (N + kQT - 1) / kQT);
     hipStream_t st = ctx->stream;
-    if (sims)
-        refcos_q8_kernel<true, false><<<grid, 256, 0, st>>>(src.q8, src.q8_info, src.off, src.norm, tgt.q8, tgt.q8_info, tgt.off,
-                                                            tgt.norm, N, M, src.dim, src.q8_groups, tgt.q8_groups, dist_dev, 1.0,
-                                                            thr, hdr1, (PairEntry *)list1, cap, sims, 1);
-    else if (k_top > 1)
-        refcos_q8_kernel<false, true><<<grid, 256, 0, st>>>(src.q8, src.q8_info, src.off, src.norm, tgt.q8, tgt.q8_info, tgt.off,
-                                                            tgt.norm, N, M, src.dim, src.q8_groups, tgt.q8_groups, dist_dev, 1.0,
-                                                            thr, hdr1, (PairEntry *)list1, cap, nullptr, k_top);
-    else
-        refcos_q8_kernel<false, false><<<grid, 256, 0, st>>>(src.q8, src.q8_info, src.off, src.norm, tgt.q8, tgt.q8_info, tgt.off,
-                                                             tgt.norm, N, M, src.dim, src.q8_groups, tgt.q8_groups, dist_dev, 1.0,
-                                                             thr, hdr1, (PairEntry *)list1, cap, nullptr, 1);
+    // four waves of 64 x 64 per workgroup (one per SIMD); SSYM_REFCOS_Q8_WAVES=8 takes eight of 64 x 32, two per SIMD, at
+    // 1.5 x the operand reads per MFMA -- measured 2 % SLOWER (0.191 against 0.187 ms: what the waves wait for is not
+    // hidden by a second wave), kept as a measurement switch
+    const char *knob = getenv("SSYM_REFCOS_Q8_WAVES");
+    const bool four = !(knob && atoi(knob) == 8);
+#define SSYM_Q8_LAUNCH(WS, TK, CBV, SIMS, KT)                                                                                  \
+    refcos_q8_kernel<WS, TK, CBV><<<grid, CBV == 2 ? 256 : 512, 0, st>>>(src.q8, src.q8_info, src.off, src.norm, tgt.q8,       \
+                                                                       tgt.q8_info, tgt.off, tgt.norm, N, M, src.dim,          \
+                                                                       src.q8_groups, tgt.q8_groups, dist_dev, 1.0, thr, hdr1, \
+                                                                       (PairEntry *)list1, cap, SIMS, KT)
+    if (sims) {
+        SSYM_Q8_LAUNCH(true, false, 2, sims, 1);
+    } else if (k_top > 1) {
+        if (four)
+            SSYM_Q8_LAUNCH(false, true, 2, nullptr, k_top);
+        else
+            SSYM_Q8_LAUNCH(false, true, 1, nullptr, k_top);
+    } else {
+        if (four)
+            SSYM_Q8_LAUNCH(false, false, 2, nullptr, 1);
+        else
+            SSYM_Q8_LAUNCH(false, false, 1, nullptr, 1);
+    }
+#undef SSYM_Q8_LAUNCH
     SSYM_HIP_CHECK(ctx, hipGetLastError());
     return SSYM_OK;
 }
