@@ -7,7 +7,7 @@
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-template <int THREADS>
+template <int THREADS, bool CHAINED>
 __global__ __launch_bounds__(THREADS, 1) void k(int iters, int *out, v4i a0, v4i b0)
 {
     v16i acc[3][2][2];
@@ -23,6 +23,21 @@ __global__ __launch_bounds__(THREADS, 1) void k(int iters, int *out, v4i a0, v4i
             bv[p][q] = b0 - (int)threadIdx.x + p - q;
         }
     for (int it = 0; it < iters; ++it) {
+        if (CHAINED) {           // the order the compiler's scheduler gave the kernel: an accumulator's updates back to back
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    acc[0][a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[0][a], bv[0][b], acc[0][a][b], 0, 0, 0);
+                    acc[1][a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[0][a], bv[1][b], acc[1][a][b], 0, 0, 0);
+                    acc[1][a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[1][a], bv[0][b], acc[1][a][b], 0, 0, 0);
+                    acc[2][a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[0][a], bv[2][b], acc[2][a][b], 0, 0, 0);
+                    acc[2][a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[1][a], bv[1][b], acc[2][a][b], 0, 0, 0);
+                    acc[2][a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[2][a], bv[0][b], acc[2][a][b], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            continue;
+        }
 #pragma unroll
         for (int pa = 0; pa < 3; ++pa)
 #pragma unroll
@@ -53,18 +68,20 @@ int main()
     v4i a0 = {1, 2, 3, 4}, b0 = {5, 6, 7, 8};
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int mode = 0; mode < 2; ++mode) {
+    for (int mode = 0; mode < 4; ++mode) {
         float ms = 0;
         for (int rep = 0; rep < 2; ++rep) {
             hipEventRecord(e0);
-            if (mode == 0) k<256><<<p.multiProcessorCount, 256>>>(iters, out, a0, b0);
-            else           k<512><<<p.multiProcessorCount, 512>>>(iters, out, a0, b0);
+            if (mode == 0) k<256, false><<<p.multiProcessorCount, 256>>>(iters, out, a0, b0);
+            if (mode == 1) k<512, false><<<p.multiProcessorCount, 512>>>(iters, out, a0, b0);
+            if (mode == 2) k<256, true><<<p.multiProcessorCount, 256>>>(iters, out, a0, b0);
+            if (mode == 3) k<512, true><<<p.multiProcessorCount, 512>>>(iters, out, a0, b0);
             hipEventRecord(e1);
             hipEventSynchronize(e1);
             hipEventElapsedTime(&ms, e0, e1);
         }
-        const double mfmaPerSimd = (double)iters * 24 * (mode == 0 ? 1 : 2);
-        printf("%d wave(s) per SIMD: %.3f ms, %.1f ns per MFMA and SIMD = %.1f cycles at 2.4 GHz; %.0f TOP/s over %d CUs\n", mode + 1, ms,
+        const double mfmaPerSimd = (double)iters * 24 * ((mode & 1) == 0 ? 1 : 2);
+        printf("%s%d wave(s) per SIMD: %.3f ms, %.1f ns per MFMA and SIMD = %.1f cycles at 2.4 GHz; %.0f TOP/s over %d CUs\n", mode >= 2 ? "chained updates, " : "", (mode & 1) + 1, ms,
                ms * 1e6 / mfmaPerSimd, ms * 1e6 / mfmaPerSimd * 2.4, mfmaPerSimd * 4 * p.multiProcessorCount * 65536.0 / (ms * 1e-3) / 1e12,
                p.multiProcessorCount);
     }
