@@ -8,23 +8,7 @@
 
 using namespace ssym;
 
-// Behind the refcos search's results: four header words of its two lists and three device timestamps (start, main kernel
-// done, now) -- one copy back instead of three, and no event between the search's kernels (an event record costs ~7 us
-// of gap on the stream; a search is 0.2 ms).  tail: [h1 x 2][h2 x 2][stamp x 3 (8-byte aligned)].
-__global__ void pack_headers_kernel(const uint32_t *__restrict__ h1, const uint32_t *__restrict__ h2, uint32_t *__restrict__ tail,
-                                    unsigned long long *__restrict__ stamps)
-{
-    if (threadIdx.x < 2)
-        tail[threadIdx.x] = h1[threadIdx.x];
-    else if (threadIdx.x < 4)
-        tail[threadIdx.x] = h2[threadIdx.x - 2];
-    else if (threadIdx.x == 4 && stamps) {
-        unsigned long long *out = reinterpret_cast<unsigned long long *>(tail + 4);
-        out[0] = stamps[0];
-        out[1] = stamps[1];
-        out[2] = (unsigned long long)wall_clock64();
-    }
-}
+// the tail behind the refcos search's results (refcos_mfma.hip, refcos_pack_tail): header words of its lists + timestamps
 constexpr size_t kTailBytes = 4 * sizeof(uint32_t) + 3 * sizeof(unsigned long long);
 
 static thread_local std::string g_create_err;
@@ -476,7 +460,11 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
             uint32_t h1[2] = {0, 0}, h2[2] = {0, 0};
             if (!stampsDev)
                 SSYM_HIP_CHECK(ctx, hipEventRecord(ev[0], st));
-            rc = launch_refcos_match_mfma(ctx, src, tgt, distDev, index_base, idxDev, costDev, &h1dev, &h2dev, k_top, q8, stampsDev);
+            // (where the tail goes: behind the host outputs' device block, or -- device outputs -- behind the timestamps)
+            char *packed = (!ctx->stream_only && !outDev && hdrTail) ? stage_take(ctx, costBytes + idxBytes + kTailBytes) : nullptr;
+            uint32_t *tailDev = packed ? hdrTail : (stampsDev ? (uint32_t *)(stampsDev + 4) : nullptr);
+            rc = launch_refcos_match_mfma(ctx, src, tgt, distDev, index_base, idxDev, costDev, &h1dev, &h2dev, k_top, q8, stampsDev,
+                                          tailDev);
             if (rc != SSYM_OK)
                 return rc;
             tm.refcos_filter = q8 ? 2 : 1;
@@ -495,12 +483,9 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
             // host outputs: results, headers and timestamps come back in one copy and under one synchronisation; should
             // the list have overflowed the results are dropped and the exact kernel's staged instead
             const size_t pendingBefore = ctx->pending_d2h.size();
-            char *packed = (!outDev && hdrTail) ? stage_take(ctx, costBytes + idxBytes + kTailBytes) : nullptr;
             unsigned long long tailHost[(kTailBytes + 7) / 8] = {0};
             const unsigned char *tailAt = nullptr;
             if (packed) {
-                pack_headers_kernel<<<1, 64, 0, st>>>(h1dev, h2dev, hdrTail, stampsDev);
-                SSYM_HIP_CHECK(ctx, hipGetLastError());
                 SSYM_HIP_CHECK(ctx, hipMemcpyAsync(packed, costDev, costBytes + idxBytes + kTailBytes, hipMemcpyDeviceToHost, st));
                 if (out_cost)
                     ctx->pending_d2h.push_back({out_cost, packed, costBytes});
@@ -508,9 +493,6 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
                 outputsStaged = true;
                 tailAt = (const unsigned char *)packed + costBytes + idxBytes;
             } else if (stampsDev) {              // device outputs (or no staging window): the tail alone comes back
-                uint32_t *tailDev = (uint32_t *)(stampsDev + 4);
-                pack_headers_kernel<<<1, 64, 0, st>>>(h1dev, h2dev, tailDev, stampsDev);
-                SSYM_HIP_CHECK(ctx, hipGetLastError());
                 SSYM_HIP_CHECK(ctx, hipMemcpyAsync(tailHost, tailDev, kTailBytes, hipMemcpyDeviceToHost, st));
                 tailAt = (const unsigned char *)tailHost;
                 if (!outDev) {

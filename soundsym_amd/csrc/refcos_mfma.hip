@@ -615,11 +615,38 @@ __global__ void refcos_fold_idx_kernel(const uint32_t *__restrict__ hdr2, const 
         atomicMin(&bestIdx[pr.y], pr.x);
 }
 
+// Behind the search's results, for the caller's one copy back: four header words of the two lists and three device
+// timestamps (start, main kernel done, now).  tail: [h1 x 2][h2 x 2][stamp x 3 (8-byte aligned)].
+__device__ __forceinline__ void refcos_pack_tail(int lane, const uint32_t *__restrict__ h1, const uint32_t *__restrict__ h2,
+                                                 uint32_t *__restrict__ tail, const unsigned long long *__restrict__ stamps)
+{
+    if (lane < 2)
+        tail[lane] = h1[lane];
+    else if (lane < 4)
+        tail[lane] = h2[lane - 2];
+    else if (lane == 4 && stamps) {
+        unsigned long long *out = reinterpret_cast<unsigned long long *>(tail + 4);
+        out[0] = stamps[0];
+        out[1] = stamps[1];
+        out[2] = (unsigned long long)wall_clock64();
+    }
+}
+
+__global__ void refcos_pack_tail_kernel(const uint32_t *__restrict__ h1, const uint32_t *__restrict__ h2, uint32_t *__restrict__ tail,
+                                        const unsigned long long *__restrict__ stamps)
+{
+    refcos_pack_tail((int)threadIdx.x, h1, h2, tail, stamps);
+}
+
 __global__ void refcos_fold_out_kernel(const unsigned long long *__restrict__ bestKey, const uint32_t *__restrict__ bestIdx,
                                        uint32_t nTgt, uint32_t indexBase, uint32_t *__restrict__ outIdx,
-                                       double *__restrict__ outCost)
+                                       double *__restrict__ outCost, const uint32_t *__restrict__ h1,
+                                       const uint32_t *__restrict__ h2, uint32_t *__restrict__ tail,
+                                       const unsigned long long *__restrict__ stamps)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tail && blockIdx.x == gridDim.x - 1 && threadIdx.x >= blockDim.x - 8)      // (the search's last kernel packs the tail itself)
+        refcos_pack_tail((int)(threadIdx.x - (blockDim.x - 8)), h1, h2, tail, stamps);
     if (t >= nTgt)
         return;
     const bool won = bestIdx[t] != 0xffffffffu;          // something beat the fold start (0, 2.0), src/sound.rs:361-367
@@ -691,7 +718,7 @@ size_t refcos_list_capacity(uint32_t n_src, uint32_t n_tgt)
 int32_t launch_refcos_match_mfma(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, const double *dist_dev,
                                  uint32_t index_base, uint32_t *out_idx_dev, double *out_cost_dev,
                                  const uint32_t **list1_hdr, const uint32_t **list2_hdr, uint32_t k_top, bool integer_filter,
-                                 unsigned long long *stamps)
+                                 unsigned long long *stamps, uint32_t *tail)
 {
     const uint32_t N = src.n, M = tgt.n;
     hipStream_t st = ctx->stream;
@@ -752,9 +779,12 @@ int32_t launch_refcos_match_mfma(ssym_ctx *ctx, const SegmentSet &src, const Seg
         rc = launch_dtw_final(ctx, src, tgt, nullptr, (uint32_t)cap, index_base, k_top, out_idx_dev, out_cost_dev);
         if (rc != SSYM_OK)
             return rc;
+        if (tail)
+            refcos_pack_tail_kernel<<<1, 64, 0, st>>>(hdr1, hdr2, tail, stamps);
     } else {
         refcos_fold_idx_kernel<<<keepBlocks, 256, 0, st>>>(hdr2, pairs, keys, bestKey, bestIdx);
-        refcos_fold_out_kernel<<<(M + 255) / 256, 256, 0, st>>>(bestKey, bestIdx, M, index_base, out_idx_dev, out_cost_dev);
+        refcos_fold_out_kernel<<<(M + 255) / 256, 256, 0, st>>>(bestKey, bestIdx, M, index_base, out_idx_dev, out_cost_dev, hdr1, hdr2,
+                                                              tail, stamps);
     }
     SSYM_HIP_CHECK(ctx, hipGetLastError());
     *list1_hdr = hdr1;

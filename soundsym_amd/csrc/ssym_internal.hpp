@@ -374,7 +374,7 @@ int32_t launch_refcos_q8_kernel(ssym_ctx *ctx, const SegmentSet &src, const Segm
 int32_t launch_refcos_match_mfma(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, const double *dist_dev,
                                  uint32_t index_base, uint32_t *out_idx_dev, double *out_cost_dev,
                                  const uint32_t **list1_hdr, const uint32_t **list2_hdr, uint32_t k_top = 1, bool integer_filter = false,
-                                 unsigned long long *stamps = nullptr);
+                                 unsigned long long *stamps = nullptr, uint32_t *tail = nullptr);
 int32_t launch_refcos_mfma_sims(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, double *sims,
                                 bool integer_filter = false);
 char *stage_take(ssym_ctx *ctx, size_t bytes);      // pack.hip: room in the call's pinned window (NULL: none)
