@@ -284,8 +284,11 @@ __global__ __launch_bounds__(256) void refcos_match_one_kernel(
     uint32_t nSrc, uint32_t dim, const void *__restrict__ queries, const uint64_t *__restrict__ qOff /* frames */,
     int queryIsF32, const double *__restrict__ distances /* NULL: defaultDist */, double defaultDist,
     double *__restrict__ partValAll, uint32_t *__restrict__ partIdxAll, unsigned *__restrict__ tickets,
-    uint32_t *__restrict__ outIdxAll, double *__restrict__ outValAll)
+    uint32_t *__restrict__ outIdxAll, double *__restrict__ outValAll,
+    unsigned long long *__restrict__ stamps /* nullable, host-visible: [0] a first workgroup starts, [1 + y] query y is done */)
 {
+    if (stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+        stamps[0] = (unsigned long long)wall_clock64();
     // blockIdx.y = the query (a handful per call: ssym_match_one, small ssym_match_batch calls)
     const uint32_t y = blockIdx.y;
     const unsigned long long qBase = qOff[y] * dim;
@@ -391,6 +394,8 @@ __global__ __launch_bounds__(256) void refcos_match_one_kernel(
         *outIdx = minIdx;
         *outVal = minVal;
         *ticket = 0;                                // ready for the next call
+        if (stamps)
+            stamps[1 + y] = (unsigned long long)wall_clock64();
         __threadfence_system();
     }
 }
@@ -409,7 +414,7 @@ bool refcos_few_supported(const ssym_ctx *ctx, const SegmentSet &src, const uint
 // rebased to 0, distances or NULL; out_val / out_idx: pinned, n_queries entries each
 int32_t launch_refcos_match_few(ssym_ctx *ctx, const SegmentSet &src, const void *queries, const uint64_t *q_off,
                                 uint32_t n_queries, const double *distances, double default_dist, double *out_val,
-                                uint32_t *out_idx)
+                                uint32_t *out_idx, unsigned long long *stamps)
 {
     const uint32_t nb = (src.n + kOneEntries - 1) / kOneEntries;
     int32_t rc = ensure(ctx, ctx->part, (sizeof(double) + sizeof(uint32_t)) * (size_t)nb * n_queries + 256);
@@ -425,7 +430,7 @@ int32_t launch_refcos_match_few(ssym_ctx *ctx, const SegmentSet &src, const void
     uint32_t *partIdx = (uint32_t *)(partVal + (size_t)nb * n_queries);
     refcos_match_one_kernel<<<dim3(nb, n_queries), 256, 0, ctx->stream>>>(
         src.raw, src.off, src.norm, src.n, src.dim, queries, q_off, ctx->dtype == SSYM_DTYPE_F32 ? 1 : 0, distances,
-        default_dist, partVal, partIdx, (unsigned *)ctx->one_ticket.ptr, out_idx, out_val);
+        default_dist, partVal, partIdx, (unsigned *)ctx->one_ticket.ptr, out_idx, out_val, stamps);
     SSYM_HIP_CHECK(ctx, hipGetLastError());
     return SSYM_OK;
 }

@@ -357,7 +357,7 @@ int32_t launch_refcos_sims(ssym_ctx *ctx, const SegmentSet &src, const SegmentSe
 bool refcos_few_supported(const ssym_ctx *ctx, const SegmentSet &src, const uint64_t *q_off, uint32_t n_queries);
 int32_t launch_refcos_match_few(ssym_ctx *ctx, const SegmentSet &src, const void *queries, const uint64_t *q_off,
                                 uint32_t n_queries, const double *distances, double default_dist, double *out_val,
-                                uint32_t *out_idx);
+                                uint32_t *out_idx, unsigned long long *stamps = nullptr);
 bool dtw_few_supported(const ssym_ctx *ctx, const SegmentSet &src, const uint64_t *q_off, uint32_t n_queries);
 int32_t launch_dtw_match_few(ssym_ctx *ctx, const SegmentSet &src, const void *queries, const uint64_t *q_off,
                              uint32_t n_queries, const double *distances, double *out_cost, uint32_t *out_idx);
