@@ -436,9 +436,11 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
         // (a sharded step only enqueues: its candidate list's header travels in the gathered status like the dtw
         //  lists', and the attempt every rank repeats after an overflow -- so_cap set -- takes the exact tile kernel)
         // Top-k goes that way up to k = 8: a wave offers the k-th smallest bound of ITS 64 rows, which loosens with k --
-        // 4096 x 4096 x 128f x 12d: k = 2 / 4 / 8 / 16 key 11 / 55 / 194 / 553 pairs per target exactly and take 1.2 / 1.7 /
-        // 3.1 / 6.9 ms against 4.5 / 4.6 / 4.8 / 5.3 ms on the exact tile kernel (tools/refcos_topk_timing.py).
-        bool viaMfma = !(ctx->stream_only && (ctx->so_cap || k_top > 1)) && k_top <= 8 && refcos_mfma_supported(ctx, src, tgt);
+        // 4096 x 4096 x 128f x 12d: k = 2 / 4 / 8 / 16 key 11 / 55 / 195 / 554 pairs per target exactly and take 0.49 / 0.97 /
+        // 2.39 / 5.98 ms against 3.2 / 3.1 / 3.3 / 3.9 ms on the exact tile kernel (tools/refcos_topk_timing.py).
+        const char *kmaxKnob = getenv("SSYM_REFCOS_TOPK_MAX");                       // (measurements: where the filters stop paying)
+        const uint32_t kFilterMax = kmaxKnob ? (uint32_t)std::max(1, atoi(kmaxKnob)) : 8u;
+        bool viaMfma = !(ctx->stream_only && (ctx->so_cap || k_top > 1)) && k_top <= kFilterMax && refcos_mfma_supported(ctx, src, tgt);
         ctx->so_refcos = false;
         // Which filter: the integer one where both sets have its records; should ITS list overflow -- values so close that
         // 23 bits of fixed point cannot tell them apart -- the f64 filter gets the search before the exact tile kernel does

@@ -722,7 +722,7 @@ int32_t launch_refcos_match_mfma(ssym_ctx *ctx, const SegmentSet &src, const Seg
 {
     const uint32_t N = src.n, M = tgt.n;
     hipStream_t st = ctx->stream;
-    const size_t cap = std::min<uint64_t>((uint64_t)N * M, (uint64_t)refcos_list_capacity(N, M) * std::min<uint32_t>(k_top, 8));
+    const size_t cap = std::min<uint64_t>((uint64_t)N * M, (uint64_t)refcos_list_capacity(N, M) * std::min<uint32_t>(k_top, 64));
     int32_t rc = ensure(ctx, ctx->cand, 4 * sizeof(uint32_t) + sizeof(PairEntry) * cap);
     if (rc == SSYM_OK)
         rc = ensure(ctx, ctx->cand2, 4 * sizeof(uint32_t) + sizeof(uint2) * cap);
