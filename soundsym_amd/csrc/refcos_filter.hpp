@@ -14,6 +14,11 @@ struct PairEntry {                  // list 1: a pair that may hold its target's
     double key_lo;
 };
 
+struct PairEntryK {                 // list 1 of a top-k search: the interval's upper end travels too (the k-th smallest of a
+    uint32_t s, t;                  // target's upper ends, over ALL its listed pairs, is the target's threshold)
+    double key_lo, key_hi;
+};
+
 struct RowInfo {                    // per segment of the tile
     double sq;                      // >= sqrt(norm)
     double inv;                     // fl(1 / norm)

@@ -225,11 +225,20 @@ __device__ __forceinline__ void refcos_epilogue(double4v (&acc)[4][4], RowInfo *
                                                                               __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
                         if (in) {
                             if (pos < cap) {
-                                PairEntry e;
-                                e.s = sTile + wm * 64 + a * 16 + 4 * i + lg;
-                                e.t = tTile + wn * 64 + b * 16 + lr;
-                                e.key_lo = acc[a][b][i];
-                                list[pos] = e;
+                                if constexpr (TOPK) {
+                                    PairEntryK e;
+                                    e.s = sTile + wm * 64 + a * 16 + 4 * i + lg;
+                                    e.t = tTile + wn * 64 + b * 16 + lr;
+                                    e.key_lo = acc[a][b][i];
+                                    e.key_hi = khis[b][a][i];
+                                    reinterpret_cast<PairEntryK *>(list)[pos] = e;
+                                } else {
+                                    PairEntry e;
+                                    e.s = sTile + wm * 64 + a * 16 + 4 * i + lg;
+                                    e.t = tTile + wn * 64 + b * 16 + lr;
+                                    e.key_lo = acc[a][b][i];
+                                    list[pos] = e;
+                                }
                             } else {
                                 hdr[1] = 1;
                             }
@@ -533,6 +542,135 @@ __global__ void refcos_keep_kernel(const uint32_t *__restrict__ hdr1, const Pair
         pairs[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = make_uint2(e.s, e.t);
 }
 
+// ---- top-k searches: list 1 -> per-target thresholds from ALL of a target's listed pairs -> candidates ----------------------
+// The threshold a wave offers a column is the k-th smallest upper bound among ITS 64 rows; every pair that can be among a
+// target's k smallest keys is in list 1 under the smallest such offer, and so are at least k pairs whose upper bound does
+// not exceed it.  Hence the k-th smallest DISTINCT key_hi over a target's listed pairs is the k-th smallest over all its
+// pairs -- a threshold as good as if every row had been looked at (the wave-local one keeps ~25 k pairs per target, this
+// one k and what ties with it).  The entries are grouped by target (count, scan, scatter), then one wave per target
+// runs the k rounds on its group and hands the pairs with key_lo under the threshold to the exact keys.
+__global__ void refcos_topk_count_kernel(const uint32_t *__restrict__ hdr1, const PairEntryK *__restrict__ list, uint32_t cap,
+                                         uint32_t *__restrict__ cnt, unsigned long long *stamps)
+{
+    const uint32_t n = min(hdr1[0], cap);
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && stamps)
+        stamps[1] = (unsigned long long)wall_clock64();    // the main kernel is done
+    for (uint32_t k = i; k < n; k += gridDim.x * blockDim.x)
+        atomicAdd(&cnt[list[k].t], 1u);
+}
+
+// exclusive scan of cnt[0..m) into start[0..m] by ONE workgroup (m = targets of a call); cnt becomes the groups' fill cursors
+__global__ __launch_bounds__(1024) void refcos_topk_scan_kernel(uint32_t *__restrict__ cnt, uint32_t m, uint32_t *__restrict__ start)
+{
+    __shared__ uint32_t sTot[1024];
+    const uint32_t per = (m + 1023) / 1024, lo = threadIdx.x * per, hi = min(lo + per, m);
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; ++i)
+        sum += cnt[i];
+    sTot[threadIdx.x] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const uint32_t v = threadIdx.x >= (unsigned)o ? sTot[threadIdx.x - o] : 0u;
+        __syncthreads();
+        sTot[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = threadIdx.x ? sTot[threadIdx.x - 1] : 0u;
+    for (uint32_t i = lo; i < hi; ++i) {
+        const uint32_t c = cnt[i];
+        start[i] = run;
+        cnt[i] = 0;
+        run += c;
+    }
+    if (threadIdx.x == 1023)
+        start[m] = sTot[1023];
+}
+
+__global__ void refcos_topk_scatter_kernel(const uint32_t *__restrict__ hdr1, const PairEntryK *__restrict__ list, uint32_t cap,
+                                           const uint32_t *__restrict__ start, uint32_t *__restrict__ cursor,
+                                           PairEntryK *__restrict__ sorted)
+{
+    const uint32_t n = min(hdr1[0], cap);
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const PairEntryK e = list[k];
+        sorted[start[e.t] + atomicAdd(&cursor[e.t], 1u)] = e;
+    }
+}
+
+// one wave per target: the k-th smallest distinct key_hi of its group, then its pairs with key_lo under it -> list 2
+__global__ __launch_bounds__(256) void refcos_topk_select_kernel(const uint32_t *__restrict__ start, const PairEntryK *__restrict__ sorted,
+                                                                 uint32_t m, uint32_t kTop, uint32_t cap2, uint32_t *__restrict__ hdr2,
+                                                                 uint2 *__restrict__ pairs)
+{
+    const uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (t >= m)
+        return;
+    const uint32_t lo = start[t], hi = start[t + 1];
+    const double INF = __builtin_inf();
+    double prev = -1.0;                                               // (keys are >= 0)
+    if (hi - lo <= 64u * 64u) {
+        // the group's upper bounds in registers, read once (k rounds over global memory were 5.5 of k = 64's 9 ms)
+        double v[64];
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+            const uint32_t k = lo + (uint32_t)lane + 64u * j;
+            v[j] = k < hi ? sorted[k].key_hi : INF;
+        }
+        for (uint32_t r = 0; r < kTop; ++r) {
+            double best = INF;
+#pragma unroll
+            for (int j = 0; j < 64; ++j)
+                best = (v[j] > prev && v[j] < best) ? v[j] : best;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1)
+                best = fmin(best, __shfl_xor(best, o));
+            prev = best;                                              // +inf once the group is used up: it stays
+            if (!(prev < INF))
+                break;
+        }
+    } else {
+        for (uint32_t r = 0; r < kTop; ++r) {
+            double best = INF;
+            for (uint32_t k = lo + lane; k < hi; k += 64) {
+                const double v = sorted[k].key_hi;
+                best = (v > prev && v < best) ? v : best;
+            }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1)
+                best = fmin(best, __shfl_xor(best, o));
+            prev = best;
+            if (!(prev < INF))
+                break;
+        }
+    }
+    const double thr = prev;
+    for (uint32_t k0 = lo; k0 < hi; k0 += 64) {
+        const uint32_t k = k0 + lane;
+        PairEntryK e{};
+        bool keep = false;
+        if (k < hi) {
+            e = sorted[k];
+            keep = e.key_lo <= thr && e.key_lo < INF;
+        }
+        const unsigned long long mask = __ballot(keep);
+        if (!mask)
+            continue;
+        uint32_t base = 0;
+        if (lane == 0)
+            base = atomicAdd(&hdr2[0], (uint32_t)__popcll(mask));
+        base = __shfl(base, 0);
+        const uint32_t pos = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        if (keep) {
+            if (pos < cap2)
+                pairs[pos] = make_uint2(e.s, e.t);
+            else
+                hdr2[1] = 1;
+        }
+    }
+}
+
 // The candidates' keys exactly as the reference computes them: eight lanes per pair, lane i keeps rulinalg's
 // running sum p_i (the code shape of refcos_match_one_kernel), combination, tail, division, |sim - distance|;
 // the smallest key below the fold start 2.0 per target is kept with an integer atomic (keys >= 0).
@@ -723,7 +861,12 @@ int32_t launch_refcos_match_mfma(ssym_ctx *ctx, const SegmentSet &src, const Seg
     const uint32_t N = src.n, M = tgt.n;
     hipStream_t st = ctx->stream;
     const size_t cap = std::min<uint64_t>((uint64_t)N * M, (uint64_t)refcos_list_capacity(N, M) * std::min<uint32_t>(k_top, 64));
-    int32_t rc = ensure(ctx, ctx->cand, 4 * sizeof(uint32_t) + sizeof(PairEntry) * cap);
+    const size_t entryBytes = k_top > 1 ? sizeof(PairEntryK) : sizeof(PairEntry);
+    int32_t rc = ensure(ctx, ctx->cand, 4 * sizeof(uint32_t) + entryBytes * cap);
+    if (rc == SSYM_OK && k_top > 1)      // top-k: the entries grouped by target, the groups' counts / cursors and starts
+        rc = ensure(ctx, ctx->cmat, sizeof(PairEntryK) * cap);
+    if (rc == SSYM_OK && k_top > 1)
+        rc = ensure(ctx, ctx->selcnt, sizeof(uint32_t) * (2 * (size_t)M + 2));
     if (rc == SSYM_OK)
         rc = ensure(ctx, ctx->cand2, 4 * sizeof(uint32_t) + sizeof(uint2) * cap);
     if (rc == SSYM_OK)
@@ -768,7 +911,21 @@ int32_t launch_refcos_match_mfma(ssym_ctx *ctx, const SegmentSet &src, const Seg
     if (!stamps)                         // (with device timestamps no event sits between the kernels: each costs ~7 us of gap)
         SSYM_HIP_CHECK(ctx, hipEventRecord(ctx->ev[1], st));      // main kernel | selection, exact keys, fold
     const unsigned keepBlocks = (unsigned)std::min<size_t>((cap + 255) / 256, 65535u * 16u);
-    refcos_keep_kernel<<<keepBlocks, 256, 0, st>>>(hdr1, list1, (uint32_t)cap, thr, hdr2, pairs, stamps);
+    if (k_top > 1) {
+        uint32_t *cnt = (uint32_t *)ctx->selcnt.ptr, *start = cnt + M;
+        PairEntryK *sorted = (PairEntryK *)ctx->cmat.ptr;
+        const PairEntryK *listK = reinterpret_cast<const PairEntryK *>(list1);
+        rc = zero_words(ctx, cnt, sizeof(uint32_t) * M);
+        if (rc != SSYM_OK)
+            return rc;
+        const unsigned sweepBlocks = std::min<unsigned>(keepBlocks, (unsigned)ctx->num_cus * 8);
+        refcos_topk_count_kernel<<<sweepBlocks, 256, 0, st>>>(hdr1, listK, (uint32_t)cap, cnt, stamps);
+        refcos_topk_scan_kernel<<<1, 1024, 0, st>>>(cnt, M, start);
+        refcos_topk_scatter_kernel<<<sweepBlocks, 256, 0, st>>>(hdr1, listK, (uint32_t)cap, start, cnt, sorted);
+        refcos_topk_select_kernel<<<(M + 3) / 4, 256, 0, st>>>(start, sorted, M, k_top, (uint32_t)cap, hdr2, pairs);
+    } else {
+        refcos_keep_kernel<<<keepBlocks, 256, 0, st>>>(hdr1, list1, (uint32_t)cap, thr, hdr2, pairs, stamps);
+    }
     refcos_pairs_kernel<<<std::min<unsigned>((unsigned)((cap + 31) / 32), (unsigned)ctx->num_cus * 16), 256, 0, st>>>(
         src.raw, src.off, src.norm, tgt.raw, tgt.off, tgt.norm, src.dim, dist_dev, 1.0, hdr2, pairs, keys,
         k_top > 1 ? nullptr : bestKey);

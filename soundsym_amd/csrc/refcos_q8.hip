@@ -521,7 +521,19 @@ __global__ __launch_bounds__(CB == 2 ? 256 : 512, 1) void refcos_q8_kernel(
         seenBits[b] = __shfl(seenBits[b], lr);
         cur[b] = fmin(fmin(cur[b], __longlong_as_double((long long)seenBits[b])), 1.7976931348623157e308);
     }
-    if (plain) {
+    // (top-k searches list key_hi beside key_lo: in plain waves both are functions of the z still sitting in klo[], formed
+    //  where they are needed; otherwise z becomes key_lo in place)
+    auto lo_of = [&](int b, int a, int g) -> double {
+        if (TOPK && plain)
+            return fmax(__fma_rn(klo[b][a][g], 1.0 - c9, -Kb[b]) * (1.0 - 4.0 * u), 0.0);
+        return klo[b][a][g];
+    };
+    auto hi_of = [&](int b, int a, int g) -> double {
+        if (plain)
+            return (klo[b][a][g] + __fma_rn(c9, klo[b][a][g] + 2.0 * fabs(ci[b].dist), Cb[b])) * (1.0 + 4.0 * u);
+        return khis[TOPK ? b : 0][TOPK ? a : 0][TOPK ? g : 0];
+    };
+    if (plain && !TOPK) {
 #pragma unroll
         for (int b = 0; b < CB; ++b)
 #pragma unroll
@@ -537,7 +549,7 @@ __global__ __launch_bounds__(CB == 2 ? 256 : 512, 1) void refcos_q8_kernel(
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int g = 0; g < 16; ++g)
-                total += (unsigned)__popcll(__ballot(klo[b][a][g] <= cur[b]));
+                total += (unsigned)__popcll(__ballot(lo_of(b, a, g) <= cur[b]));
     if (total) {
         uint32_t base = 0;
         if (lane == 0)
@@ -549,18 +561,28 @@ __global__ __launch_bounds__(CB == 2 ? 256 : 512, 1) void refcos_q8_kernel(
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int g = 0; g < 16; ++g) {
-                    const bool in = klo[b][a][g] <= cur[b];
+                    const double lo = lo_of(b, a, g);
+                    const bool in = lo <= cur[b];
                     const unsigned long long m = __ballot(in);
                     if (m) {
                         const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
                                                                               __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
                         if (in) {
                             if (pos < cap) {
-                                PairEntry e;
-                                e.s = sTile + wm * 64 + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
-                                e.t = tTile + wn * 32 * CB + b * 32 + lr;
-                                e.key_lo = klo[b][a][g];
-                                list[pos] = e;
+                                if constexpr (TOPK) {
+                                    PairEntryK e;
+                                    e.s = sTile + wm * 64 + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
+                                    e.t = tTile + wn * 32 * CB + b * 32 + lr;
+                                    e.key_lo = lo;
+                                    e.key_hi = hi_of(b, a, g);
+                                    reinterpret_cast<PairEntryK *>(list)[pos] = e;
+                                } else {
+                                    PairEntry e;
+                                    e.s = sTile + wm * 64 + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
+                                    e.t = tTile + wn * 32 * CB + b * 32 + lr;
+                                    e.key_lo = lo;
+                                    list[pos] = e;
+                                }
                             } else {
                                 hdr[1] = 1;
                             }
