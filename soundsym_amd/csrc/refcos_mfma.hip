@@ -601,7 +601,7 @@ __global__ void refcos_topk_scatter_kernel(const uint32_t *__restrict__ hdr1, co
 // one wave per target: the k-th smallest distinct key_hi of its group, then its pairs with key_lo under it -> list 2
 __global__ __launch_bounds__(256) void refcos_topk_select_kernel(const uint32_t *__restrict__ start, const PairEntryK *__restrict__ sorted,
                                                                  uint32_t m, uint32_t kTop, uint32_t cap2, uint32_t *__restrict__ hdr2,
-                                                                 uint2 *__restrict__ pairs)
+                                                                 uint2 *__restrict__ pairs, uint2 *__restrict__ region /* [m]: {first, count} in list 2 */)
 {
     const uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -646,6 +646,19 @@ __global__ __launch_bounds__(256) void refcos_topk_select_kernel(const uint32_t 
         }
     }
     const double thr = prev;
+    // the target's candidates as ONE stretch of list 2 (counted first, reserved once): the final fold reads them back per target
+    uint32_t total = 0;
+    for (uint32_t k0 = lo; k0 < hi; k0 += 64) {
+        const uint32_t k = k0 + lane;
+        const bool keep = k < hi && sorted[k].key_lo <= thr && sorted[k].key_lo < INF;
+        total += (uint32_t)__popcll(__ballot(keep));
+    }
+    uint32_t base = 0;
+    if (lane == 0 && total)
+        base = atomicAdd(&hdr2[0], total);
+    base = __shfl(base, 0);
+    if (lane == 0)
+        region[t] = make_uint2(base, total);
     for (uint32_t k0 = lo; k0 < hi; k0 += 64) {
         const uint32_t k = k0 + lane;
         PairEntryK e{};
@@ -655,12 +668,6 @@ __global__ __launch_bounds__(256) void refcos_topk_select_kernel(const uint32_t 
             keep = e.key_lo <= thr && e.key_lo < INF;
         }
         const unsigned long long mask = __ballot(keep);
-        if (!mask)
-            continue;
-        uint32_t base = 0;
-        if (lane == 0)
-            base = atomicAdd(&hdr2[0], (uint32_t)__popcll(mask));
-        base = __shfl(base, 0);
         const uint32_t pos = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
         if (keep) {
             if (pos < cap2)
@@ -668,6 +675,59 @@ __global__ __launch_bounds__(256) void refcos_topk_select_kernel(const uint32_t 
             else
                 hdr2[1] = 1;
         }
+        base += (uint32_t)__popcll(mask);
+    }
+}
+
+// The k rounds of the first-minimum fold over a target's exactly keyed candidates (one wave per target, its candidates one
+// stretch of list 2): round r takes the smallest (key, index) above round r - 1's -- what k successive at_distance calls
+// would return if each winner left the dictionary (src/sound.rs:361-367; the rules of select.hip's dtw_final_*_kernel, which
+// needed four launches per round).  Keys of +inf (the reference's key was >= 2.0 or NaN) never enter; rows run out into
+// SSYM_NO_MATCH / NaN.
+__global__ __launch_bounds__(256) void refcos_topk_final_kernel(const uint2 *__restrict__ region, const uint2 *__restrict__ pairs,
+                                                                const double *__restrict__ keys, uint32_t m, uint32_t kTop,
+                                                                uint32_t indexBase, uint32_t *__restrict__ outIdx,
+                                                                double *__restrict__ outCost)
+{
+    const uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (t >= m)
+        return;
+    const uint2 rg = region[t];
+    const double INF = __builtin_inf();
+    double prevKey = -1.0;
+    uint32_t prevIdx = 0;
+    bool any = true;
+    for (uint32_t r = 0; r < kTop; ++r) {
+        double bk = INF;
+        uint32_t bi = 0xffffffffu;
+        if (any)
+            for (uint32_t j = lane; j < rg.y; j += 64) {
+                const double key = keys[rg.x + j];
+                const uint32_t idx = pairs[rg.x + j].x;
+                const bool above = r == 0 || key > prevKey || (key == prevKey && idx > prevIdx);
+                if (key < INF && above && (key < bk || (key == bk && idx < bi))) {
+                    bk = key;
+                    bi = idx;
+                }
+            }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const double ok = __shfl_xor(bk, o);
+            const uint32_t oi = __shfl_xor(bi, o);
+            if (ok < bk || (ok == bk && oi < bi)) {
+                bk = ok;
+                bi = oi;
+            }
+        }
+        any = bi != 0xffffffffu;
+        if (lane == 0) {
+            outIdx[(size_t)t * kTop + r] = any ? bi + indexBase : SSYM_NO_MATCH;
+            if (outCost)
+                outCost[(size_t)t * kTop + r] = any ? bk : __builtin_nan("");
+        }
+        prevKey = bk;
+        prevIdx = bi;
     }
 }
 
@@ -866,7 +926,7 @@ int32_t launch_refcos_match_mfma(ssym_ctx *ctx, const SegmentSet &src, const Seg
     if (rc == SSYM_OK && k_top > 1)      // top-k: the entries grouped by target, the groups' counts / cursors and starts
         rc = ensure(ctx, ctx->cmat, sizeof(PairEntryK) * cap);
     if (rc == SSYM_OK && k_top > 1)
-        rc = ensure(ctx, ctx->selcnt, sizeof(uint32_t) * (2 * (size_t)M + 2));
+        rc = ensure(ctx, ctx->selcnt, sizeof(uint32_t) * (4 * (size_t)M + 4));
     if (rc == SSYM_OK)
         rc = ensure(ctx, ctx->cand2, 4 * sizeof(uint32_t) + sizeof(uint2) * cap);
     if (rc == SSYM_OK)
@@ -922,7 +982,8 @@ int32_t launch_refcos_match_mfma(ssym_ctx *ctx, const SegmentSet &src, const Seg
         refcos_topk_count_kernel<<<sweepBlocks, 256, 0, st>>>(hdr1, listK, (uint32_t)cap, cnt, stamps);
         refcos_topk_scan_kernel<<<1, 1024, 0, st>>>(cnt, M, start);
         refcos_topk_scatter_kernel<<<sweepBlocks, 256, 0, st>>>(hdr1, listK, (uint32_t)cap, start, cnt, sorted);
-        refcos_topk_select_kernel<<<(M + 3) / 4, 256, 0, st>>>(start, sorted, M, k_top, (uint32_t)cap, hdr2, pairs);
+        refcos_topk_select_kernel<<<(M + 3) / 4, 256, 0, st>>>(start, sorted, M, k_top, (uint32_t)cap, hdr2, pairs,
+                                                               (uint2 *)(start + M + 2));
     } else {
         refcos_keep_kernel<<<keepBlocks, 256, 0, st>>>(hdr1, list1, (uint32_t)cap, thr, hdr2, pairs, stamps);
     }
@@ -930,12 +991,10 @@ int32_t launch_refcos_match_mfma(ssym_ctx *ctx, const SegmentSet &src, const Seg
         src.raw, src.off, src.norm, tgt.raw, tgt.off, tgt.norm, src.dim, dist_dev, 1.0, hdr2, pairs, keys,
         k_top > 1 ? nullptr : bestKey);
     if (k_top > 1) {
-        // the k rounds of the first-minimum fold over the exactly keyed candidates (select.hip; the keys are the values
-        // it folds and reports: no distance left to subtract)
-        SSYM_HIP_CHECK(ctx, hipGetLastError());
-        rc = launch_dtw_final(ctx, src, tgt, nullptr, (uint32_t)cap, index_base, k_top, out_idx_dev, out_cost_dev);
-        if (rc != SSYM_OK)
-            return rc;
+        // the k rounds of the first-minimum fold over the exactly keyed candidates, per target (the keys are the values it
+        // folds and reports: no distance left to subtract)
+        refcos_topk_final_kernel<<<(M + 3) / 4, 256, 0, st>>>((const uint2 *)((uint32_t *)ctx->selcnt.ptr + 2 * (size_t)M + 2), pairs, keys, M,
+                                                              k_top, index_base, out_idx_dev, out_cost_dev);
         if (tail)
             refcos_pack_tail_kernel<<<1, 64, 0, st>>>(hdr1, hdr2, tail, stamps);
     } else {
