@@ -182,3 +182,52 @@ def test_reference_key_lies_inside_the_integer_filters_interval(length, scale):
             assert klo <= k_ref <= khi, (length, scale, trial, d, dq, d_ref, klo, k_ref, khi)
         if trial == 0 and length >= 100:                            # ~1e-5 of a similarity's scale on ordinary data
             assert extra * np.sqrt(nrm) <= 2e-5, extra * np.sqrt(nrm)
+
+
+def test_column_constants_of_the_integer_filters_short_form_dominate_every_rows_own_bound():
+    """The kernel's plain waves do not form a row's own half-width R but R_ub(z) = c9 (z + 2 |dist|) + C from per-COLUMN
+    constants: the column's numbers against the largest a1..a4 among the wave's 64 rows, and |s| <= z + |dist|
+    (csrc/refcos_q8.hip).  R_ub must be at least every row's R, the threshold it gives at least the smallest key_hi, and
+    the key_lo it gives at most every row's own -- on 64 ragged rows against one column, same operations as the kernel."""
+    import math
+    import bounds
+    rng = np.random.default_rng(4242)
+    c9 = 9.0 * U * 1.0000001
+    for trial in range(6):
+        lens = rng.integers(8, 400, 64)
+        rows = [rng.standard_normal(int(l)) * 10.0 ** rng.uniform(-2, 2) for l in lens]
+        col = rng.standard_normal(int(rng.integers(8, 400))) * 10.0 ** rng.uniform(-2, 2)
+        d = float(rng.uniform(-0.5, 1.5))
+
+        def consts(v):
+            q = bounds.q8_quantise(v)
+            nv = 0.0
+            for x in v:
+                nv = float(np.float64(x) * np.float64(x) + np.float64(nv))
+            inv = float(np.float64(1.0) / np.float64(nv))
+            sq = float(np.sqrt(np.float64(nv))) * (1.0 + 4.5e-16)
+            scl = 2.0 ** -q[3]
+            cl = (3.0 * v.size + 16.0) * (U * 1.02)
+            return dict(q=q, n=nv, inv=inv, a1=q[4] * scl * inv, a2=scl * inv,
+                        a3=math.sqrt(16384.25 * v.size) * (1.0 + 2.0 ** -50) * scl * inv,
+                        a4=math.sqrt(cl) * (1.0 + 2.0 ** -50) * (sq * inv), len=v.size)
+
+        cr = [consts(v) for v in rows]
+        cc = consts(col)
+        m1, m2, m3, m4 = (max(c[k] for c in cr) for k in ("a1", "a2", "a3", "a4"))
+        C = 1.0001 * (m4 * cc["a4"] + (m1 * cc["a2"] + (m2 * cc["a1"] + m3 * cc["a3"]))) + 1e-290
+        K = (2.0 * c9 * abs(d) + C) * (1.0 + 4.0 * U)
+        zs, his, los = [], [], []
+        for v, c in zip(rows, cr):
+            dq, gk, a2b2, extra = bounds.q8_dot_and_extra(c["q"], cc["q"], c["len"], cc["len"], c["inv"], cc["inv"])
+            sv = gk * (c["a2"] * cc["a2"])
+            z = abs(sv - d)
+            R_row = 9.0 * U * (abs(sv) + abs(d)) + 1.0001 * (c["a4"] * cc["a4"] + extra) + 1e-290
+            R_ub = c9 * (z + 2.0 * abs(d)) + C
+            assert R_ub >= R_row, (trial, R_ub, R_row)
+            zs.append(z)
+            his.append((z + R_row) * (1.0 + 4.0 * U))
+            los.append(max((z - R_row) * (1.0 - 4.0 * U), 0.0))
+            assert max((z * (1.0 - c9) - K) * (1.0 - 4.0 * U), 0.0) <= los[-1] + 1e-300
+        zmin = min(zs)
+        assert (zmin + (c9 * (zmin + 2.0 * abs(d)) + C)) * (1.0 + 4.0 * U) >= min(his)
