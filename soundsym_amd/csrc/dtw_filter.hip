@@ -16,6 +16,7 @@
 #include "ssym_internal.hpp"
 #include "dtw_filter_kernel.hpp"
 #include "dtw_filter_pk_kernel.hpp"
+#include "dtw_filter_sp_kernel.hpp"
 #include "dtw_band_kernel.hpp"
 
 #include <algorithm>
@@ -242,6 +243,20 @@ static void launch_one(hipStream_t st, const SegmentSet &src, const SegmentSet &
             (int)tgt.frames_pad, (int)tgt.n_pad, nSrcPairs, nTasks, taskChunk, outScale, handoff, taskCtr, cmat,
             rowOrigin, spBase);
         return;
+    }
+    // single-pass launches without early abandoning: the kernel that pipelines across tasks and skips padding rows
+    // (dtw_filter_sp_kernel.hpp; SSYM_FILTER_SP=0 keeps dtw_filter_kernel for A/B measurements, same bits either way)
+    static const bool spOn = !(getenv("SSYM_FILTER_SP") && atoi(getenv("SSYM_FILTER_SP")) == 0);
+    // (with three operand planes its LDS -- ring and staging block -- admits two workgroups per CU up to two tiles)
+    if constexpr (NT <= 3 && (KU == 2 || NT <= 2)) {
+        if (!abandon && nPasses == 1 && spOn) {
+            constexpr int OCCSP = (NT == 1 && KU == 2) ? 3 : 2;
+            const int gridSp = std::min(gridBlocks / OCC * OCCSP, (blocksWanted + 7) / 8 * 8);
+            dtw_filter_sp_kernel<NT, SQ, OCCSP, KU, kSpRowBlock><<<dim3(gridSp), 64 * kFilterWavesPerBlock, 0, st>>>(
+                (const _Float16 *)src.rec, (const _Float16 *)tgt.rec, src.len, tgt.len, (int)src.frames_pad,
+                (int)tgt.frames_pad, (int)tgt.n_pad, nSrcPairs, nTasks, taskChunk, outScale, taskCtr, cmat, rowOrigin, spBase);
+            return;
+        }
     }
     if (abandon)
         dtw_filter_kernel<NT, SQ, OCC, true, KU><<<dim3(grid), 64 * kFilterWavesPerBlock, 0, st>>>(
