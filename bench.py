@@ -187,6 +187,138 @@ def secondary_metrics(device: int) -> dict:
     return out
 
 
+RAGGED_SEED = 0x5EED0A28          # 4096 x 4096 segments of 5...40 frames: the shape SoundDictionary::add_segments emits
+
+
+def ragged_metrics(device: int) -> dict:
+    """The reference's REAL segment shape (src/sound.rs:330-343: a segment holds seg / HOP frames, seg = letters x 256
+    samples, src/lib.rs:137 -- short and ragged, compared over the common prefix by refcos, src/sound.rs:24-28): 4096 x 4096
+    segments of 5...40 frames, dtw x 13 values f32 and refcos x 12 values f64, plus BASELINE's configs[0] (the reference's
+    two recordings, 284 x 55 segments) end to end.  Rates on TRUE cells (sum of source frames x sum of target frames):
+    the padding the kernels add is reported as a ratio, never counted as work."""
+    from soundsym_amd import Engine, synth
+    from soundsym_amd.engine import pack_segments
+    out = {}
+    n, lo, hi = 4096, 5, 40
+    valu_peak_cells = 1024 * 64 / 16.0 * 2.4e9
+    e = Engine(metric="dtw", dtype="f32", device=device)
+
+    def dtw_leg(src, tgt, planted=None):
+        sf, so = pack_segments(src, 13, np.float32)
+        tf, to = pack_segments(tgt, 13, np.float32)
+        d, q = e.dictionary(sf, so, 13), e.queries(tf, to, 13)
+        for _ in range(5):
+            idx, _ = e.match(d, q)
+        steps, kms, tot = 20, [], []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            idx, _ = e.match(d, q)
+            tmx = e.timings()
+            kms.append(tmx["main_ms"])
+            tot.append(tmx["total_ms"])
+        dt = (time.perf_counter() - t0) / steps
+        true_cells = float(np.diff(so).astype(np.float64).sum()) * float(np.diff(to).astype(np.float64).sum())
+        k_s = float(np.mean(kms)) * 1e-3
+        leg = {"value": n * n / dt, "unit": "segment-pairs/s", "ms_per_step": dt * 1e3,
+               "phase_ms": {k: round(float(v), 3) for k, v in tmx.items() if k.endswith("_ms")},
+               "filter_ms": k_s * 1e3, "filter_launches": int(tmx["main_launches"]),
+               "true_cells_per_s": true_cells / k_s, "true_cells": true_cells,
+               "padded_over_true_cells": tmx["n_filter_cells"] / true_cells if tmx["n_filter_cells"] else None,
+               "pairs_refined_f64": int(tmx["n_refined"]),
+               "valu": {"achieved": true_cells / k_s, "unit": "true DP cells/s", "peak": valu_peak_cells,
+                        "frac": true_cells / k_s / valu_peak_cells,
+                        "note": "16 VALU cycles per cell per SIMD x 1024 SIMDs at 2.4 GHz, as the headline's roofline.valu; "
+                                "cells of the pairs' own matrices only (sum fa x sum fb), over the filter launches' time"}}
+        if planted is not None:
+            leg["indices_equal_planted"] = bool(np.array_equal(idx.astype(np.int64), planted))
+        d.close()
+        q.close()
+        return leg
+
+    src, tgt = synth.make_ragged(n, n, lo, hi, 13, RAGGED_SEED)
+    out["dtw"] = dtw_leg(src, tgt)
+    out["dtw"]["workload"] = (f"{n}x{n} segments of {lo}...{hi} frames x 13 dims, f32, dtw, synth.make_ragged seed "
+                              f"0x{RAGGED_SEED:X}: unrelated targets (the selection's worst case)")
+    srcp, tgtp, pi = synth.make_ragged(n, n, lo, hi, 13, RAGGED_SEED + 1, planted=True)
+    out["dtw_planted"] = dtw_leg(srcp, tgtp, pi)
+    out["dtw_planted"]["workload"] = ("the same shape, every target a source resampled to another length plus noise "
+                                      "(synth.make_ragged planted=True)")
+    e.close()
+
+    r = Engine(metric="refcos", dtype="f64", device=device)
+    src12, tgt12 = synth.make_ragged(n, n, lo, hi, 12, RAGGED_SEED + 2)
+    sf, so = pack_segments([a.astype(np.float64) * 0.05 for a in src12], 12)
+    tf, to = pack_segments([a.astype(np.float64) * 0.05 for a in tgt12], 12)
+    d, q = r.dictionary(sf, so, 12), r.queries(tf, to, 12)
+    for _ in range(3):
+        r.match(d, q)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        r.match(d, q)
+    dt = (time.perf_counter() - t0) / 10
+    tmr = r.timings()
+    out["refcos"] = {"value": n * n / dt, "unit": "segment-pairs/s", "ms_per_step": dt * 1e3,
+                     "workload": f"{n}x{n} segments of {lo}...{hi} frames x 12 dims, f64, the reference's metric over the "
+                                 "common prefix (bit-exact)",
+                     "filter": {0: "none (exact tile kernel)", 1: "f64 matrix pipe", 2: "int8 matrix pipe"}[int(tmr["refcos_filter"])],
+                     "phase_ms": {k: round(float(v), 3) for k, v in tmr.items() if k.endswith("_ms")},
+                     "pairs_rescored_exactly": int(tmr["n_refined"])}
+
+    # BASELINE configs[0]: tests/sample.wav in 16-frame chunks (284) as the dictionary, tests/Section_7_1.wav cut by the 55
+    # labels of tests/vowel.txt as targets (data files of the reference's tests, committed under tests/golden/), features
+    # from ssym_mfcc.  One ssym_match_batch per metric on host targets -- what clone_from_dictionary becomes.
+    feats = config0_features(r)
+    if feats is not None:
+        (sflat, soff), (tflat, toff) = feats
+        leg0 = {"workload": f"configs[0]: {soff.size - 1} x {toff.size - 1} segments of the reference's recordings, 12 MFCCs per frame"}
+        for metric, eng in (("refcos", r), ("dtw", Engine(metric="dtw", dtype="f64", device=device))):
+            d0 = eng.dictionary(sflat, soff, 12)
+            for _ in range(3):
+                eng.match_batch(d0, tflat, toff)
+            t0 = time.perf_counter()
+            for _ in range(20):
+                eng.match_batch(d0, tflat, toff)
+            leg0[metric + "_ms_per_call"] = (time.perf_counter() - t0) / 20 * 1e3
+            d0.close()
+            if eng is not r:
+                eng.close()
+        out["config0"] = leg0
+        out["_config0_feats"] = feats
+    r.close()
+    return out
+
+
+def config0_features(engine):
+    """Features of BASELINE configs[0]'s two recordings (tests/golden/audio): ((source flat, offsets), (target flat, offsets))
+    or None when the fixtures are not there."""
+    from soundsym_amd import io as sio
+    from soundsym_amd.api import HOP, NCOEFFS, frame_features
+    gold = os.path.join(ROOT, "tests", "golden")
+    ps, pt, pl = (os.path.join(gold, "audio", "sample.wav"), os.path.join(gold, "audio", "Section_7_1.wav"),
+                  os.path.join(gold, "vowel.txt"))
+    if not all(os.path.exists(x) for x in (ps, pt, pl)):
+        return None
+    s_smp, srate = sio.read_wav(ps)
+    t_smp, trate = sio.read_wav(pt)
+    sfe = frame_features(s_smp, srate, engine=engine)
+    seg = 16 * HOP
+    lens = [seg] * (s_smp.size // seg)
+    rest = (s_smp.size - sum(lens)) // HOP * HOP
+    lens += [rest] if rest else []
+    sft, fpos = [], 0
+    for L in lens:
+        nf = L // HOP
+        sft.append(sfe[fpos:fpos + nf * NCOEFFS].reshape(nf, NCOEFFS))
+        fpos += nf * NCOEFFS
+    tft = []
+    for a, b, _ in sio.audacity_labels_to_timestamps(pl):
+        piece = t_smp[int(round(a * trate)):int(round(b * trate)) + 1]
+        if piece.size >= HOP:
+            tft.append(frame_features(piece, trate, engine=engine).reshape(-1, NCOEFFS))
+    from soundsym_amd.engine import pack_segments
+    return pack_segments([x for x in sft if x.shape[0] > 0], NCOEFFS), pack_segments(tft, NCOEFFS)
+
+
 def secondary_cpu(out: dict) -> None:
     """refcos as the reference runs it: one thread, norms recomputed per pair (the oracle), on a sub-grid."""
     import oracle as oracle_pkg
@@ -202,6 +334,15 @@ def secondary_cpu(out: dict) -> None:
     dt = time.perf_counter() - t0
     out["refcos"]["cpu_baseline"] = {"value": k * k / dt, "unit": "segment-pairs/s", "cores": 1, "kind": "port",
                                      "sample": f"{k}x{k} sub-grid, single thread as the reference runs it"}
+    feats = out.get("ragged", {}).pop("_config0_feats", None)
+    if feats is not None:          # configs[0] on the host: the oracle, one thread, the same features
+        (sflat, soff), (tflat, toff) = feats
+        t0 = time.perf_counter()
+        o.refcos_match_all(sflat, soff, tflat, toff, 12)
+        t1 = time.perf_counter()
+        o.dtw_match_all(sflat, soff, tflat, toff, 12, nthreads=1)
+        t2 = time.perf_counter()
+        out["ragged"]["config0"]["cpu_oracle_one_thread_ms"] = {"refcos": (t1 - t0) * 1e3, "dtw": (t2 - t1) * 1e3}
 
 
 def main():
@@ -448,6 +589,7 @@ def main():
                               "pack_ms, device time), against the same step on resident targets"}
         secondary = secondary_metrics(local_rank)
         secondary["host_batch"] = host_batch
+        secondary["ragged"] = ragged_metrics(local_rank)
 
     if rank == 0:
         # Roofline of the dominant kernel (dtw_filter_kernel / dtw_band_kernel).  Its duration is measured live
@@ -575,6 +717,7 @@ def main():
         if secondary is not None:
             if not args.no_cpu_baseline:
                 secondary_cpu(secondary)
+            secondary.get("ragged", {}).pop("_config0_feats", None)
             line["secondary"] = secondary
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())

@@ -118,7 +118,8 @@ typedef struct ssym_timings {
     int32_t used_filter;   /* dtw: 1 = MFMA filter + refine, 0 = exact kernel on every pair      */
     float prune_ms;        /* SSYM_DTW_PRUNE: candidate search + exact scores + thresholds        */
     int32_t pruned;        /* 1 = the filter ran with early abandoning                           */
-    uint64_t n_filter_cells; /* pruned runs: DP cells the filter evaluated (padding included)    */
+    uint64_t n_filter_cells; /* dtw, unbanded filter: DP cells it evaluated, padding included (pruned runs: counted by
+                                the kernel; full runs: from the launches' geometry); 0 elsewhere   */
     float collective_ms;   /* ssym_match_sharded: the RCCL all-reduce(s) + all-gather, device time  */
     int32_t attempts;      /* ssym_match_sharded: selection attempts of the step (1 unless a rank's
                               candidate list overflowed and every rank redid the tail)             */

@@ -620,7 +620,7 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
                     return rc;
             }
             tm.pruned = prune ? 1 : 0;
-            tm.main_launches = 1;
+            tm.main_launches = ctx->filter_launches;     // one per class of source lengths (dtw_filter.hip)
             if (phase == 1) {
                 // hand the threshold out: non-negative doubles (or +inf), bit for bit what stage 1 uses
                 slots_to_targets_kernel<<<(M + 255) / 256, 256, 0, st>>>((const double *)ctx->tmin.ptr, tgt.perm, M,
@@ -729,6 +729,8 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
                 }
             }
             tm.main_ms = phase == 2 ? ctx->pending.main_ms : ev_ms(ev[6], ev[1]);
+            if (!tm.pruned && ctx->band < 0)
+                tm.n_filter_cells = ctx->launched_cells * 64ull;      // from the launches' geometry (dtw_filter.hip)
             if (tm.pruned) {
                 tm.prune_ms = phase == 2 ? 0.f : ev_ms(ev[0], ev[6]);
                 tm.n_filter_cells = ctx->pruned_cells * 64ull;

@@ -806,8 +806,10 @@ int32_t match_sharded_step(ssym_ctx *ctx, ssym_comm *comm, const ssym_dict *dict
     *agreed = true;
     stage_finish(ctx);
     if (filterPath) {
-        tm.main_launches = 1;
+        tm.main_launches = ctx->filter_launches;
         tm.main_ms = ev_ms2(ctx->ev[6], ctx->ev[1]);
+        if (!tm.pruned && ctx->band < 0)
+            tm.n_filter_cells = ctx->launched_cells * 64ull;
         if (tm.pruned) {
             tm.n_filter_cells = ctx->pruned_cells * 64ull;
             if (ctx->band < 0) {

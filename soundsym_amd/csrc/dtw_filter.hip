@@ -212,11 +212,45 @@ static int32_t ensure_records(ssym_ctx *ctx, const SegmentSet &set, double scale
     return SSYM_OK;
 }
 
+// DP cells per lane (64 pairs of a task share them) a launch of the unbanded filter evaluates, padding included: per
+// source pair the rows of the passes it runs (dtw_filter_kernel skips leading passes that hold only padding;
+// dtw_filter_sp_kernel skips leading row blocks of `rowBlock` rows), per target group the columns of its longest member
+// (at least `minCols`).  Rows depend on the pair only and columns on the group only, so the sum is a product.
+static unsigned long long launch_cells(const SegmentSet &src, const SegmentSet &tgt, int spBase, int nSrcPairs,
+                                       int rowOrigin, int passRows, int nPasses, int rowBlock, int minCols)
+{
+    auto len = [](const SegmentSet &set, uint32_t slot) -> uint32_t {
+        if (slot >= set.n)
+            return 0u;
+        const uint32_t s = set.h_perm[slot];
+        return (uint32_t)(set.h_off[s + 1] - set.h_off[s]);
+    };
+    unsigned long long rows = 0, cols = 0;
+    for (uint32_t g = 0; g < tgt.n_pad / 32; ++g) {
+        uint32_t m = 0;
+        for (uint32_t t = 0; t < 32; ++t)
+            m = std::max(m, len(tgt, 32 * g + t));
+        cols += rowBlock ? std::max<uint32_t>(m, (uint32_t)minCols) : m;
+    }
+    for (int sp = spBase; sp < spBase + nSrcPairs; ++sp) {
+        const int longer = (int)std::max(len(src, 2u * sp), len(src, 2u * sp + 1u));
+        const int r0min = (int)src.frames_pad - longer;
+        if (rowBlock) {
+            const int sk = std::min(std::max(r0min - rowOrigin, 0), 15) / rowBlock;
+            rows += (unsigned long long)(passRows - sk * rowBlock);
+        } else {
+            const int firstPass = std::min(std::max(r0min - rowOrigin, 0) / passRows, nPasses - 1);
+            rows += (unsigned long long)(nPasses - firstPass) * passRows;
+        }
+    }
+    return rows * cols;
+}
+
 template <int NT, bool SQ, int KU>
 static void launch_one(hipStream_t st, const SegmentSet &src, const SegmentSet &tgt, int nPasses,
                        int gridBlocks, float outScale, float *handoff, unsigned *taskCtr, float *cmat,
                        const float *abandon, unsigned long long *colCtr, const uint32_t *candSlot,
-                       int spBase, int nSrcPairs, int rowOrigin)
+                       int spBase, int nSrcPairs, int rowOrigin, unsigned long long *cellsOut)
 {
     // sources of at most 16 frames (one tile, one pass): three waves per SIMD, see filter_ring() -- 11 %
     // faster there; at 32 frames the gain was within 3 % and cost spills
@@ -255,9 +289,13 @@ static void launch_one(hipStream_t st, const SegmentSet &src, const SegmentSet &
             dtw_filter_sp_kernel<NT, SQ, OCCSP, KU, kSpRowBlock><<<dim3(gridSp), 64 * kFilterWavesPerBlock, 0, st>>>(
                 (const _Float16 *)src.rec, (const _Float16 *)tgt.rec, src.len, tgt.len, (int)src.frames_pad,
                 (int)tgt.frames_pad, (int)tgt.n_pad, nSrcPairs, nTasks, taskChunk, outScale, taskCtr, cmat, rowOrigin, spBase);
+            if (cellsOut)
+                *cellsOut += launch_cells(src, tgt, spBase, nSrcPairs, rowOrigin, 16 * NT, 1, kSpRowBlock, kSpRing);
             return;
         }
     }
+    if (cellsOut && !abandon)
+        *cellsOut += launch_cells(src, tgt, spBase, nSrcPairs, rowOrigin, 16 * NT, nPasses, 0, 0);
     if (abandon)
         dtw_filter_kernel<NT, SQ, OCC, true, KU><<<dim3(grid), 64 * kFilterWavesPerBlock, 0, st>>>(
             (const _Float16 *)src.rec, (const _Float16 *)tgt.rec, src.len, tgt.len, (int)src.frames_pad, nPasses,
@@ -372,6 +410,7 @@ int32_t ensure_filter_records(ssym_ctx *ctx, const SegmentSet &src, const Segmen
 int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt, float *cmat,
                           const float *abandon, unsigned long long *colCtr, const uint32_t *candSlot)
 {
+    ctx->filter_launches = 1;
     if (ctx->band >= 0 && !filter_band_as_bound(ctx, src, tgt))
         return launch_dtw_filter_banded(ctx, src, tgt, cmat, abandon, colCtr, candSlot);
     FilterShape shape = filter_shape((int)src.max_frames);
@@ -416,6 +455,8 @@ int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
     const bool sq = ctx->squared != 0;
     const float outScale = (float)(sq ? 1.0 / (scale * scale) : 1.0 / scale);
     float *hand = (float *)ctx->handoff.ptr;
+    ctx->launched_cells = 0;
+    ctx->filter_launches = 0;
 
     // Record slots are ordered by segment length, so source pairs fall into contiguous CLASSES by the
     // 16-row tiles their longer member needs.  Pairs that fit one, two or three tiles run the single-pass
@@ -453,9 +494,10 @@ int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
     const bool two = filter_mfmas(filter_pieces(filter_dim_used((int)src.dim)), filter_dim_used((int)src.dim)) == 2;
 #define SSYM_LAUNCH1(NT_, SQ_, KU_, PASSES_, ORIGIN_, LO_, HI_, K_)                                               \
     launch_one<NT_, SQ_, KU_>(st, src, tgt, PASSES_, gridBlocks, outScale, hand, taskCtr + (K_) * 8 * kTaskCtrStride, \
-                              cmat, abandon, colCtr, candSlot, LO_, (HI_) - (LO_), ORIGIN_)
+                              cmat, abandon, colCtr, candSlot, LO_, (HI_) - (LO_), ORIGIN_, &ctx->launched_cells)
 #define SSYM_LAUNCH(NT_, PASSES_, ORIGIN_, LO_, HI_, K_)                                                          \
     if ((HI_) > (LO_)) {                                                                                          \
+        ++ctx->filter_launches;                                                                                   \
         if (sq && two) SSYM_LAUNCH1(NT_, true, 2, PASSES_, ORIGIN_, LO_, HI_, K_);                                \
         else if (sq) SSYM_LAUNCH1(NT_, true, 3, PASSES_, ORIGIN_, LO_, HI_, K_);                                  \
         else if (two) SSYM_LAUNCH1(NT_, false, 2, PASSES_, ORIGIN_, LO_, HI_, K_);                                \
@@ -491,3 +533,14 @@ int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
 }
 
 }  // namespace ssym
+
+#ifdef SSYM_SP_PROF
+// tools only: read and clear the single-pass kernel's tick sums (dtw_filter_sp_kernel.hpp)
+extern "C" __attribute__((visibility("default"))) int ssym_debug_sp_prof(unsigned long long *out)
+{
+    unsigned long long zero[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ssym::ssym_sp_prof), sizeof(zero)) != hipSuccess)
+        return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(ssym::ssym_sp_prof), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+#endif

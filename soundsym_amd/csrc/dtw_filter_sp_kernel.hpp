@@ -43,6 +43,19 @@
 
 namespace ssym {
 
+// tools only (-DSSYM_SP_PROF): shader-clock ticks per wave summed into ssym_sp_prof -- [0] waves, [1] whole life of a wave,
+// [2] column loops, [3] task starts (staging reads ... first MFMA), [4] waiting for task-counter grabs, [5] tasks, [6] columns,
+// [7] the first task's operands (nothing to hide them behind), [8] from a wave's start to its first task, [9] from a task's
+// last column to the next task (result store, task bookkeeping), [10] after the last task
+#ifdef SSYM_SP_PROF
+__device__ unsigned long long ssym_sp_prof[12];
+#define SSYM_SP_T(v_) const unsigned long long v_ = __builtin_readcyclecounter()
+#define SSYM_SP_ACC(k_, d_) prof[k_] += (d_)
+#else
+#define SSYM_SP_T(v_)
+#define SSYM_SP_ACC(k_, d_)
+#endif
+
 #ifndef SSYM_SP_ROWBLOCK
 #define SSYM_SP_ROWBLOCK 4
 #endif
@@ -52,12 +65,13 @@ constexpr int sp_slot_bytes(int ku) { return ku * 1024; }      // 64 lanes x KU 
 
 // One column: NT tiles, the first from row R0 (rows above hold padding for both sources of the wave); the next tile's
 // MFMA chain is in flight while a tile's cells run.  Lr = D(., j-1), Lw = D(., j).  Straight-line code.
-template <int NT, bool SQ, int KU, int R0>
+// FIRST: column 0, where D(i, 0) = c(i, 0) + (i == the source's first row ? 0 : D(i - 1, 0)) -- nothing is read from the
+// column before it, so neither column array needs initialising when a task starts (r0rel: the lane's first real row).
+template <int NT, bool SQ, int KU, int R0, bool FIRST>
 __device__ __forceinline__ float dp_column_sp(const half8 (&A)[NT][KU], const half8 (&Bc)[KU], const half8 (&Bn)[KU],
-                                              f32x16 &acc, float diagEnter, const float (&Lr)[NT * 16],
-                                              float (&Lw)[NT * 16])
+                                              f32x16 &acc, int r0rel, const float (&Lr)[NT * 16], float (&Lw)[NT * 16])
 {
-    float up = __builtin_inff(), diag = diagEnter;
+    float up = __builtin_inff(), diag = __builtin_inff();
 #pragma unroll
     for (int T = 0; T < NT; ++T) {
         f32x16 accn;
@@ -70,8 +84,13 @@ __device__ __forceinline__ float dp_column_sp(const half8 (&A)[NT][KU], const ha
             const int idx = T * 16 + r;
             const float x = acc[r];
             const float c = SQ ? __builtin_fabsf(x) : __builtin_amdgcn_sqrtf(__builtin_fabsf(x));
-            const float m = __builtin_fminf(__builtin_fminf(up, diag), Lr[idx]);
-            diag = Lr[idx];
+            float m;
+            if (FIRST) {
+                m = (idx == r0rel) ? 0.0f : up;
+            } else {
+                m = __builtin_fminf(__builtin_fminf(up, diag), Lr[idx]);
+                diag = Lr[idx];
+            }
             const float cur = c + m;
             Lw[idx] = cur;
             up = cur;
@@ -80,6 +99,19 @@ __device__ __forceinline__ float dp_column_sp(const half8 (&A)[NT][KU], const ha
     }
     return up;   // D(last row, j)
 }
+
+// BYTES per lane: (scalar base + the lane's constant offset) -> LDS block l (+ OFF on both sides).  The base is made opaque
+// so that it stays in scalar registers (the optimiser would otherwise fold it into 64-bit vector additions per access).
+// (A macro: as a __device__ function template its inline-asm constraints fail the HOST pass silently, and the kernel's
+// later instantiations lose their launch stubs.)
+#define SSYM_SP_DMA(BASE_, LANEOFF_, LDS_, BYTES_, OFF_)                                                          \
+    do {                                                                                                          \
+        const char *dmaBase_ = (BASE_);                                                                           \
+        asm volatile("" : "+s"(dmaBase_));                                                                        \
+        asm volatile("" : "+v"(LANEOFF_));                                                                        \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(dmaBase_ + (LANEOFF_)), \
+                                         (__attribute__((address_space(3))) void *)(LDS_), BYTES_, OFF_, 0);      \
+    } while (0)
 
 // max over the wave's lanes 0..31 of a non-negative value (the group's longest target): five DPP steps instead of the
 // LDS round trips of a shuffle reduction (gfx9 row_shr / row_bcast), result as a scalar
@@ -108,44 +140,80 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_sp_
     constexpr int SLOT = sp_slot_bytes(KU);
     constexpr int P = 2 + NT * KU;                               // prefetch DMAs per task
     constexpr int kWaitStrict = wait_vmcnt(2 * KU), kWaitRelaxed = wait_vmcnt(2 * KU + P);
-    constexpr unsigned NONE = 0xffffffffu;
     constexpr unsigned kColBytes = kTgtFrameHalfs * 2;           // one frame slot of a target group
     const float INF = __builtin_inff();
+#ifdef SSYM_SP_PROF
+    unsigned long long prof[12] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long profMark = 0;
+    auto prof_flush = [&]() {
+        if ((threadIdx.x & 63) == 0)
+            for (int k = 0; k < 12; ++k)
+                atomicAdd(&ssym_sp_prof[k], prof[k]);
+    };
+#endif
+    SSYM_SP_T(tLife0);
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int col = lane & 31;
     const int half = lane >> 5;
-    unsigned laneOff16 = lane * 16;
     __shared__ __attribute__((aligned(16))) char lds[kFilterWavesPerBlock][sp_wave_lds(NT, KU)];
     char *const myRing = lds[wave];
     char *const myA = myRing + kSpRing * SLOT;
     char *const myLen = myA + NT * KU * 1024;
     const unsigned long long groupBytes = (unsigned long long)tgtFramesPad * kColBytes;
+    const unsigned long long pairBytes = (unsigned long long)srcRows * (2 * REC * 2);        // the two sources of a pair
     const int lastSlot = tgtFramesPad - 1;
+    // per-lane constants of the task's addresses: every access below is (scalar base of the task) + (one of these)
+    unsigned laneOff16 = lane * 16;                                                          // a column's operands
+    unsigned laneA;                                                                          // the lane's A rows in its pair
+    {
+        const int arow = lane & 31;
+        laneA = (unsigned)((((arow >> 2) & 1) * srcRows + rowOrigin + (arow & 3) + 4 * (arow >> 3)) * (REC * 2) + half * 48);
+    }
+    unsigned laneSrcLen = half * 4, laneTgtLen = col * 4;
+    unsigned laneOut = ((unsigned)half * (unsigned)mPad + (unsigned)col) * 4u;               // (mPad < 2^29: n_pad is 32 bits)
 
-    // ---- task sequence: the eight XCD-local counters of dtw_filter_kernel, handed out one task ahead -----------------
-    const unsigned qd = (unsigned)nTasks >> 3, rm = (unsigned)nTasks & 7u;
-    unsigned hop = 0, xcd = 0, rangeLo = 0, rangeLen = 0, gi = 0, giEnd = 0;
+    // ---- task sequence: eight XCD-local counters (workgroups b, b + 8, ... share an XCD), handed out one task ahead.
+    // XCD x owns the target groups x, x + 8, x + 16, ... -- groups are ordered by length, so every XCD gets the same mix
+    // of short and long targets (dtw_filter_kernel's contiguous ranges gave the last XCD eight times the first one's work
+    // on 5...40-frame targets) -- times all source pairs; a range is walked from its END (longest targets and sources
+    // first); a wave whose range is spent helps the next XCD's.  Inside a chunk the walk is a decrement: one division per
+    // grab, none per task.
+    const unsigned nGroups = (unsigned)mPad >> 5;
+    unsigned hop = 0, xcd = 0, rangeLen = 0, chunkLeft = 0;
+    int ctg = 0, csp = 0;                        // the next task of the chunk: target group, source pair of the launch
     auto set_range = [&]() {
         xcd = (blockIdx.x + hop) & 7u;
-        rangeLo = xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd;
-        rangeLen = qd + (xcd < rm ? 1u : 0u);
+        rangeLen = xcd < nGroups ? ((nGroups - xcd + 7u) >> 3) * (unsigned)nSrcPairs : 0u;
     };
     set_range();
-    auto next_task = [&]() -> unsigned {         // linear task id, NONE when every range is spent
+    auto next_task = [&](int &tg, int &sp) -> bool {      // false when every range is spent
         for (;;) {
-            if (gi < giEnd)
-                return rangeLo + (rangeLen - 1u - gi++);
+            if (chunkLeft) {
+                tg = ctg;
+                sp = csp;
+                --chunkLeft;
+                if (--csp < 0) {
+                    csp = nSrcPairs - 1;
+                    ctg -= 8;
+                }
+                return true;
+            }
             if (hop >= 8)
-                return NONE;
+                return false;
+            SSYM_SP_T(tg0);
             unsigned got = 0;
             if (lane == 0)
                 got = atomicAdd(&taskCtr[xcd * kTaskCtrStride], (unsigned)taskChunk);
             got = (unsigned)__builtin_amdgcn_readfirstlane((int)got);
+            SSYM_SP_T(tg1);
+            SSYM_SP_ACC(4, tg1 - tg0);
             if (got < rangeLen) {
-                gi = got;
-                giEnd = min(got + (unsigned)taskChunk, rangeLen);
+                const unsigned i = rangeLen - 1u - got, gl = i / (unsigned)nSrcPairs;
+                chunkLeft = min((unsigned)taskChunk, rangeLen - got);
+                csp = (int)(i - gl * (unsigned)nSrcPairs);
+                ctg = (int)(xcd + 8u * gl);
             } else {
                 ++hop;
                 if (hop < 8)
@@ -153,19 +221,15 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_sp_
             }
         }
     };
-    // frame slot c of the target group at byte offset groupOff -> ring slot of virtual column vcol.  The address is a
-    // scalar base plus the lane's constant 32-bit offset: no vector instruction per column
-    auto stage = [&](unsigned long long groupOff, int c, unsigned vcol) {
-        const char *gb = reinterpret_cast<const char *>(tgtRec) + groupOff + (unsigned long long)min(c, lastSlot) * kColBytes;
-        asm volatile("" : "+s"(gb));              // (opaque: keeps the base out of 64-bit vector additions)
-        asm volatile("" : "+v"(laneOff16));
+    // frame slot c of target group tg -> ring slot of virtual column vcol
+    auto stage = [&](int tg, int c, unsigned vcol) {
+        const char *gb = reinterpret_cast<const char *>(tgtRec) + (unsigned long long)tg * groupBytes +
+                         (unsigned long long)min(c, lastSlot) * kColBytes;
         char *slot = myRing + (vcol & (kSpRing - 1)) * SLOT;
-        const __attribute__((address_space(1))) void *gp = (const __attribute__((address_space(1))) void *)(gb + laneOff16);
-        __attribute__((address_space(3))) void *lp = (__attribute__((address_space(3))) void *)slot;
-        __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(gp, lp, 16, 1024, 0);
+        SSYM_SP_DMA(gb, laneOff16, slot, 16, 0);
+        SSYM_SP_DMA(gb, laneOff16, slot, 16, 1024);
         if (KU == 3)
-            __builtin_amdgcn_global_load_lds(gp, lp, 16, 2048, 0);
+            SSYM_SP_DMA(gb, laneOff16, slot, 16, 2048);
     };
     auto fetch = [&](unsigned vcol, half8 (&B)[KU]) {
         const char *slot = myRing + (vcol & (kSpRing - 1)) * SLOT;
@@ -173,48 +237,48 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_sp_
         for (int m = 0; m < KU; ++m)
             B[m] = *reinterpret_cast<const half8 *>(slot + m * 1024 + lane * 16);
     };
-    auto task_tg = [&](unsigned lin) { return (int)(lin / (unsigned)nSrcPairs); };
-    auto task_sp = [&](unsigned lin) { return spBase + (int)(lin % (unsigned)nSrcPairs); };
     // a task's lengths and source operands -> the staging block (P DMAs)
     auto prefetch = [&](int tg, int sp) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcLen + 2 * sp + half),
-                                         (__attribute__((address_space(3))) void *)myLen, 4, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tgtLen + 32 * tg + col),
-                                         (__attribute__((address_space(3))) void *)(myLen + 256), 4, 0, 0);
-        const int arow = lane & 31;
-        const int a_src = 2 * sp + ((arow >> 2) & 1);
-        const int a_frm = rowOrigin + (arow & 3) + 4 * (arow >> 3);
-        const char *abase = reinterpret_cast<const char *>(srcRec + ((size_t)a_src * srcRows + a_frm) * REC + half * 24);
+        SSYM_SP_DMA(reinterpret_cast<const char *>(srcLen + 2 * (spBase + sp)), laneSrcLen, myLen, 4, 0);
+        SSYM_SP_DMA(reinterpret_cast<const char *>(tgtLen + 32 * tg), laneTgtLen, myLen + 256, 4, 0);
+        const char *pb = reinterpret_cast<const char *>(srcRec) + (unsigned long long)(spBase + sp) * pairBytes;
 #pragma unroll
         for (int T = 0; T < NT; ++T)
 #pragma unroll
             for (int m = 0; m < KU; ++m)
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void *)(abase + (size_t)T * kFilterRowsPerTile * REC * 2 + m * 16),
-                    (__attribute__((address_space(3))) void *)(myA + (T * KU + m) * 1024), 16, 0, 0);
+                SSYM_SP_DMA(pb + T * (kFilterRowsPerTile * REC * 2) + m * 16, laneA, myA + (T * KU + m) * 1024, 16, 0);
     };
 
-    unsigned cur = next_task();
-    if (cur == NONE)
+    int tg, sp, ntg = 0, nsp = 0;
+    if (!next_task(tg, sp)) {
+#ifdef SSYM_SP_PROF
+        prof_flush();
+#endif
         return;
-    unsigned vc = 0;                              // virtual column of the current task's column 0 (ring slot = vc & 3)
-    {   // the first task: nothing to hide its operands behind
-        const int tg = task_tg(cur), sp = task_sp(cur);
-        prefetch(tg, sp);
-#pragma unroll
-        for (int c = 0; c < kSpRing; ++c)
-            stage((unsigned long long)tg * groupBytes, c, (unsigned)c);
     }
-    unsigned nxt = next_task();
-    __builtin_amdgcn_s_waitcnt(wait_vmcnt(0));
+    unsigned vc = 0;                              // virtual column of the current task's column 0 (ring slot = vc & 3)
+    prefetch(tg, sp);                             // the first task: nothing to hide its operands behind
+#pragma unroll
+    for (int c = 0; c < kSpRing; ++c)
+        stage(tg, c, (unsigned)c);
+    bool haveNext = next_task(ntg, nsp);
+    {
+        SSYM_SP_T(tf0);
+        __builtin_amdgcn_s_waitcnt(wait_vmcnt(0));
+        SSYM_SP_T(tf1);
+        SSYM_SP_ACC(7, tf1 - tf0);
+    }
 
     for (;;) {
-        const int tg = task_tg(cur), sp = task_sp(cur);
-        const unsigned nl = nxt == NONE ? cur : nxt;          // (no next task: the prefetches repeat this one, unused)
-        const int ntg = task_tg(nl), nsp = task_sp(nl);
-        const unsigned long long tgtOff = (unsigned long long)tg * groupBytes, nextOff = (unsigned long long)ntg * groupBytes;
-
+        if (!haveNext) {                          // (no next task: the prefetches repeat this one, unused)
+            ntg = tg;
+            nsp = sp;
+        }
         // this task's lengths and source operands: prefetched during the previous task (landed before its column 3)
+        SSYM_SP_T(tTask0);
+#ifdef SSYM_SP_PROF
+        prof[profMark ? 9 : 8] += tTask0 - (profMark ? profMark : tLife0);
+#endif
         asm volatile("" ::: "memory");
         const int fa = *reinterpret_cast<const int *>(myLen + lane * 4);
         const int fb = *reinterpret_cast<const int *>(myLen + 256 + lane * 4);
@@ -226,25 +290,11 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_sp_
                 A[T][m] = *reinterpret_cast<const half8 *>(myA + (T * KU + m) * 1024 + lane * 16);
 
         const int fb_m1 = fb - 1;
-        const int r0 = srcRows - fa;                          // first real row: sources are END-ALIGNED in their slots
+        const int r0rel = srcRows - fa - rowOrigin;           // the lane's first real row: sources are END-ALIGNED in their slots
         // at least a ring's worth of columns: the ring stays in step (columns beyond a target's end read zero records)
         const int nCols = max(wave_max_lo32(fb), kSpRing);
-        const int mk = r0 - 1 - rowOrigin;                    // the lane's marker row: D(r0 - 1, -1) = 0 starts the recurrence
-        const int mk0 = __builtin_amdgcn_readlane(mk, 0), mk1 = __builtin_amdgcn_readlane(mk, 32);
-        const int sk = min(max(min(mk0, mk1) + 1, 0), 15) / G;           // first row block of the first tile with a frame
-        const int rowEnter = rowOrigin + sk * G;
-
-        // D(., -1): +inf, except the marker -- at most two rows of the wave (one per source), found with scalar compares;
-        // a source whose first row is the entry row starts from diagCol0 instead
-        float L0[BR], L1[BR];
-#pragma unroll
-        for (int i = 0; i < BR; ++i) {
-            L0[i] = INF;
-            if (i == mk0 || i == mk1)                         // wave-uniform
-                L0[i] = (i == mk) ? 0.0f : INF;
-            L1[i] = INF;
-        }
-        const float diagCol0 = (r0 == rowEnter) ? 0.0f : INF;
+        const int r0lo = min(__builtin_amdgcn_readlane(r0rel, 0), __builtin_amdgcn_readlane(r0rel, 32));
+        const int sk = min(max(r0lo, 0), 15) / G;             // first row block of the first tile with a frame
 
         // columns 0 and 1 have landed (S(-4), S(-3) of the previous task; younger: S(-2), S(-1), its result store)
         __builtin_amdgcn_s_waitcnt(kWaitStrict);
@@ -259,33 +309,47 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_sp_
         asm volatile("" ::: "memory");
 
         float res = INF;
-        // the column loop, two columns per trip (B0 / B1 and L0 / L1 swap roles), once per first row R0 of the first tile
+        SSYM_SP_T(tCols0);
+        SSYM_SP_ACC(3, tCols0 - tTask0);
+        SSYM_SP_ACC(5, 1);
+        SSYM_SP_ACC(6, (unsigned long long)nCols);
+        // The columns, once per first row R0 of the first tile: column 0, then two columns per trip (B0 / B1 and the column
+        // arrays swap roles).  Column j reads column j + 1 from the ring and stages into the slot column j just left: this
+        // task's column j + 4, or the next task's first columns.
         auto run_columns = [&](auto r0tag) {
             constexpr int R0 = decltype(r0tag)::value;
-            for (int j = 0; j < nCols; j += 2) {
-                {   // even column j: operands in B0, D(., j-1) in L0
-                    if (j == 2)
-                        __builtin_amdgcn_s_waitcnt(kWaitRelaxed);
-                    else if (j != 0)
-                        __builtin_amdgcn_s_waitcnt(kWaitStrict);
-                    asm volatile("" ::: "memory");
-                    fetch(vc + j + 1, B1);
-                    // into the slot column j just left: this task's column j + 4, or the next task's first columns
-                    const bool own = j + kSpRing < nCols;
-                    stage(own ? tgtOff : nextOff, own ? j + kSpRing : j + kSpRing - nCols, vc + j);
-                    const float bottom = dp_column_sp<NT, SQ, KU, R0>(A, B0, B1, acc, (j == 0) ? diagCol0 : INF, L0, L1);
-                    res = (j == fb_m1) ? bottom : res;        // D(fa-1, fb-1)
-                }
-                if (j + 1 < nCols) {                          // odd column j + 1 (wave-uniform)
-                    if (j == 0)
+            float L0[BR], L1[BR];                             // D(., j) for odd / even j; column 0 needs no column before it
+            auto stage_next = [&](int j) {
+                const bool own = j + kSpRing < nCols;
+                stage(own ? tg : ntg, own ? j + kSpRing : j + kSpRing - nCols, vc + j);
+            };
+            {
+                fetch(vc + 1, B1);
+                stage_next(0);
+                const float bottom = dp_column_sp<NT, SQ, KU, R0, true>(A, B0, B1, acc, r0rel, L0, L1);
+                res = (0 == fb_m1) ? bottom : res;            // D(fa-1, fb-1)
+            }
+            for (int j = 1; j < nCols; j += 2) {
+                {   // odd column j: operands in B1, D(., j-1) in L1
+                    if (j == 1)
                         __builtin_amdgcn_s_waitcnt(kWaitRelaxed);
                     else
                         __builtin_amdgcn_s_waitcnt(kWaitStrict);
                     asm volatile("" ::: "memory");
-                    fetch(vc + j + 2, B0);
-                    const bool own = j + 1 + kSpRing < nCols;
-                    stage(own ? tgtOff : nextOff, own ? j + 1 + kSpRing : j + 1 + kSpRing - nCols, vc + j + 1);
-                    const float bottom = dp_column_sp<NT, SQ, KU, R0>(A, B1, B0, acc, INF, L1, L0);
+                    fetch(vc + j + 1, B0);
+                    stage_next(j);
+                    const float bottom = dp_column_sp<NT, SQ, KU, R0, false>(A, B1, B0, acc, 0, L1, L0);
+                    res = (j == fb_m1) ? bottom : res;
+                }
+                if (j + 1 < nCols) {                          // even column j + 1 (wave-uniform)
+                    if (j == 1)
+                        __builtin_amdgcn_s_waitcnt(kWaitRelaxed);
+                    else
+                        __builtin_amdgcn_s_waitcnt(kWaitStrict);
+                    asm volatile("" ::: "memory");
+                    fetch(vc + j + 2, B1);
+                    stage_next(j + 1);
+                    const float bottom = dp_column_sp<NT, SQ, KU, R0, false>(A, B0, B1, acc, 0, L0, L1);
                     res = (j + 1 == fb_m1) ? bottom : res;
                 }
             }
@@ -301,16 +365,39 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_sp_
             SSYM_SP_CASE(4) SSYM_SP_CASE(5) SSYM_SP_CASE(6) SSYM_SP_CASE(7)
         }
 #undef SSYM_SP_CASE
-        cmat[(size_t)(2 * sp + half) * mPad + 32 * tg + col] = res * outScale;
-        if (nxt == NONE)
+        {
+            SSYM_SP_T(tCols1);
+            SSYM_SP_ACC(2, tCols1 - tCols0);
+#ifdef SSYM_SP_PROF
+            profMark = tCols1;
+#endif
+        }
+        {   // the result: (scalar base of the task) + (the lane's constant offset)
+            char *ob = reinterpret_cast<char *>(cmat) + ((unsigned long long)(2 * (spBase + sp)) * (unsigned)mPad + 32u * (unsigned)tg) * 4ull;
+            asm volatile("" : "+s"(ob));
+            asm volatile("" : "+v"(laneOut));
+            *reinterpret_cast<float *>(ob + laneOut) = res * outScale;
+        }
+        if (!haveNext)
             break;
         // the next task becomes the current one
         vc += (unsigned)nCols;
-        cur = nxt;
-        nxt = next_task();
+        tg = ntg;
+        sp = nsp;
+        haveNext = next_task(ntg, nsp);
     }
     // (the last task's stages of "next" columns are still in flight: they must have landed before the LDS is released)
     __builtin_amdgcn_s_waitcnt(wait_vmcnt(0));
+#ifdef SSYM_SP_PROF
+    {
+        SSYM_SP_T(tLife1);
+        SSYM_SP_ACC(1, tLife1 - tLife0);
+        SSYM_SP_ACC(10, tLife1 - profMark);
+        prof_flush();
+    }
+#endif
 }
 
 }  // namespace ssym
+
+#undef SSYM_SP_DMA

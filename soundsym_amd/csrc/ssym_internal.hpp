@@ -148,6 +148,8 @@ struct ssym_ctx {
     hipEvent_t ev[10]{};        // 0-6: phases of a match; 8-9: ssym_match_batch's pack
     float prune_swept = 1.f;               // share of the filter's cells the last pruned call swept (picks the pass height)
     unsigned long long pruned_cells = 0;   // SSYM_DTW_PRUNE: the filter's counter of the last call (host copy)
+    int filter_launches = 1;               // kernel launches of the last dtw filter call (one per class of source lengths)
+    unsigned long long launched_cells = 0; // unbanded filter without early abandoning: DP cells (per lane) of the last call's launches, padding included
     // set by ssym_match_batch / ssym_match_one around their internal pack: the call synchronises
     // once at its end, so the pack stages need not wait for their copies individually
     bool defer_sync = false;

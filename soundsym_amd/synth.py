@@ -156,12 +156,28 @@ def make_grid(n_src: int, n_tgt: int, frames: int, dim: int, seed: int,
     return Grid(x.astype(np.float32), y.astype(np.float32), planted.astype(np.int64), frames, dim)
 
 
-def make_ragged(n_src: int, n_tgt: int, min_frames: int, max_frames: int, dim: int, seed: int):
-    """Variable-length segments (the reference's real shape): lists of [f_i, d]."""
+def make_ragged(n_src: int, n_tgt: int, min_frames: int, max_frames: int, dim: int, seed: int, planted: bool = False):
+    """Variable-length segments (the reference's real shape, SURVEY.md D4: add_segments gives a segment seg / HOP frames,
+    src/sound.rs:330-343): lists of [f_i, d] arrays, lengths uniform in [min_frames, max_frames].
+
+    planted=False: sources and targets are unrelated (no target has a close source: the selection's worst case).
+    planted=True: target t is source pi(t) resampled to a length within two frames of the source's (nearest frame along
+    a straight warping line) plus noise 0.05 * sigma_k -- a planted neighbour of a different length; returns
+    (src, tgt, pi).  (Frames here are independent draws, so a resampling to a very different length would leave whole
+    frames unmatched and a short unrelated source could cost less: DTW costs grow with the path.)"""
     st = Stream(seed)
     sig = sigma(dim)
     ls = min_frames + st.integers(n_src, max_frames - min_frames + 1)
     lt = min_frames + st.integers(n_tgt, max_frames - min_frames + 1)
     src = [(st.normal(int(f) * dim).reshape(int(f), dim) * sig).astype(np.float32) for f in ls]
-    tgt = [(st.normal(int(f) * dim).reshape(int(f), dim) * sig).astype(np.float32) for f in lt]
-    return src, tgt
+    if not planted:
+        tgt = [(st.normal(int(f) * dim).reshape(int(f), dim) * sig).astype(np.float32) for f in lt]
+        return src, tgt
+    pi = st.permutation(n_src)[:n_tgt] if n_tgt <= n_src else st.integers(n_tgt, n_src)
+    lt = np.clip(ls[pi] + (lt % 5) - 2, min_frames, max_frames)
+    tgt = []
+    for t in range(n_tgt):
+        a, f = src[int(pi[t])], int(lt[t])
+        rows = np.rint(np.linspace(0.0, a.shape[0] - 1.0, f)).astype(np.int64)
+        tgt.append((a[rows].astype(np.float64) + st.normal(f * dim).reshape(f, dim) * (0.05 * sig)).astype(np.float32))
+    return src, tgt, pi.astype(np.int64)

@@ -208,3 +208,62 @@ def test_config4_eight_ranks_through_ssym_match_sharded(dtw):
         assert tm["attempts"] == 1 and tm["used_filter"] == 1
         refined += tm["n_refined"]
     assert refined <= 3 * m, refined
+
+
+# --- the reference's real segment shape: 4096 x 4096 ragged segments of 5...40 frames (bench.py secondary.ragged) -----
+
+def _ragged_pick(src, tgt, pick, dim, dtype):
+    from soundsym_amd.engine import pack_segments
+    sf, so = pack_segments(src, dim, dtype)
+    tf, to = pack_segments(tgt, dim, dtype)
+    ts, tos = pack_segments([tgt[i] for i in pick], dim, dtype)
+    return (sf, so), (tf, to), (ts, tos)
+
+
+@pytest.mark.parametrize("planted", [False, True])
+def test_ragged_4096x4096_dtw(dtw, oracle, planted):
+    """SoundDictionary::add_segments emits segments of seg / HOP frames (src/sound.rs:330-343, src/lib.rs:137): short
+    and ragged.  The full-size ragged grid of bench.py's secondary.ragged through the filter path (one launch per
+    class of source lengths on dtw_filter_sp_kernel), 16 sampled targets against the oracle over all 4096 sources,
+    run-to-run identical; the same search with SSYM_FILTER_SP=0 semantics is covered by test_gpu_numerics."""
+    import bench
+    if planted:
+        src, tgt, pi = synth.make_ragged(4096, 4096, 5, 40, 13, bench.RAGGED_SEED + 1, planted=True)
+    else:
+        src, tgt = synth.make_ragged(4096, 4096, 5, 40, 13, bench.RAGGED_SEED)
+    pick = np.arange(7, 4096, 256)
+    (sf, so), (tf, to), (ts, tos) = _ragged_pick(src, tgt, pick, 13, np.float32)
+    d, q = dtw.dictionary(sf, so, 13), dtw.queries(tf, to, 13)
+    idx, cost = dtw.match(d, q)
+    tm = dtw.timings()
+    assert tm["used_filter"] == 1 and tm["n_pairs"] == 4096 * 4096 and tm["main_launches"] == 3
+    true_cells = float(np.diff(so).astype(np.float64).sum()) * float(np.diff(to).astype(np.float64).sum())
+    assert true_cells <= tm["n_filter_cells"] <= 1.35 * true_cells      # padding: row blocks of 4, a group's longest target
+    idx2, cost2 = dtw.match(d, q)
+    assert np.array_equal(idx, idx2) and np.array_equal(cost, cost2)    # run-to-run identical
+    if planted:
+        assert np.array_equal(idx.astype(np.int64), pi)
+    want_idx, want_cost = oracle.dtw_match_all(sf.astype(np.float64), so, ts.astype(np.float64), tos, 13, nthreads=16)
+    assert np.array_equal(idx[pick], want_idx)
+    assert np.allclose(cost[pick], want_cost, rtol=1e-5, atol=0)        # the north star's tolerance
+    assert np.allclose(cost[pick], want_cost, rtol=1e-12, atol=0)       # what the exact re-scoring delivers
+
+
+def test_ragged_4096x4096_refcos(oracle):
+    """The reference's own metric on the same shape (12 values per frame, f64, the dot over the common prefix,
+    src/sound.rs:24-31): indices and values bit for bit against the oracle for 16 sampled targets, run-to-run identical."""
+    import bench
+    src, tgt = synth.make_ragged(4096, 4096, 5, 40, 12, bench.RAGGED_SEED + 2)
+    src = [a.astype(np.float64) * 0.05 for a in src]
+    tgt = [a.astype(np.float64) * 0.05 for a in tgt]
+    pick = np.arange(3, 4096, 256)
+    (sf, so), (tf, to), (ts, tos) = _ragged_pick(src, tgt, pick, 12, np.float64)
+    r = Engine(metric="refcos", dtype="f64")
+    d, q = r.dictionary(sf, so, 12), r.queries(tf, to, 12)
+    idx, val = r.match(d, q)
+    assert r.timings()["used_filter"] == 1
+    idx2, val2 = r.match(d, q)
+    assert np.array_equal(idx, idx2) and np.array_equal(val, val2)
+    want_idx, want_val = oracle.refcos_match_all(sf, so, ts, tos, 12)
+    assert np.array_equal(idx[pick], want_idx) and np.array_equal(val[pick], want_val)
+    r.close()
