@@ -362,7 +362,19 @@ def main():
     ap.add_argument("--frames", type=int, default=0)
     ap.add_argument("--dim", type=int, default=0)
     ap.add_argument("--band", type=int, default=None, help="Sakoe-Chiba radius, -1 = none")
+    ap.add_argument("--replay-world", type=int, default=0,
+                    help="MEASUREMENT on one GPU: the step rank --replay-rank of a run over this many GPUs would make -- its "
+                         "shard of the sources through ssym_match_sharded on a world-1 RCCL communicator, with the bounds of the "
+                         "FULL dictionary (what the larger run's all-reduce returns) replayed into the bound exchange "
+                         "(ssym_comm_replay_bounds), so that selection and re-scoring see what that rank would see")
+    ap.add_argument("--replay-rank", type=int, default=0)
     args = ap.parse_args()
+    if args.replay_world:
+        if args.gpus != 1 or not (0 <= args.replay_rank < args.replay_world):
+            sys.exit("--replay-world G needs --gpus 1 and 0 <= --replay-rank < G")
+        os.environ["SSYM_BENCH_FORCE_DIST"] = "1"
+        os.environ["SSYM_TEST_HOOKS"] = "1"
+        args.no_secondary = args.no_cpu_baseline = True
     wl = dict(WORKLOADS[args.workload])
     custom = []
     for key, val in (("n_src", args.sources), ("n_tgt", args.targets), ("frames", args.frames), ("dim", args.dim)):
@@ -435,7 +447,9 @@ def main():
     # synthetic workload (seeded; the generator is counter-based, so each rank materialises only its
     # own source shard of the one global grid -- the targets and planted indices are the same on all)
     lo, hi = sharding.shard_range(n_src_total, n_gpus, rank)
-    if n_gpus > 1:
+    if args.replay_world:
+        lo, hi = sharding.shard_range(n_src_total, args.replay_world, args.replay_rank)
+    if n_gpus > 1 or args.replay_world:
         grid = synth.make_grid(n_src_total, m, frames, DIM_, SEED, src_range=(lo, hi))
         shard = grid.sources
     else:
@@ -468,6 +482,23 @@ def main():
             ok = int(t.item())
         if ok:
             comm = sharding.init_comm(eng, rank, world)
+
+    replay = None
+    if args.replay_world:
+        if comm is None:
+            sys.exit("--replay-world needs the library's RCCL communicator")
+        # the bounds of the FULL dictionary: the minimum over the shards' offers, i.e. the larger run's all-reduce result
+        full = synth.make_grid(n_src_total, m, frames, DIM_, SEED)
+        dfull = eng.dictionary(torch.from_numpy(np.ascontiguousarray(full.sources).reshape(-1)).cuda(),
+                               np.arange(n_src_total + 1, dtype=np.uint64) * frames, DIM_)
+        replay = torch.empty(m, dtype=torch.float64, device="cuda")
+        eng.match_begin(dfull, q, replay)
+        tmp_i, tmp_c = torch.empty_like(out_idx), torch.empty_like(out_cost)
+        eng.match_finish(replay.clone(), tmp_i, tmp_c)           # (a begun match has to be finished)
+        torch.cuda.synchronize()
+        dfull.close()
+        del full
+        comm.replay_bounds(replay)
 
     def run_step(oi, oc, prune=False, queries=None):
         qq = q if queries is None else queries
@@ -512,10 +543,13 @@ def main():
         last.update(tm)
 
     elapsed, (fin_idx, fin_cost) = timed(lambda: run_step(out_idx, out_cost), args.steps, args.warmup, note)
-    pairs_per_step = n_src_total * m
+    pairs_per_step = (hi - lo) * m if args.replay_world else n_src_total * m
     value = pairs_per_step * args.steps / elapsed
     idx_host = fin_idx.cpu().numpy().view(np.uint32).astype(np.int64)
     planted_ok = bool(np.array_equal(idx_host, grid.planted))
+    if args.replay_world:      # one rank of a larger world: it answers the targets whose neighbour its shard holds
+        mine = (grid.planted >= lo) & (grid.planted < hi)
+        planted_ok = bool(np.array_equal(idx_host[mine], grid.planted[mine]))
 
     # per-rank figures of the timed steps (rank 0 prints them)
     mine = [float(np.mean(stats[k])) for k in ("main_ms", "select_ms", "refine_ms", "collective_ms", "total_ms")] + \
@@ -653,6 +687,11 @@ def main():
                                 (f"source-shard x{n_gpus}, {backend} collectives of torch.distributed around the two-phase "
                                  f"C-ABI calls" if sharded else "single GPU")),
                 "indices_equal_planted": planted_ok,
+                "replay": ({"world": args.replay_world, "rank": args.replay_rank,
+                            "note": "ONE GPU: this rank's shard through ssym_match_sharded (world-1 RCCL) with the full "
+                                    "dictionary's bounds replayed into the bound exchange; `value` counts this shard's pairs "
+                                    "only; a measurement for the strong-scaling prediction, not a multi-GPU result"}
+                           if args.replay_world else None),
                 "pairs_refined_f64": int(last.get("n_refined", 0)),
                 "phase_ms": {k: round(float(np.mean(v)), 3) for k, v in stats.items()},
                 "collective_ms": round(float(np.mean(stats["collective_ms"])), 4),

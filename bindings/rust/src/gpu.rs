@@ -138,7 +138,9 @@ extern "C" {
     pub fn ssym_comm_available() -> i32;
     pub fn ssym_comm_set_timeout(comm: *mut SsymComm, milliseconds: i64) -> i32;
     pub fn ssym_comm_is_dead(comm: *const SsymComm) -> i32;
+    // test and measurement hooks: refuse (SSYM_E_UNSUPPORTED) unless the process runs with SSYM_TEST_HOOKS=1
     pub fn ssym_comm_inject_fault(comm: *mut SsymComm, phase: i32, kind: i32) -> i32;
+    pub fn ssym_comm_replay_bounds(comm: *mut SsymComm, bounds_dev: *const f64, n: u32) -> i32;
     pub fn ssym_local_group_create(world: i32, out: *mut *mut SsymLocalGroup) -> i32;
     pub fn ssym_local_group_destroy(group: *mut SsymLocalGroup) -> i32;
     pub fn ssym_comm_create_local(ctx: *mut SsymCtx, group: *mut SsymLocalGroup, rank: i32, out: *mut *mut SsymComm) -> i32;

@@ -339,11 +339,20 @@ SSYM_API int32_t ssym_comm_available(void);
 SSYM_API int32_t ssym_comm_set_timeout(ssym_comm *comm, int64_t milliseconds);
 /* 1 = the communicator was aborted (every call on it fails with SSYM_E_COMM), 0 = usable. */
 SSYM_API int32_t ssym_comm_is_dead(const ssym_comm *comm);
-/* Fault injection for the containment tests (tests/test_gpu_comm.py), one shot: the NEXT ssym_match_sharded on this
+/* TEST AND MEASUREMENT HOOKS.  Both refuse with SSYM_E_UNSUPPORTED unless the calling process has SSYM_TEST_HOOKS=1 in its
+ * environment at the time of the call: nothing a production caller can trip over.
+ *
+ * Fault injection for the containment tests (tests/test_gpu_comm.py), one shot: the NEXT ssym_match_sharded on this
  * communicator fails in `phase` (1 = the filter phase before the bound exchange, 2 = selection / re-scoring before the
  * gather).  kind 0: the local work reports SSYM_E_NOMEM (the rank takes part, every rank returns SSYM_E_NOMEM);
  * kind 1: the rank leaves the step there without its collectives (its peers meet the deadline). */
 SSYM_API int32_t ssym_comm_inject_fault(ssym_comm *comm, int32_t phase, int32_t kind);
+/* Replay of a larger world on one GPU (bench.py --replay-world): from now on the per-target bounds every
+ * ssym_match_sharded step agrees on are the element-wise minimum of the all-reduce's result and these `n` device doubles
+ * -- the bounds ssym_match_begin returns for the FULL dictionary are exactly what the ranks of a run over its shards
+ * would have all-reduced -- so that a one-rank step on one shard selects and re-scores what that rank would in the
+ * larger run.  The buffer stays the caller's and must outlive the steps; n = the steps' number of targets; NULL clears. */
+SSYM_API int32_t ssym_comm_replay_bounds(ssym_comm *comm, const double *bounds_dev, uint32_t n);
 
 /* The ranks of ONE process (a thread per rank, every rank its own context, on one GPU or several) without RCCL:
  * the same ssym_match_sharded, its two exchanges done with host barriers around device copies instead of

@@ -47,7 +47,7 @@ ABI_SYMBOLS = [
     "ssym_samples_destroy", "ssym_reconstruct", "ssym_mfcc_num_frames", "ssym_mfcc",
     "ssym_comm_unique_id", "ssym_comm_create", "ssym_comm_destroy", "ssym_match_sharded",
     "ssym_local_group_create", "ssym_local_group_destroy", "ssym_comm_create_local",
-    "ssym_comm_available", "ssym_comm_set_timeout", "ssym_comm_is_dead", "ssym_comm_inject_fault",
+    "ssym_comm_available", "ssym_comm_set_timeout", "ssym_comm_is_dead", "ssym_comm_inject_fault", "ssym_comm_replay_bounds",
 ]
 COMM_ID_BYTES = 128        # SSYM_COMM_ID_BYTES
 
@@ -260,6 +260,8 @@ def lib() -> ctypes.CDLL:
     L.ssym_comm_is_dead.argtypes = [vp]
     L.ssym_comm_inject_fault.restype = i32
     L.ssym_comm_inject_fault.argtypes = [vp, i32, i32]
+    L.ssym_comm_replay_bounds.restype = i32
+    L.ssym_comm_replay_bounds.argtypes = [vp, vp, ctypes.c_uint32]
     _lib = L
     return L
 

@@ -150,6 +150,8 @@ struct ssym_comm {
     bool dead = false;                  // aborted: every further call answers SSYM_E_COMM
     int64_t timeout_ms = 60000;         // deadline of one step (ssym_comm_set_timeout, $SSYM_COMM_TIMEOUT_MS)
     int fault_phase = 0, fault_kind = 0;   // ssym_comm_inject_fault, one shot
+    const double *replay_bounds = nullptr; // ssym_comm_replay_bounds: joins every bound exchange as one more rank's offer
+    uint32_t replay_n = 0;
     hipEvent_t ev[8]{};    // 0-1 all-reduce of the candidates' costs, 2-3 of the bounds, 4 step start, 5-6 all-gather, 7 step end
 };
 
@@ -197,6 +199,14 @@ static float ev_ms2(hipEvent_t a, hipEvent_t b)
 {
     float ms = 0.f;
     return hipEventElapsedTime(&ms, a, b) == hipSuccess ? ms : 0.f;
+}
+
+// out[i] = min(out[i], other[i]): the replayed bounds of a larger world join the exchange (ssym_comm_replay_bounds)
+__global__ void comm_min_with_kernel(double *__restrict__ out, const double *__restrict__ other, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        out[i] = fmin(out[i], other[i]);
 }
 
 __global__ void comm_min_rows_kernel(const double *__restrict__ rows, int nRows, uint32_t n, double *__restrict__ out)
@@ -458,10 +468,31 @@ int32_t ssym_comm_is_dead(const ssym_comm *comm)
     return comm ? (comm->dead ? 1 : 0) : SSYM_E_INVALID;
 }
 
+// The two hooks below exist for tests and measurements; a process has to ask for them (SSYM_TEST_HOOKS=1 in its
+// environment when the call is made), otherwise they refuse.
+static bool test_hooks_enabled()
+{
+    const char *e = getenv("SSYM_TEST_HOOKS");
+    return e && atoi(e) != 0;
+}
+
+int32_t ssym_comm_replay_bounds(ssym_comm *comm, const double *bounds_dev, uint32_t n)
+{
+    if (!comm || (bounds_dev && n == 0))
+        return SSYM_E_INVALID;
+    if (!test_hooks_enabled())
+        return SSYM_E_UNSUPPORTED;
+    comm->replay_bounds = bounds_dev;
+    comm->replay_n = bounds_dev ? n : 0;
+    return SSYM_OK;
+}
+
 int32_t ssym_comm_inject_fault(ssym_comm *comm, int32_t phase, int32_t kind)
 {
     if (!comm || phase < 0 || phase > 2 || kind < 0 || kind > 1)
         return SSYM_E_INVALID;
+    if (!test_hooks_enabled())
+        return SSYM_E_UNSUPPORTED;
     comm->fault_phase = phase;
     comm->fault_kind = kind;
     return SSYM_OK;
@@ -669,6 +700,14 @@ int32_t match_sharded_step(ssym_ctx *ctx, ssym_comm *comm, const ssym_dict *dict
     rc = comm_all_reduce_min(ctx, comm, bounds, M);
     if (rc != SSYM_OK)
         return rc;
+    if (comm->replay_bounds) {       // measurement hook: the bounds the ranks of a larger world would have agreed on
+        if (comm->replay_n != M) {
+            ctx->err = "ssym_match_sharded: ssym_comm_replay_bounds holds bounds for another number of targets";
+            return SSYM_E_INVALID;
+        }
+        comm_min_with_kernel<<<(M + 255) / 256, 256, 0, st>>>(bounds, comm->replay_bounds, M);
+        SSYM_HIP_CHECK(ctx, hipGetLastError());
+    }
     SSYM_HIP_CHECK(ctx, hipEventRecord(cev[3], st));
 
     // ---- phase 2 + exchange; repeated once by EVERY rank when any rank's candidate list overflowed -----------

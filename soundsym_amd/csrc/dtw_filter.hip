@@ -284,7 +284,10 @@ static void launch_one(hipStream_t st, const SegmentSet &src, const SegmentSet &
     // (with three operand planes its LDS -- ring and staging block -- admits two workgroups per CU up to two tiles)
     if constexpr (NT <= 3 && (KU == 2 || NT <= 2)) {
         if (!abandon && nPasses == 1 && spOn) {
-            constexpr int OCCSP = (NT == 1 && KU == 2) ? 3 : 2;
+#ifndef SSYM_SP_OCC_NT2
+#define SSYM_SP_OCC_NT2 2        // tools: 3 = two-tile tasks at three waves per SIMD (168 registers: four spilled)
+#endif
+            constexpr int OCCSP = (NT == 1 && KU == 2) ? 3 : (NT == 2 && KU == 2) ? SSYM_SP_OCC_NT2 : 2;
             const int gridSp = std::min(gridBlocks / OCC * OCCSP, (blocksWanted + 7) / 8 * 8);
             dtw_filter_sp_kernel<NT, SQ, OCCSP, KU, kSpRowBlock><<<dim3(gridSp), 64 * kFilterWavesPerBlock, 0, st>>>(
                 (const _Float16 *)src.rec, (const _Float16 *)tgt.rec, src.len, tgt.len, (int)src.frames_pad,

@@ -86,6 +86,15 @@ class Comm:
         reports an error and the rank takes part, kind 1 = the rank leaves the step without its collectives."""
         nat.check(nat.lib().ssym_comm_inject_fault(self.ptr, phase, kind), self.engine.ctx)
 
+    def replay_bounds(self, bounds) -> None:
+        """ssym_comm_replay_bounds (measurement hook, needs SSYM_TEST_HOOKS=1): a device tensor of per-target bounds
+        (f64, one per target) that joins every following step's bound exchange; None clears.  The tensor is kept alive."""
+        self._replay = bounds
+        if bounds is None:
+            nat.check(nat.lib().ssym_comm_replay_bounds(self.ptr, None, 0), self.engine.ctx)
+        else:
+            nat.check(nat.lib().ssym_comm_replay_bounds(self.ptr, bounds.data_ptr(), int(bounds.numel())), self.engine.ctx)
+
     def close(self):
         if self.ptr and self.engine.ctx:
             nat.lib().ssym_comm_destroy(self.engine.ctx, self.ptr)

@@ -11,6 +11,10 @@ if HERE not in sys.path:
     sys.path.insert(0, HERE)          # tests/bounds.py
 
 
+# the library's test hooks (ssym_comm_inject_fault, ssym_comm_replay_bounds) answer only to a process that asks for them
+os.environ.setdefault("SSYM_TEST_HOOKS", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

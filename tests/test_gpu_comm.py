@@ -439,6 +439,52 @@ def test_world1_rccl_fault_injection_and_abort():
     e.close()
 
 
+def test_test_hooks_need_the_environment_and_replayed_bounds_cut_the_rescoring(monkeypatch):
+    """ssym_comm_inject_fault / ssym_comm_replay_bounds answer only to a process with SSYM_TEST_HOOKS=1; with the FULL
+    dictionary's bounds replayed, a one-rank step on a shard that lacks most targets' neighbours re-scores (almost)
+    nothing for them and still returns the shard's own answer (what bench.py --replay-world measures)."""
+    torch = pytest.importorskip("torch")
+    from soundsym_amd import _native as nat
+    n, m, f, dim = 512, 256, 24, 13
+    g = synth.make_grid(n, m, f, dim, 0x5EED0A73)
+    e = Engine(metric="dtw", dtype="f32")
+    d, q = _grid_sets(e, g, f, dim)
+    comm = sharding.init_comm(e, 0, 1)
+    monkeypatch.delenv("SSYM_TEST_HOOKS", raising=False)
+    with pytest.raises(nat.SsymError) as ei:
+        comm.inject_fault(1, 0)
+    assert ei.value.code == nat.SSYM_E_UNSUPPORTED
+    with pytest.raises(nat.SsymError) as ei:
+        comm.replay_bounds(torch.zeros(m, dtype=torch.float64, device="cuda"))
+    assert ei.value.code == nat.SSYM_E_UNSUPPORTED
+    monkeypatch.setenv("SSYM_TEST_HOOKS", "1")
+    # the bounds of the full dictionary = what the ranks of a run over its shards would all-reduce
+    full_bounds = torch.empty(m, dtype=torch.float64, device="cuda")
+    e.match_begin(d, q, full_bounds)
+    fi, fc = torch.empty(m, dtype=torch.int32, device="cuda"), torch.empty(m, dtype=torch.float64, device="cuda")
+    e.match_finish(full_bounds.clone(), fi, fc)
+    # a shard: the first quarter of the sources
+    sf, so = g.flat("sources")
+    k = n // 4
+    ds = e.dictionary(sf[:k * f * dim], so[:k + 1], dim)
+    own_idx, own_cost = sharding.match_sharded(e, comm, ds, q, 0)
+    plain = e.timings()["n_refined"]
+    comm.replay_bounds(full_bounds)
+    r_idx, r_cost = sharding.match_sharded(e, comm, ds, q, 0)
+    replayed = e.timings()["n_refined"]
+    assert replayed < plain and replayed <= plain // 2, (plain, replayed)
+    # targets whose neighbour lives in the shard keep their answer; the others report the fold start (+inf: cannot win)
+    mine = g.planted < k
+    assert np.array_equal(r_idx[mine], own_idx[mine]) and np.array_equal(r_cost[mine], own_cost[mine])
+    assert np.all(np.isinf(r_cost[~mine]) | (r_idx[~mine] == own_idx[~mine]))
+    with pytest.raises(nat.SsymError):
+        comm.replay_bounds(torch.zeros(m + 1, dtype=torch.float64, device="cuda"))
+        sharding.match_sharded(e, comm, ds, q, 0)
+    comm.replay_bounds(None)
+    comm.close()
+    e.close()
+
+
 def test_library_communicator_beside_a_torch_nccl_process_group():
     """The process shape of a bench.py rank at N > 1: torch.distributed's "nccl" group initialised and used first,
     then the library's communicator, then both in turn (tools/rccl_beside_torch.py, its own process because a
