@@ -38,7 +38,8 @@ int filter_pieces(int dim)
 __global__ void build_filter_records_kernel(const double *__restrict__ raw, const uint64_t *__restrict__ off,
                                             const uint32_t *__restrict__ perm, uint32_t n, uint32_t dim,
                                             uint32_t dimUse, uint32_t frames_pad, int is_source,
-                                            int lead, int pieces, double scale, _Float16 *__restrict__ rec)
+                                            int lead, int pieces, double scale, _Float16 *__restrict__ rec,
+                                            unsigned *__restrict__ resid)
 {
     const uint32_t s = blockIdx.y;                              // record slot of the segment, < n_pad
     const uint32_t seg = perm[s];                               // the segment it holds (0xffffffff: none)
@@ -60,7 +61,7 @@ __global__ void build_filter_records_kernel(const double *__restrict__ raw, cons
         out[filter_slot_offset(nbase)] = (_Float16)__builtin_inff();   // |a|^2 = +inf
     if (real) {
         const double *p = raw + (off[seg] + f) * dim;
-        double nrm = 0.0;
+        double nrm = 0.0, res2 = 0.0;
         for (uint32_t e = 0; e < dimUse; ++e) {                  // frames wider than 42 values: the first 42
             const double v = p[e] * scale;                       // exact: scale is a power of two
             const _Float16 h1 = (_Float16)v;
@@ -69,6 +70,7 @@ __global__ void build_filter_records_kernel(const double *__restrict__ raw, cons
             const _Float16 h2 = two ? (_Float16)(v - (double)h1) : (_Float16)0.0f;
             const double vh = (double)h1 + (double)h2;           // the value the MFMA will see
             nrm += vh * vh;                                      // norms of the REPRESENTED frame
+            res2 += (v - vh) * (v - vh);                         // ... and how far it lies from the frame itself
             const _Float16 m1 = (_Float16)(-2.0f * (float)h1), m2 = (_Float16)(-2.0f * (float)h2);
             if (pieces == 2) {
                 out[filter_slot_offset(3 * e + 0)] = is_source ? m1 : h1;
@@ -85,6 +87,11 @@ __global__ void build_filter_records_kernel(const double *__restrict__ raw, cons
                 out[filter_slot_offset(e)] = is_source ? m1 : h1;
             }
         }
+        // |frame - represented frame|, unscaled, rounded up: a local cost of this frame moves by at most that much when the
+        // record stands in for the frame (the margin's rounding term, dtw_margin.hpp); the slot keeps its frames' maximum
+        const float r = __double2float_ru(sqrt(res2) / scale * 1.0000001);
+        if (r > 0.0f)
+            atomicMax(&resid[s], __float_as_uint(r));
         const _Float16 p1 = (_Float16)nrm;
         const _Float16 p2 = (_Float16)(nrm - (double)p1);
         const _Float16 p3 = (_Float16)(nrm - (double)p1 - (double)p2);
@@ -201,10 +208,12 @@ static int32_t ensure_records(ssym_ctx *ctx, const SegmentSet &set, double scale
     set.rec_bytes = bytes;
     dim3 grid((slots + 63) / 64, set.n_pad);
     const int dimUse = filter_dim_used((int)set.dim);
+    unsigned *resid = (unsigned *)(set.max_sqnorm + 2 * (size_t)set.n_pad);      // (non-negative floats: integer maximum)
+    SSYM_HIP_CHECK(ctx, hipMemsetAsync(resid, 0, sizeof(unsigned) * set.n_pad, ctx->stream));
     build_filter_records_kernel<<<grid, 64, 0, ctx->stream>>>(set.raw, set.off, set.perm, set.n, set.dim,
                                                               (uint32_t)dimUse, slots, set.is_source ? 1 : 0, lead,
                                                               filter_pieces(dimUse), scale,
-                                                              (_Float16 *)set.rec);
+                                                              (_Float16 *)set.rec, resid);
     SSYM_HIP_CHECK(ctx, hipGetLastError());
     set.rec_scale = scale;
     set.rec_slots = slots;

@@ -343,9 +343,11 @@ static int32_t build_derived(ssym_ctx *ctx, SegmentSet &set)
         { int32_t rcs = stage_h2d(ctx, set.perm, set.h_perm.data(), sizeof(uint32_t) * set.n_pad); if (rcs != SSYM_OK) return rcs; }
         { int32_t rca = dev_alloc(ctx, (void **)&set.len, sizeof(int32_t) * set.n_pad); if (rca != SSYM_OK) return rca; }
         SSYM_HIP_CHECK(ctx, hipMemsetAsync(set.len, 0, sizeof(int32_t) * set.n_pad, st));
-        // [n_pad] max squared frame norm per slot (read by the kernels), then [n_pad] max |value| per slot (host only)
-        { int32_t rca = dev_alloc(ctx, (void **)&set.max_sqnorm, sizeof(float) * 2 * (size_t)set.n_pad); if (rca != SSYM_OK) return rca; }
-        SSYM_HIP_CHECK(ctx, hipMemsetAsync(set.max_sqnorm, 0, sizeof(float) * 2 * (size_t)set.n_pad, st));
+        // [n_pad] max squared frame norm per slot (read by the kernels), then [n_pad] max |value| per slot (host only), then
+        // [n_pad] the largest distance between a frame of the slot and the frame its filter record represents (written when
+        // the records are built, dtw_filter.hip; read by the selection's margin, dtw_margin.hpp)
+        { int32_t rca = dev_alloc(ctx, (void **)&set.max_sqnorm, sizeof(float) * 3 * (size_t)set.n_pad); if (rca != SSYM_OK) return rca; }
+        SSYM_HIP_CHECK(ctx, hipMemsetAsync(set.max_sqnorm, 0, sizeof(float) * 3 * (size_t)set.n_pad, st));
         dim3 grid((mf + 63) / 64, n);
         segment_stats_kernel<<<grid, 64, 0, st>>>(set.raw, set.off, set.perm, n, dim, set.len,
                                                   (unsigned *)set.max_sqnorm,

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(kSelTgt * kSelSub) void dtw_colmin_kernel(
     __syncthreads();
     if (t < nTgt) {
         const double delta = dist ? dist[permT[t]] : 0.0;
-        const double nb = (double)tgtMaxSq[t];
+        const double nb = (double)tgtMaxSq[t], rb = (double)tgtMaxSq[mp.tgt_resid_off + t];
         const int fb = tgtLen[t];
         const uint32_t s0 = blockIdx.y * kSelChunk + ty * (kSelChunk / kSelSub);
         const uint32_t s1 = min(s0 + kSelChunk / kSelSub, nSrc);
@@ -112,7 +112,8 @@ __global__ __launch_bounds__(kSelTgt * kSelSub) void dtw_colmin_kernel(
         for (uint32_t s = s0; s < s1; ++s) {
             const size_t o = (size_t)s * mPad + t;
             double klo, khi;
-            dtw_key_interval(mp, (double)cmat[o], 0.0, (double)srcMaxSq[s], nb, srcLen[s], fb, delta, klo, khi);
+            dtw_key_interval(mp, (double)cmat[o], 0.0, (double)srcMaxSq[s], nb, srcLen[s], fb, delta, klo, khi,
+                             (double)srcMaxSq[mp.src_resid_off + s], rb);
             if (khi < best && khi > floorv)
                 best = khi;
         }
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(kSelTgt * kSelSub) void dtw_mark_kernel(
         const double thr = __longlong_as_double((long long)ub[t]);
         if (thr < __builtin_inf()) {     // else no finite cost for this target: the fold keeps (0, +inf)
             const double delta = dist ? dist[permT[t]] : 0.0;
-            const double nb = (double)tgtMaxSq[t];
+            const double nb = (double)tgtMaxSq[t], rb = (double)tgtMaxSq[mp.tgt_resid_off + t];
             const int fb = tgtLen[t];
             const uint32_t c0 = blockIdx.y * kSelChunk;
             const uint32_t s0 = c0 + ty * (kSelChunk / kSelSub);
@@ -156,7 +157,8 @@ __global__ __launch_bounds__(kSelTgt * kSelSub) void dtw_mark_kernel(
             for (uint32_t s = s0; s < s1; ++s) {
                 const size_t o = (size_t)s * mPad + t;
                 double klo, khi;
-                dtw_key_interval(mp, (double)cmat[o], 0.0, (double)srcMaxSq[s], nb, srcLen[s], fb, delta, klo, khi);
+                dtw_key_interval(mp, (double)cmat[o], 0.0, (double)srcMaxSq[s], nb, srcLen[s], fb, delta, klo, khi,
+                                 (double)srcMaxSq[mp.src_resid_off + s], rb);
                 if (klo <= thr)
                     hits |= 1ull << (s - c0);
             }
@@ -252,7 +254,8 @@ __global__ void dtw_stage2_ub_kernel(const uint32_t *__restrict__ hdr1, const ui
         const uint2 p = pairs1[k];
         double klo, khi;
         dtw_key_interval(mp, (double)cmat[(size_t)p.x * mPad + p.y], (double)xmin[k], (double)srcMaxSq[p.x],
-                         (double)tgtMaxSq[p.y], srcLen[p.x], tgtLen[p.y], dist ? dist[permT[p.y]] : 0.0, klo, khi);
+                         (double)tgtMaxSq[p.y], srcLen[p.x], tgtLen[p.y], dist ? dist[permT[p.y]] : 0.0, klo, khi,
+                         (double)srcMaxSq[mp.src_resid_off + p.x], (double)tgtMaxSq[mp.tgt_resid_off + p.y]);
         const double floorv = prev ? __longlong_as_double((long long)prev[p.y]) : -1.0;
         if (khi < __builtin_inf() && khi > floorv)
             atomicMin(&ub[p.y], (unsigned long long)__double_as_longlong(khi));
@@ -275,7 +278,8 @@ __global__ void dtw_stage2_keep_kernel(const uint32_t *__restrict__ hdr1, const 
         const uint2 p = pairs1[k];
         double klo, khi;
         dtw_key_interval(mp, (double)cmat[(size_t)p.x * mPad + p.y], (double)xmin[k], (double)srcMaxSq[p.x],
-                         (double)tgtMaxSq[p.y], srcLen[p.x], tgtLen[p.y], dist ? dist[permT[p.y]] : 0.0, klo, khi);
+                         (double)tgtMaxSq[p.y], srcLen[p.x], tgtLen[p.y], dist ? dist[permT[p.y]] : 0.0, klo, khi,
+                         (double)srcMaxSq[mp.src_resid_off + p.x], (double)tgtMaxSq[mp.tgt_resid_off + p.y]);
         // ub1 = the stage-1 threshold: never above ub on one GPU, but in a source-sharded run it is
         // the minimum over ALL ranks (ssym_match_begin / _finish) and may undercut this shard's best
         const double thr = fmin(__longlong_as_double((long long)ub[p.y]), __longlong_as_double((long long)ub1[p.y]));

@@ -38,6 +38,45 @@ def worst_case_bound(src, tgt, dim_used, fa, fb):
     return 1.02 * (fa + fb - 1) * cell, s
 
 
+def record_residual(frames, s, dim_used, is_source):
+    """|frame - the frame its filter record represents| per frame, unscaled (csrc/dtw_filter.hip
+    build_filter_records_kernel): values are rounded to one f16 piece, or two where the layout keeps both -- up to 13
+    values the source everywhere and the target in its first two values (layout 3; SSYM_FILTER_K48: both sides
+    everywhere), wider frames one piece on both sides."""
+    f16 = lambda x: np.asarray(x, dtype=np.float64).astype(np.float16).astype(np.float64)
+    v = np.asarray(frames, dtype=np.float64)[..., :dim_used] * s
+    h1 = f16(v)
+    two = np.zeros(v.shape[-1], dtype=bool)
+    if dim_used <= 13:
+        if os.environ.get("SSYM_FILTER_K48") or is_source:
+            two[:] = True
+        two[:2] = True
+    vh = h1 + np.where(two, f16(v - h1), 0.0)
+    return np.sqrt(((v - vh) ** 2).sum(-1)) / s
+
+
+def pair_bound_matrix(src, tgt, dim_used):
+    """[n_src, n_tgt] |C~ - C| bounds of the filter as the selection's first stage prices a pair since round 4
+    (csrc/dtw_margin.hpp, xmin = 0): the square-root term from the two SEGMENTS' largest squared frame norms and, for
+    what the records round away, the segments' MEASURED residuals (never above the layout's worst case)."""
+    u = 2.0 ** -24
+    in_a, in_b = input_rounding(dim_used)
+    sq = lambda a: float((np.asarray(a, dtype=np.float64)[..., :dim_used] ** 2).sum(-1).max()) * 1.000002 if np.asarray(a).size else 0.0
+    full = lambda a: float((np.asarray(a, dtype=np.float64) ** 2).sum(-1).max()) * 1.000002 if np.asarray(a).size else 0.0
+    vmax = max(max(float(np.abs(a).max()) for a in src if np.asarray(a).size),
+               max(float(np.abs(a).max()) for a in tgt if np.asarray(a).size)) * 1.000001
+    s = common_scale(vmax, max(max(full(a) for a in src), max(full(a) for a in tgt)))
+    na = np.array([sq(a) for a in src])
+    nb = np.array([sq(a) for a in tgt])
+    ra = np.array([float(record_residual(a, s, dim_used, True).max()) * 1.000001 if np.asarray(a).size else 0.0 for a in src])
+    rb = np.array([float(record_residual(a, s, dim_used, False).max()) * 1.000001 if np.asarray(a).size else 0.0 for a in tgt])
+    fa = np.array([np.asarray(a).shape[0] for a in src])
+    fb = np.array([np.asarray(a).shape[0] for a in tgt])
+    E = 256 * u * (na[:, None] + nb[None, :]) + 2.0 ** -12 / s ** 2
+    cell = np.sqrt(E) + 1.001 * (np.minimum(ra, in_a * np.sqrt(na))[:, None] + np.minimum(rb, in_b * np.sqrt(nb))[None, :]) + 2.0 ** -20 / s
+    return 1.02 * (fa[:, None] + fb[None, :] - 1) * cell, ra, rb, na, nb
+
+
 # ---- the refcos integer filter (csrc/refcos_q8.hip), restated --------------------------------------------------------
 def q8_quantise(a):
     """A segment's values as 23-bit fixed point in three balanced base-256 digits (refcos_q8_records_kernel).

@@ -14,7 +14,7 @@ import pytest
 
 from soundsym_amd import Engine, EmptyDictionaryError, SsymError, synth
 from soundsym_amd.engine import pack_segments
-from bounds import input_rounding
+from bounds import input_rounding, pair_bound_matrix
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -174,6 +174,13 @@ def test_dtw_golden_grid(dtw, oracle):
     bound = _filter_bound(list(g["sources"]), list(g["targets"]), f, f)
     err = np.abs(filt - g["matrix"])
     assert (err <= bound + 1e-5 * g["matrix"]).all(), (err.max(), bound)
+    # ... and within the bound the selection's first stage now gives every PAIR: its two segments' norms and the
+    # measured residual of their records (what the target's one f16 piece really rounds away, not 2^-11 |b|)
+    pb, ra, rb, _, nb = pair_bound_matrix(list(g["sources"]), list(g["targets"]), dim)
+    assert (err <= pb + 1e-5 * g["matrix"]).all(), float((err / (pb + 1e-5 * g["matrix"])).max())
+    assert (pb <= 1.03 * bound + 1e-12).all()                       # never looser than the set-wide worst case
+    if not os.environ.get("SSYM_FILTER_K48"):
+        assert np.median(rb / (2.0 ** -11 * np.sqrt(nb))) < 0.8     # and it does tighten: cepstral decay, two values kept whole
     # non-planted pairs are far from cancellation: there the filter is f32-accurate already, up to what the record
     # layout rounds away of the TARGET frames (one f16 piece: 2^-11 per value, far from adding up along a path)
     off_diag = g["matrix"] > 4 * g["cost"].max()
@@ -217,6 +224,9 @@ def test_dtw_golden_ragged(dtw):
     tgt = [g["tgt"][int(a) * 13:int(b) * 13].reshape(-1, 13) for a, b in zip(g["tgt_off"][:-1], g["tgt_off"][1:])]
     bound = _filter_bound(src, tgt, fa, fb)
     assert (np.abs(filt - g["matrix"]) <= bound + 1e-5 * g["matrix"]).all()
+    pb = pair_bound_matrix(src, tgt, 13)[0]                          # ragged lengths: every pair under ITS bound
+    fin = np.isfinite(g["matrix"])
+    assert (np.abs(filt - g["matrix"])[fin] <= (pb + 1e-5 * g["matrix"])[fin]).all()
 
 
 @pytest.mark.parametrize("n,m,f,dim", [(40, 70, 64, 13), (17, 33, 100, 12), (9, 5, 128, 13), (64, 32, 7, 5)])
