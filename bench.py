@@ -135,14 +135,18 @@ def secondary_metrics(device: int) -> dict:
     roof64 = {"bound": "mfma", "kernel": "refcos_mfma_kernel" if tm64["used_filter"] else "refcos_sims8_kernel",
               "kernel_ms": k64 * 1e3, "achieved": flops / k64 / 1e12, "peak": 78.6, "unit": "TFLOP/s",
               "frac": flops / k64 / 1e12 / 78.6,
-              "model": "2*F*d f64 flops per pair (SURVEY.md 8(d)) over the main kernel's time (HIP events); "
+              "model": "2*F*d f64 flops per pair (SURVEY.md 8(d)) over the main kernel's time -- device wall-clock stamps "
+                       "written by the search's own kernels (capi.hip useStamps): from the first thread of its init kernel to the "
+                       "first thread of the kernel after the main one, i.e. the init kernel and one launch gap included; "
                        "peak = dense f64 MFMA rate, v_mfma_f64_16x16x4_f64 at 64 cycles per instruction"}
     if tmr["refcos_filter"] == 2:
         roof = {"bound": "mfma", "kernel": "refcos_q8_kernel", "kernel_ms": k_s * 1e3, "achieved": 6.0 * flops / k_s / 1e12,
                 "peak": 5033.0, "unit": "TFLOP/s", "frac": 6.0 * flops / k_s / 1e12 / 5033.0,
-                "model": "six int8 GEMMs (12*F*d integer operations per pair) over the main kernel's time (HIP events); "
-                         "peak = dense i8 MFMA rate, v_mfma_i32_32x32x32_i8 at 32 cycles per instruction; what binds the "
-                         "kernel is operand delivery, not the pipe (DESIGN.md 5.5)"}
+                "model": "six int8 GEMMs (12*F*d integer operations per pair) over the main kernel's time (device wall-clock "
+                         "stamps, init kernel and one launch gap included); peak = dense i8 MFMA rate, v_mfma_i32_32x32x32_i8 "
+                         "at 32 cycles per instruction x 1024 SIMDs x the nominal 2.4 GHz (tools/mfma_i8_rate.hip measures 33-38 "
+                         "cycles per instruction for the chunk's own MFMA stream); what binds the kernel is operand delivery, "
+                         "not the pipe (DESIGN.md 5.5)"}
     else:
         roof = roof64
     out["refcos"] = {"value": n * n / dt, "unit": "segment-pairs/s", "ms_per_step": dt * 1e3,

@@ -322,7 +322,11 @@ SSYM_API int32_t ssym_merge_shards_at(ssym_ctx *ctx, uint32_t n_shards, uint32_t
  *     default 60 s, $SSYM_COMM_TIMEOUT_MS), then abort their communicator (ncclCommAbort) and return
  *     SSYM_E_TIMEOUT; the rank that could not take part aborts its own and returns its error.  An aborted communicator
  *     answers every further call with SSYM_E_COMM and can only be destroyed; RCCL's asynchronous errors
- *     (ncclCommGetAsyncError) end the wait the same way.
+ *     (ncclCommGetAsyncError) end the wait the same way.  After an abort the context's stream is drained under a
+ *     second, short deadline (5 s): that ncclCommAbort makes the queued collectives leave the stream has been seen with a
+ *     world-1 communicator only -- no run over more than one GPU exists, so the behaviour at world > 1 is UNVERIFIED; a
+ *     stream that does not drain is reported in ssym_last_error ("did not drain"), never waited for without bound, and
+ *     the context should then be destroyed.
  * RCCL is looked up at run time (symbols already in the process, else librccl.so.1 / $SSYM_RCCL_LIB), so a
  * single-GPU user needs no RCCL at all; without it the three calls fail with SSYM_E_UNSUPPORTED. */
 #define SSYM_COMM_ID_BYTES 128

@@ -468,6 +468,13 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
             uint32_t *tailDev = packed ? hdrTail : (stampsDev ? (uint32_t *)(stampsDev + 4) : nullptr);
             rc = launch_refcos_match_mfma(ctx, src, tgt, distDev, index_base, idxDev, costDev, &h1dev, &h2dev, k_top, q8, stampsDev,
                                           tailDev);
+            if (rc == SSYM_E_NOMEM && !ctx->stream_only) {
+                // the filters' lists did not fit (a top-k list of a large grid is a few GB): the exact tile kernel needs
+                // N x M x 8 bytes only and was the path of these calls before the filters took them
+                ctx->err.clear();
+                viaMfma = false;
+                break;
+            }
             if (rc != SSYM_OK)
                 return rc;
             tm.refcos_filter = q8 ? 2 : 1;

@@ -286,6 +286,36 @@ static int32_t comm_all_reduce_min(ssym_ctx *ctx, ssym_comm *c, double *buf, uin
     return SSYM_OK;
 }
 
+// After an abort the stream should drain: the aborted collectives' kernels leave their loops.  That is what RCCL
+// promises and what a world-1 communicator has been seen to do; with more ranks it is unverified (no multi-GPU box has
+// run this), so the drain is bounded as well: the stream's tail event is polled for a short second deadline, and a
+// stream that does not drain leaves the context's stream in an unknown state -- reported, not waited for.
+static bool comm_drain_after_abort(ssym_ctx *ctx, int64_t limit_ms = 5000)
+{
+    hipEvent_t tail = nullptr;
+    if (hipEventCreateWithFlags(&tail, hipEventDisableTiming) != hipSuccess)
+        return false;
+    bool drained = false;
+    if (hipEventRecord(tail, ctx->stream) == hipSuccess) {
+        using clock = std::chrono::steady_clock;
+        const clock::time_point t0 = clock::now();
+        for (;;) {
+            const hipError_t e = hipEventQuery(tail);
+            if (e == hipSuccess) {
+                drained = true;
+                break;
+            }
+            if (e != hipErrorNotReady || clock::now() - t0 > std::chrono::milliseconds(limit_ms))
+                break;
+            std::this_thread::yield();
+        }
+    }
+    (void)hipEventDestroy(tail);
+    if (!drained)
+        ctx->err += "; the stream did not drain after the abort (its remaining work is abandoned: destroy the context)";
+    return drained;
+}
+
 // The step's one synchronisation, under the communicator's deadline.  With RCCL the stream holds collectives that only
 // finish when every rank has enqueued its part, so a peer that never arrives would keep hipStreamSynchronize forever:
 // the end-of-step event is polled instead, RCCL's asynchronous error state with it; on expiry the communicator is
@@ -316,14 +346,14 @@ static int32_t comm_wait_step(ssym_ctx *ctx, ssym_comm *c, hipEvent_t done)
             ctx->err = std::string("ssym_match_sharded: RCCL reported an asynchronous error: ") + rccl().GetErrorString(async) +
                        "; the communicator is aborted";
             comm_abort(c);
-            (void)hipStreamSynchronize(ctx->stream);
+            (void)comm_drain_after_abort(ctx);
             return SSYM_E_COMM;
         }
         if (waited > limit) {
             ctx->err = "ssym_match_sharded: the step did not complete within " + std::to_string(c->timeout_ms) +
                        " ms (a rank failed to take part); the communicator is aborted";
             comm_abort(c);
-            (void)hipStreamSynchronize(ctx->stream);      // the aborted collectives leave the stream
+            (void)comm_drain_after_abort(ctx);            // the aborted collectives leave the stream (bounded wait)
             return SSYM_E_TIMEOUT;
         }
         if (waited > std::chrono::milliseconds(2))
@@ -438,7 +468,10 @@ int32_t ssym_comm_destroy(ssym_ctx *ctx, ssym_comm *c)
         return SSYM_OK;
     if (ctx) {
         (void)hipSetDevice(ctx->device);
-        (void)hipStreamSynchronize(ctx->stream);
+        if (c->dead)
+            (void)comm_drain_after_abort(ctx);   // (a dead communicator: never an unbounded wait behind its collectives)
+        else
+            (void)hipStreamSynchronize(ctx->stream);
     }
     if (c->nccl && rccl().ok)
         (void)rccl().CommDestroy(c->nccl);       // (an aborted communicator is gone already: nccl == NULL)
@@ -901,11 +934,13 @@ int32_t match_sharded_impl(ssym_ctx *ctx, ssym_comm *comm, const ssym_dict *dict
         const std::string keep = ctx->err;
         comm_abort(comm);
         ctx->stream_only = false;
-        (void)hipStreamSynchronize(ctx->stream);
+        ctx->err.clear();
+        (void)comm_drain_after_abort(ctx);
+        const std::string drainNote = ctx->err;
         release_deferred(ctx);
         ctx->pending_d2h.clear();
         ctx->pending.valid = false;
-        ctx->err = keep + " [this rank left the sharded step: its communicator is aborted]";
+        ctx->err = keep + " [this rank left the sharded step: its communicator is aborted]" + drainNote;
     }
     return rc;
 }

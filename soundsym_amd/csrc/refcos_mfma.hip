@@ -922,7 +922,8 @@ int32_t launch_refcos_match_mfma(ssym_ctx *ctx, const SegmentSet &src, const Seg
     hipStream_t st = ctx->stream;
     // (entries are counted in 32 bits and a top-k list is held twice at 24 bytes an entry: 2^28 entries at the most -- a list
     //  that would need more overflows, and the call takes the next filter or the tile kernel)
-    const size_t cap = std::min<uint64_t>(std::min<uint64_t>((uint64_t)N * M, 1ull << 28),
+    // (... and the kernels that sweep a list with one thread per entry are launched with at most 65535 x 16 workgroups)
+    const size_t cap = std::min<uint64_t>(std::min<uint64_t>((uint64_t)N * M, std::min<uint64_t>(1ull << 28, 65535ull * 16 * 256)),
                                           (uint64_t)refcos_list_capacity(N, M) * std::min<uint32_t>(k_top, 64));
     const size_t entryBytes = k_top > 1 ? sizeof(PairEntryK) : sizeof(PairEntry);
     int32_t rc = ensure(ctx, ctx->cand, 4 * sizeof(uint32_t) + entryBytes * cap);

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(CB == 2 ? 256 : 512, 1) void refcos_q8_kernel(
     const uint64_t *__restrict__ tgtOff, const double *__restrict__ tgtNorm, uint32_t nSrc, uint32_t nTgt, uint32_t dim,
     uint32_t srcGroups, uint32_t tgtGroups, const double *__restrict__ dist, double defaultDist,
     unsigned long long *__restrict__ thr, uint32_t *__restrict__ hdr, PairEntry *__restrict__ list, uint32_t cap,
-    double *__restrict__ simOut, uint32_t kTop)
+    double *__restrict__ simOut, uint32_t kTop, uint32_t tilesX, uint32_t tilesY)
 {
     __shared__ __attribute__((aligned(16))) unsigned char sA0[kQT * 128], sA1[kQT * 128], sA2[kQT * 128], sA3[kQT * 128];
     __shared__ __attribute__((aligned(16))) unsigned char sB0[kQT * 128], sB1[kQT * 128], sB2[kQT * 128], sB3[kQT * 128];
@@ -175,18 +175,25 @@ __global__ __launch_bounds__(CB == 2 ? 256 : 512, 1) void refcos_q8_kernel(
     // epilogue's memory round trips), at 1.5 x the operand reads per MFMA.
     constexpr int kWN = CB == 2 ? 2 : 4, kNT = 64 * 2 * kWN, kSweep = kNT / 8, kP = kQT / kSweep;
     const int wm = wave / kWN, wn = wave % kWN;
-    // (XCD-aware tile order: refcos_mfma.hip)
-    uint32_t bx = blockIdx.x, by = blockIdx.y;
-    {
-        const uint32_t nx = gridDim.x, ny = gridDim.y, total = nx * ny;
-        if ((nx & 7u) == 0 && (total & 7u) == 0) {
-            const uint32_t lin = bx + nx * by;
-            const uint32_t q = (lin & 7u) * (total >> 3) + (lin >> 3);
-            const uint32_t r = q % (8u * ny);
-            bx = 8u * (q / (8u * ny)) + (r & 7u);
+    // PERSISTENT workgroups (round 4): one per CU, tile after tile (linear tile numbers blockIdx.x, + gridDim.x, ...), so
+    // that the next tile's first four chunks can be requested BEFORE the current tile's epilogue -- with one workgroup per
+    // CU nothing else hides a tile's first memory round trip.  (XCD-aware tile order as in refcos_mfma.hip: workgroup
+    // number & 7 is the XCD, and gridDim.x is a multiple of 8 whenever the order applies.)
+    const uint32_t tilesTotal = tilesX * tilesY;
+    auto tile_of = [&](uint32_t lin, uint32_t &bx, uint32_t &by) {
+        bx = lin % tilesX;
+        by = lin / tilesX;
+        if ((tilesX & 7u) == 0 && (tilesTotal & 7u) == 0 && (gridDim.x & 7u) == 0) {
+            const uint32_t q = (lin & 7u) * (tilesTotal >> 3) + (lin >> 3);
+            const uint32_t r = q % (8u * tilesY);
+            bx = 8u * (q / (8u * tilesY)) + (r & 7u);
             by = r >> 3;
         }
-    }
+    };
+    bool prefetched = false;                               // the tile's first four chunks were requested by the tile before
+  for (uint32_t tileLin = blockIdx.x; tileLin < tilesTotal; tileLin += gridDim.x) {
+    uint32_t bx, by;
+    tile_of(tileLin, bx, by);
     const uint32_t sTile = by * kQT, tTile = bx * kQT;
 
     // staging: thread -> (row = tid / 8 + 32 p, position tid & 7) for p = 0..3 on both sides; the piece it fetches is
@@ -210,9 +217,9 @@ __global__ __launch_bounds__(CB == 2 ? 256 : 512, 1) void refcos_q8_kernel(
         constexpr int s = decltype(S)::value;
         return s == 0 ? sB0 : s == 1 ? sB1 : s == 2 ? sB2 : sB3;
     };
-    auto fetch = [&](unsigned c, auto S) {                // eight DMAs, nothing waits here
+    auto fetch_from = [&](const unsigned char *baseA, const unsigned char *baseB, unsigned c, auto S) {   // eight DMAs, nothing waits here
         unsigned char *const dA = stageA(S), *const dB = stageB(S);
-        const unsigned char *ua = tileA + (size_t)c * 128, *ub = tileB + (size_t)c * 128;
+        const unsigned char *ua = baseA + (size_t)c * 128, *ub = baseB + (size_t)c * 128;
         asm volatile("" : "+s"(ua), "+s"(ub));            // (scalar base + 32-bit lane offset: refcos_mfma.hip)
 #pragma unroll
         for (int p = 0; p < kP; ++p) {
@@ -224,17 +231,20 @@ __global__ __launch_bounds__(CB == 2 ? 256 : 512, 1) void refcos_q8_kernel(
         }
     };
 
+    auto fetch = [&](unsigned c, auto S) { fetch_from(tileA, tileB, c, S); };
     // The first four chunks are requested before anything is known about the tile's segments (their rows exist and are
     // zero beyond a segment's end whatever its length): the per-segment values below are fetched under them.
     const unsigned nGroupsMin = min(srcGroups, tgtGroups);
     // (always four groups of eight DMAs, a chunk index beyond the rows' end clamped to their last group: the waits below
     //  count groups, and a group that is not needed lands in a stage nobody reads)
-    if (nGroupsMin > 0) {
-        fetch(0, std::integral_constant<int, 0>{});
-        fetch(min(1u, nGroupsMin - 1), std::integral_constant<int, 1>{});
-        fetch(min(2u, nGroupsMin - 1), std::integral_constant<int, 2>{});
-        fetch(min(3u, nGroupsMin - 1), std::integral_constant<int, 3>{});
-    }
+    auto first_four = [&](const unsigned char *baseA, const unsigned char *baseB) {
+        fetch_from(baseA, baseB, 0, std::integral_constant<int, 0>{});
+        fetch_from(baseA, baseB, min(1u, nGroupsMin - 1), std::integral_constant<int, 1>{});
+        fetch_from(baseA, baseB, min(2u, nGroupsMin - 1), std::integral_constant<int, 2>{});
+        fetch_from(baseA, baseB, min(3u, nGroupsMin - 1), std::integral_constant<int, 3>{});
+    };
+    if (nGroupsMin > 0 && !prefetched)
+        first_four(tileA, tileB);
     if (tid < 2)
         sMaxLen[tid] = 0;
     if (tid < 6)
@@ -378,6 +388,21 @@ __global__ __launch_bounds__(CB == 2 ? 256 : 512, 1) void refcos_q8_kernel(
             step(c + 3, std::integral_constant<int, 3>{});
     }
 
+    // The next tile's first four chunks, requested before this tile's epilogue (every wave's reads of the stages are in its
+    // registers -- lgkmcnt(0) -- and every wave has got there -- the barrier -- so the stages are free; the clamped copies
+    // the last steps requested are older and land first).  Its epilogue's own memory operations queue up behind them.
+    prefetched = false;
+#ifndef SSYM_Q8_NOPREFETCH
+    if (nGroupsMin > 0 && tileLin + gridDim.x < tilesTotal) {
+        uint32_t nbx, nby;
+        tile_of(tileLin + gridDim.x, nbx, nby);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        asm volatile("s_barrier" ::: "memory");
+        first_four((const unsigned char *)srcQ + (size_t)(nby * kQT) * srcGroups * 128,
+                   (const unsigned char *)tgtQ + (size_t)(nbx * kQT) * tgtGroups * 128);
+        prefetched = true;
+    }
+#endif
 #ifdef SSYM_Q8_NOEPI         // (tools only: the main loop alone, every accumulator kept alive)
     {
         v16i t = acc[0][0][0];
@@ -394,7 +419,8 @@ __global__ __launch_bounds__(CB == 2 ? 256 : 512, 1) void refcos_q8_kernel(
             x ^= t[g];
         if (x == 0x12345678 && hdr[0] == 77)
             thr[0] = 1;
-        return;
+        __syncthreads();
+        continue;
     }
 #endif
     // ---- epilogue: integer dots -> key intervals -> thresholds and list 1 (the steps of refcos_mfma.hip's) -----------
@@ -591,6 +617,8 @@ __global__ __launch_bounds__(CB == 2 ? 256 : 512, 1) void refcos_q8_kernel(
                     }
                 }
     }
+    __syncthreads();       // every wave is through the epilogue before the next tile rewrites the per-segment values in LDS
+  }
     __builtin_amdgcn_s_waitcnt(rm_wait_vmcnt(0));          // (the last, unused DMA groups have long landed: the LDS they write
                                                            //  into must still be this workgroup's when they do)
 }
@@ -669,7 +697,12 @@ int32_t launch_refcos_q8_kernel(ssym_ctx *ctx, const SegmentSet &src, const Segm
                                 double *sims)
 {
     const uint32_t N = src.n, M = tgt.n;
-    dim3 grid((M + kQT - 1) / kQT, (N + kQT - 1) / kQT);
+    const uint32_t tilesX = (M + kQT - 1) / kQT, tilesY = (N + kQT - 1) / kQT;
+    // persistent: one workgroup per CU (a multiple of 8 so that workgroup number & 7 stays the XCD), tile after tile
+    const uint32_t tiles = tilesX * tilesY;
+    static const bool persist = !(getenv("SSYM_REFCOS_Q8_PERSIST") && atoi(getenv("SSYM_REFCOS_Q8_PERSIST")) == 0);
+    const uint32_t cus = (uint32_t)std::max(8, ctx->num_cus / 8 * 8);
+    dim3 grid(persist ? std::min(tiles, cus) : tiles);
     hipStream_t st = ctx->stream;
     // four waves of 64 x 64 per workgroup (one per SIMD); SSYM_REFCOS_Q8_WAVES=8 takes eight of 64 x 32, two per SIMD, at
     // 1.5 x the operand reads per MFMA -- measured 2 % SLOWER (0.191 against 0.187 ms: what the waves wait for is not
@@ -680,7 +713,7 @@ int32_t launch_refcos_q8_kernel(ssym_ctx *ctx, const SegmentSet &src, const Segm
     refcos_q8_kernel<WS, TK, CBV><<<grid, CBV == 2 ? 256 : 512, 0, st>>>(src.q8, src.q8_info, src.off, src.norm, tgt.q8,       \
                                                                        tgt.q8_info, tgt.off, tgt.norm, N, M, src.dim,          \
                                                                        src.q8_groups, tgt.q8_groups, dist_dev, 1.0, thr, hdr1, \
-                                                                       (PairEntry *)list1, cap, SIMS, KT)
+                                                                       (PairEntry *)list1, cap, SIMS, KT, tilesX, tilesY)
     if (sims) {
         SSYM_Q8_LAUNCH(true, false, 2, sims, 1);
     } else if (k_top > 1) {
