@@ -274,7 +274,9 @@ static void launch_one(hipStream_t st, const SegmentSet &src, const SegmentSet &
     // tasks per grab: several SHORT tasks at a time so that the L2 atomics stay invisible (at 16 frames a
     // task is ~1 us of work), one at a time once a task is long enough to matter for the tail; always
     // at least 16 grabs per wave
-    const long cellsPerTask = (long)(16 * NT * nPasses) * std::max<uint32_t>(tgt.max_frames, 1);
+    // (a task's size by the MEAN target length, not the longest: a ragged set's typical task is what the grab amortises)
+    const long meanTgt = tgt.n ? (long)((tgt.total_frames + tgt.n - 1) / tgt.n) : 1;
+    const long cellsPerTask = (long)(16 * NT * nPasses) * std::max<long>(meanTgt, 1);
     int taskChunk = (int)std::max(1L, std::min(8L, 8192 / std::max(1L, cellsPerTask)));
     taskChunk = std::max(1, std::min(taskChunk, nTasks / (grid * kFilterWavesPerBlock * 16)));
     // SSYM_FILTER_PK=1 (experiment, off in the product: +1...1.5 % measured): 64-row passes without early
