@@ -233,18 +233,19 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_ker
 
     // Work distribution: a task is one wave's (source pair, target group) = 64 pairs; waves take
     // tasks from 8 counters, one per XCD group (workgroups b, b+8, ... share an XCD and gridDim.x is a
-    // multiple of 8), each counter covering a contiguous range of the (target group, source pair)
-    // space so that a group's targets stay in that XCD's L2.  Ranges are walked from their END:
+    // multiple of 8), each counter covering the (target group, source pair) space of every eighth
+    // target group, so that a group's targets stay in that XCD's L2.  Ranges are walked from their END:
     // record slots are ordered by segment length, so the longest tasks start first and the short
     // ones fill the tail (with ragged segment lengths a static assignment left most of the chip
     // waiting for the workgroup that held the longest sources).  A wave whose range is exhausted
     // helps the next XCD's range, so every wave leaves only when all counters are spent.
     unsigned colSteps = 0;      // PRUNE: columns this wave swept (wave-uniform), reported once at the end
-    const unsigned qd = (unsigned)nTasks >> 3, rm = (unsigned)nTasks & 7u;
+    // (round 4: XCD x owns the target groups x, x + 8, ... instead of a contiguous eighth -- groups are ordered by length,
+    //  and on ragged targets the last eighth held several times the first one's work; nothing changes on equal lengths)
+    const unsigned nGroups = (unsigned)mPad >> 5;
     for (unsigned hop = 0; hop < 8; ++hop) {
       const unsigned xcd = (blockIdx.x + hop) & 7u;
-      const unsigned rangeLo = xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd;
-      const unsigned rangeLen = qd + (xcd < rm ? 1u : 0u);
+      const unsigned rangeLen = xcd < nGroups ? ((nGroups - xcd + 7u) >> 3) * (unsigned)nSrcPairs : 0u;
       for (;;) {
         // tasks are taken kTaskChunk at a time: the counters are atomics in L2, and 2.6e5 single-task
         // grabs on one cache line were a 3 ms floor under every launch (visible for short segments)
@@ -260,8 +261,8 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_ker
         int preFa = 0, preFb = 0;
         bool havePre = false;                   // wave-uniform
        for (unsigned gi = got; gi < gotEnd; ++gi) {
-        const unsigned lin = rangeLo + (rangeLen - 1u - gi);
-        const int tg = (int)(lin / (unsigned)nSrcPairs);
+        const unsigned lin = rangeLen - 1u - gi;                      // position in the XCD's range, walked from its end
+        const int tg = (int)(xcd + 8u * (lin / (unsigned)nSrcPairs));
         const int sp = spBase + (int)(lin % (unsigned)nSrcPairs);    // source pair of this wave
 
         const int fa = havePre ? preFa : srcLen[2 * sp + half];
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_ker
         if (havePre) {
             const unsigned linN = lin - 1u;
             preFa = srcLen[2 * (spBase + (int)(linN % (unsigned)nSrcPairs)) + half];
-            preFb = tgtLen[32 * (int)(linN / (unsigned)nSrcPairs) + col];
+            preFb = tgtLen[32 * (int)(xcd + 8u * (linN / (unsigned)nSrcPairs)) + col];
         }
         const int r0 = srcRows - fa;   // first real row: sources are END-ALIGNED in their row slots
 
