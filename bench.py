@@ -123,9 +123,13 @@ def secondary_metrics(device: int) -> dict:
     # The search's filter is the integer one (csrc/refcos_q8.hip: six exact int8 GEMMs on v_mfma_i32_32x32x32_i8) where
     # the sets' values allow it, the f64 matrix pipe (csrc/refcos_mfma.hip) otherwise; both are timed, the default first.
     dt, k_s, tmr = leg()
+    had_hooks = os.environ.get("SSYM_TEST_HOOKS")
+    os.environ["SSYM_TEST_HOOKS"] = "1"          # (the library reads its measurement knobs only when asked to)
     os.environ["SSYM_REFCOS_Q8"] = "0"
     dt64, k64, tm64 = leg()
     del os.environ["SSYM_REFCOS_Q8"]
+    if had_hooks is None:
+        del os.environ["SSYM_TEST_HOOKS"]
     # algorithmic work of the reference's metric: 2 L f64 flops per pair, L = F d, as one zero-padded GEMM.
     # f64 filter: v_mfma_f64_16x16x4_f64, 64 cycles per instruction on MI355X (measured: profiles/r02_refcos_1gpu.md), i.e.
     # 2048 flops / 64 cycles x 1024 SIMDs x 2.4 GHz = 78.6 TFLOP/s.  Integer filter: the same dot as SIX int8 GEMMs (digit

@@ -344,7 +344,10 @@ SSYM_API int32_t ssym_comm_set_timeout(ssym_comm *comm, int64_t milliseconds);
 /* 1 = the communicator was aborted (every call on it fails with SSYM_E_COMM), 0 = usable. */
 SSYM_API int32_t ssym_comm_is_dead(const ssym_comm *comm);
 /* TEST AND MEASUREMENT HOOKS.  Both refuse with SSYM_E_UNSUPPORTED unless the calling process has SSYM_TEST_HOOKS=1 in its
- * environment at the time of the call: nothing a production caller can trip over.
+ * environment at the time of the call: nothing a production caller can trip over.  The same variable gates the library's
+ * measurement knobs (SSYM_FILTER_*, SSYM_REFCOS_*, SSYM_EXACT_*, SSYM_CELLS_*, SSYM_PRUNE_NT: A/B switches between kernels
+ * that return the same bits): without it none of them is read.  SSYM_COMM_TIMEOUT_MS and SSYM_RCCL_LIB
+ * are configuration and always honoured.
  *
  * Fault injection for the containment tests (tests/test_gpu_comm.py), one shot: the NEXT ssym_match_sharded on this
  * communicator fails in `phase` (1 = the filter phase before the bound exchange, 2 = selection / re-scoring before the

@@ -439,7 +439,7 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
         // what is LISTED; the threshold that selects the candidates is the k-th smallest bound over all of a target's listed
         // pairs (refcos_mfma.hip, refcos_topk_*).  4096 x 4096 x 128f x 12d, k = 2 / 4 / 8 / 16 / 64: 0.41 / 0.47 / 0.63 / 0.93 /
         // 2.9 ms against 3.2 / 3.1 / 3.3 / 3.9 / 7.0 ms on the exact tile kernel (tools/refcos_topk_timing.py).
-        const char *kmaxKnob = getenv("SSYM_REFCOS_TOPK_MAX");                       // (measurements: where the filters stop paying)
+        const char *kmaxKnob = ssym_knob("SSYM_REFCOS_TOPK_MAX");                       // (measurements: where the filters stop paying)
         const uint32_t kFilterMax = kmaxKnob ? (uint32_t)std::max(1, atoi(kmaxKnob)) : 64u;
         bool viaMfma = !(ctx->stream_only && (ctx->so_cap || k_top > 1)) && k_top <= kFilterMax && refcos_mfma_supported(ctx, src, tgt);
         ctx->so_refcos = false;

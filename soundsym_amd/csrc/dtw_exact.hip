@@ -1026,12 +1026,12 @@ int32_t launch_dtw_exact(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet 
     // 128 x 128 frames 0.187 -> 0.080 ms: what a rank of a source-sharded step re-scores after the bound exchange) and
     // loses once the chip is full (4096 pairs 0.48 -> 0.57 ms: its 64 KB of cells admit two workgroups per CU), so there
     // it takes lists of up to 4 pairs per CU and sources of up to 256 frames, and the kernels below take the rest.
-    static const bool cellsOff = getenv("SSYM_EXACT_CELLS") && atoi(getenv("SSYM_EXACT_CELLS")) == 0;
+    static const bool cellsOff = ssym_knob("SSYM_EXACT_CELLS") && atoi(ssym_knob("SSYM_EXACT_CELLS")) == 0;
     uint64_t lowBound = 0;              // lists at least this long are the business of the kernels below
     {
         const bool banded = ctx->band >= 0;
-        static const int panelEnv = getenv("SSYM_CELLS_PANEL") ? atoi(getenv("SSYM_CELLS_PANEL")) : 0;         // experiments
-        static const long long maxEnv = getenv("SSYM_CELLS_MAX") ? atoll(getenv("SSYM_CELLS_MAX")) : 0;
+        static const int panelEnv = ssym_knob("SSYM_CELLS_PANEL") ? atoi(ssym_knob("SSYM_CELLS_PANEL")) : 0;         // experiments
+        static const long long maxEnv = ssym_knob("SSYM_CELLS_MAX") ? atoll(ssym_knob("SSYM_CELLS_MAX")) : 0;
         const uint32_t panelX = banded ? 2 * (uint32_t)ctx->band + 1 : std::min<uint32_t>(fbEven, panelEnv > 0 ? panelEnv : 128);
         const size_t cellsLds = 2 * (size_t)fbEven * sizeof(double) + (size_t)panelX * 64 * sizeof(double) +
                                 (size_t)winRows * ldr * (bf32 ? sizeof(float) : sizeof(double));
@@ -1084,7 +1084,7 @@ int32_t launch_dtw_exact(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet 
     // once the chip is full, because a waiting wave holds its slot -- and inside a band, where a chunk
     // needs two thirds of the chunk above before it can start.  The list length lives on the device, so
     // both kernels are launched and the length decides which of them works.
-    static const bool pipeOff = getenv("SSYM_EXACT_PIPE") && atoi(getenv("SSYM_EXACT_PIPE")) == 0;
+    static const bool pipeOff = ssym_knob("SSYM_EXACT_PIPE") && atoi(ssym_knob("SSYM_EXACT_PIPE")) == 0;
     const uint64_t pipeMax = (uint64_t)ctx->num_cus * 64 / std::max<uint32_t>(pipeW, 1);
     const bool pipeOk = !pipeOff && ctx->band < 0 && dimr && dimr <= 48 && pipeW >= 2 && pipeW <= 8 &&
                         pipeLds <= 150 * 1024 && regLds <= 64 * 1024;
@@ -1100,7 +1100,7 @@ int32_t launch_dtw_exact(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet 
             return rcf;
         ctx->pipe_mask |= 1u << slot;
         redoFlag = failCount;
-        const char *fg = getenv("SSYM_EXACT_PIPE_FORCE_GIVEUP");
+        const char *fg = ssym_knob("SSYM_EXACT_PIPE_FORCE_GIVEUP");
         const int forceGiveUp = fg && atoi(fg) != 0 ? 1 : 0;
 #define SSYM_EXACT_PIPE2(D_, T_)                                                                               \
     do {                                                                                                       \

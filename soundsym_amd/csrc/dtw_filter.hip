@@ -27,7 +27,7 @@ namespace ssym {
 
 int filter_pieces(int dim)
 {
-    static const bool k48 = getenv("SSYM_FILTER_K48") != nullptr;      // measurements: the symmetric K = 48 layout
+    static const bool k48 = ssym_knob("SSYM_FILTER_K48") != nullptr;      // measurements: the symmetric K = 48 layout
     return dim > kFilterMaxDim2 ? 1 : (k48 ? 2 : 3);
 }
 
@@ -281,7 +281,7 @@ static void launch_one(hipStream_t st, const SegmentSet &src, const SegmentSet &
     taskChunk = std::max(1, std::min(taskChunk, nTasks / (grid * kFilterWavesPerBlock * 16)));
     // SSYM_FILTER_PK=1 (experiment, off in the product: +1...1.5 % measured): 64-row passes without early
     // abandoning on the two-block kernel whose additions are packed (dtw_filter_pk_kernel.hpp)
-    static const bool pkOn = getenv("SSYM_FILTER_PK") && atoi(getenv("SSYM_FILTER_PK")) != 0;
+    static const bool pkOn = ssym_knob("SSYM_FILTER_PK") && atoi(ssym_knob("SSYM_FILTER_PK")) != 0;
     if (NT == 4 && !abandon && pkOn) {
         dtw_filter_pk_kernel<SQ, KU><<<dim3(grid), 64 * kFilterWavesPerBlock, 0, st>>>(
             (const _Float16 *)src.rec, (const _Float16 *)tgt.rec, src.len, tgt.len, (int)src.frames_pad, nPasses,
@@ -291,7 +291,7 @@ static void launch_one(hipStream_t st, const SegmentSet &src, const SegmentSet &
     }
     // single-pass launches without early abandoning: the kernel that pipelines across tasks and skips padding rows
     // (dtw_filter_sp_kernel.hpp; SSYM_FILTER_SP=0 keeps dtw_filter_kernel for A/B measurements, same bits either way)
-    static const bool spOn = !(getenv("SSYM_FILTER_SP") && atoi(getenv("SSYM_FILTER_SP")) == 0);
+    static const bool spOn = !(ssym_knob("SSYM_FILTER_SP") && atoi(ssym_knob("SSYM_FILTER_SP")) == 0);
     // (with three operand planes its LDS -- ring and staging block -- admits two workgroups per CU up to two tiles)
     if constexpr (NT <= 3 && (KU == 2 || NT <= 2)) {
         if (!abandon && nPasses == 1 && spOn) {
@@ -438,7 +438,7 @@ int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
     // data without close pairs).  Results do not depend on the pass height, so it follows the data: 32 rows
     // when the previous pruned call on this context swept less than a quarter of its cells, 64 otherwise
     // (and on the first call).  SSYM_PRUNE_NT=2|4 pins it for measurements.
-    const char *pin = abandon ? getenv("SSYM_PRUNE_NT") : nullptr;
+    const char *pin = abandon ? ssym_knob("SSYM_PRUNE_NT") : nullptr;
     const int pinned = pin ? atoi(pin) : 0;
     const int pruneNt = pinned == 2 || pinned == 4 ? pinned : (ctx->prune_swept < 0.25f ? 2 : 4);
     const FilterShape setShape = shape;
@@ -500,7 +500,7 @@ int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
         return lo;
     };
     const int topTiles = setShape.nt;               // tiles of the set's own shape (4 = multi-pass)
-    static const bool oneLaunch = getenv("SSYM_FILTER_ONE_LAUNCH") != nullptr;     // measurements: the set's shape for every pair
+    static const bool oneLaunch = ssym_knob("SSYM_FILTER_ONE_LAUNCH") != nullptr;     // measurements: the set's shape for every pair
     int bound[4] = {0, 0, 0, 0};                    // bound[c]: first pair that needs more than c tiles
     for (int c = 1; c < topTiles; ++c)
         bound[c] = oneLaunch ? 0 : firstAbove(16u * c);
@@ -522,7 +522,7 @@ int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
         SSYM_LAUNCH(1, 1, rowsPad - 16, bound[0], bound[1], 0)
         SSYM_LAUNCH(2, 1, rowsPad - 32, bound[1], bound[2], 1)
         SSYM_LAUNCH(3, 1, rowsPad - 48, bound[2], bound[3], 2)
-        static const bool nt8 = getenv("SSYM_FILTER_NT8") != nullptr;
+        static const bool nt8 = ssym_knob("SSYM_FILTER_NT8") != nullptr;
         if (shape.nt == 2) {
             SSYM_LAUNCH(2, shape.rb, 0, bound[3], nPairs, 3)
         } else if (nt8 && shape.rb == 2 && !abandon) {

@@ -874,7 +874,7 @@ __global__ void refcos_init_kernel(unsigned long long *thr, unsigned long long *
 
 bool refcos_mfma_supported(const ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt)
 {
-    static const bool off = getenv("SSYM_REFCOS_MFMA") && atoi(getenv("SSYM_REFCOS_MFMA")) == 0;
+    static const bool off = ssym_knob("SSYM_REFCOS_MFMA") && atoi(ssym_knob("SSYM_REFCOS_MFMA")) == 0;
     if (off || ctx->metric != SSYM_METRIC_REFCOS || src.dim != tgt.dim)
         return false;
     // small problems: the exact tile kernel is one launch and already fast; long segments: the error constant

@@ -681,7 +681,7 @@ int32_t refcos_q8_ensure(ssym_ctx *ctx, const SegmentSet &set)
 bool refcos_q8_ready(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet &tgt)
 {
     // (read per call, not once: bench.py and the tests time and check both filters in one process)
-    const char *knob = getenv("SSYM_REFCOS_Q8");
+    const char *knob = ssym_knob("SSYM_REFCOS_Q8");
     const bool off = knob && atoi(knob) == 0;
     if (off || ctx->metric != SSYM_METRIC_REFCOS || src.dim != tgt.dim)
         return false;
@@ -700,14 +700,14 @@ int32_t launch_refcos_q8_kernel(ssym_ctx *ctx, const SegmentSet &src, const Segm
     const uint32_t tilesX = (M + kQT - 1) / kQT, tilesY = (N + kQT - 1) / kQT;
     // persistent: one workgroup per CU (a multiple of 8 so that workgroup number & 7 stays the XCD), tile after tile
     const uint32_t tiles = tilesX * tilesY;
-    static const bool persist = !(getenv("SSYM_REFCOS_Q8_PERSIST") && atoi(getenv("SSYM_REFCOS_Q8_PERSIST")) == 0);
+    static const bool persist = !(ssym_knob("SSYM_REFCOS_Q8_PERSIST") && atoi(ssym_knob("SSYM_REFCOS_Q8_PERSIST")) == 0);
     const uint32_t cus = (uint32_t)std::max(8, ctx->num_cus / 8 * 8);
     dim3 grid(persist ? std::min(tiles, cus) : tiles);
     hipStream_t st = ctx->stream;
     // four waves of 64 x 64 per workgroup (one per SIMD); SSYM_REFCOS_Q8_WAVES=8 takes eight of 64 x 32, two per SIMD, at
     // 1.5 x the operand reads per MFMA -- measured 2 % SLOWER (0.191 against 0.187 ms: what the waves wait for is not
     // hidden by a second wave), kept as a measurement switch
-    const char *knob = getenv("SSYM_REFCOS_Q8_WAVES");
+    const char *knob = ssym_knob("SSYM_REFCOS_Q8_WAVES");
     const bool four = !(knob && atoi(knob) == 8);
 #define SSYM_Q8_LAUNCH(WS, TK, CBV, SIMS, KT)                                                                                  \
     refcos_q8_kernel<WS, TK, CBV><<<grid, CBV == 2 ? 256 : 512, 0, st>>>(src.q8, src.q8_info, src.off, src.norm, tgt.q8,       \

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <exception>
 #include <map>
 #include <new>
@@ -13,6 +14,15 @@
 #include <vector>
 
 #include "soundsym_amd.h"
+
+// Measurement and test knobs (SSYM_FILTER_*, SSYM_REFCOS_*, SSYM_EXACT_*, SSYM_CELLS_*, SSYM_PRUNE_NT ...: none changes a
+// result) are read only in a process that asked for the library's test hooks with SSYM_TEST_HOOKS=1 -- a production
+// process cannot be steered by a stray variable.  (SSYM_COMM_TIMEOUT_MS and SSYM_RCCL_LIB are configuration, not knobs.)
+inline const char *ssym_knob(const char *name)
+{
+    const char *h = getenv("SSYM_TEST_HOOKS");
+    return (h && atoi(h) != 0) ? getenv(name) : nullptr;
+}
 
 namespace ssym {
 

@@ -3,6 +3,7 @@
 library SSYM_LIB names: the product library, or one built with -DSSYM_BAND_ABL=1|2|3 (no MFMAs / no LDS operand reads /
 no target loads: wrong values, valid timing) to see what each stream of the kernel costs beside the recurrence."""
 import os, sys
+os.environ.setdefault("SSYM_TEST_HOOKS", "1")      # the library reads its measurement knobs only when asked to
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from soundsym_amd import Engine, synth

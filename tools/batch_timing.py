@@ -2,6 +2,7 @@
 """tools/batch_timing.py -- ssym_match_batch (host targets: upload, pack, records, match, release -- what a drop-in caller
 of clone_from_dictionary pays per batch) against ssym_match_queries on resident targets, configs[2]'s shape."""
 import os, sys, time
+os.environ.setdefault("SSYM_TEST_HOOKS", "1")      # the library reads its measurement knobs only when asked to
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from soundsym_amd import Engine, synth

@@ -2,6 +2,7 @@
 """tools/c2_phases.py -- phase times of BASELINE configs[1] (1024 x 1024 segments, 64 frames x 13 dims): a call that short
 is a chain of ~20 launches, and the gaps between them show in total_ms."""
 import os, sys, time
+os.environ.setdefault("SSYM_TEST_HOOKS", "1")      # the library reads its measurement knobs only when asked to
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

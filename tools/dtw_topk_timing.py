@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """tools/dtw_topk_timing.py -- ssym_match_topk with the dtw metric on the headline's shape, wall clock per call and phases."""
 import os, sys, time
+os.environ.setdefault("SSYM_TEST_HOOKS", "1")      # the library reads its measurement knobs only when asked to
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from soundsym_amd import Engine, synth

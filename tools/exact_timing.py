@@ -5,6 +5,7 @@ first, recurrence afterwards).  Shapes: the 8-GPU share of configs[2] (512 x 409
 at world 1), configs[2] itself, configs[4]'s share (512 x 4096 x 256f x 40d, r = 32), short lists (early abandoning's
 candidates: M pairs), and the exact kernel on every pair of a small grid."""
 import os, sys, time
+os.environ.setdefault("SSYM_TEST_HOOKS", "1")      # the library reads its measurement knobs only when asked to
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from soundsym_amd import Engine, synth

@@ -3,6 +3,7 @@
 fixed cost of a launch (ramp-up, the tail of a persistent grid whose tasks are 64 pairs each) is what bounds the
 strong-scaling efficiency of the source-sharded step, where every rank runs N / G sources."""
 import os, sys
+os.environ.setdefault("SSYM_TEST_HOOKS", "1")      # the library reads its measurement knobs only when asked to
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

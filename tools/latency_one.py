@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Latency of ssym_match_one (the reference's one-query-at-a-time call pattern)."""
 import os, sys, time
+os.environ.setdefault("SSYM_TEST_HOOKS", "1")      # the library reads its measurement knobs only when asked to
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from soundsym_amd import Engine, synth

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """tools/match_one_timing.py -- ssym_match_one (the reference's own call pattern: one query at a time) per call, refcos and dtw."""
 import os, sys, time
+os.environ.setdefault("SSYM_TEST_HOOKS", "1")      # the library reads its measurement knobs only when asked to
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from soundsym_amd import Engine, synth

@@ -3,6 +3,7 @@
 product library and with one built with -DSSYM_ABL_DROP_MFMA=1 (two of the three MFMAs of a tile: wrong values, valid
 timing) to see what a K = 32 record layout could save at most."""
 import os, sys
+os.environ.setdefault("SSYM_TEST_HOOKS", "1")      # the library reads its measurement knobs only when asked to
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from soundsym_amd import Engine, synth

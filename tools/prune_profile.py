@@ -1,6 +1,7 @@
 """tools/prune_profile.py -- the pruned search (SSYM_DTW_PRUNE) on the bench workload, for rocprofv3:
     rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prune_prof -- python3 tools/prune_profile.py"""
 import os, sys
+os.environ.setdefault("SSYM_TEST_HOOKS", "1")      # the library reads its measurement knobs only when asked to
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

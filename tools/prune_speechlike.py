@@ -4,6 +4,7 @@ a harmonic source through three random formant peaks) with random durations, pit
 by the GPU MFCC front-end, cut at the unit boundaries.  The nearest neighbour of a target segment is then
 another realisation of the same unit -- close, but not a copy."""
 import os, sys, time
+os.environ.setdefault("SSYM_TEST_HOOKS", "1")      # the library reads its measurement knobs only when asked to
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from soundsym_amd import Engine, synth

@@ -1,6 +1,7 @@
 """tools/prune_timing.py -- the early-abandoning filter (SSYM_DTW_PRUNE) beside the full one on the same
 grid: results must be identical; prints both timings and the share of DP cells the pruned run swept."""
 import os, sys, time
+os.environ.setdefault("SSYM_TEST_HOOKS", "1")      # the library reads its measurement knobs only when asked to
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -3,6 +3,7 @@
 (tools/profile_bench.sh with SSYM_PROFILE_PY=tools/ragged_profile_cmd.py).
 usage: ragged_profile_cmd.py [n] [lo] [hi] [reps] [planted 0|1]"""
 import os, sys
+os.environ.setdefault("SSYM_TEST_HOOKS", "1")      # the library reads its measurement knobs only when asked to
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from soundsym_amd import Engine, synth

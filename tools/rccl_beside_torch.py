@@ -7,6 +7,7 @@ World size 1 (RCCL cannot put two ranks on one device): what this checks is that
 in one process, not the transport."""
 import json
 import os
+os.environ.setdefault("SSYM_TEST_HOOKS", "1")      # the library reads its measurement knobs only when asked to
 import sys
 
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

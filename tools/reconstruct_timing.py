@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of the reconstruction gather (row F2): kernel time from HIP events against HBM bytes."""
 import os, sys
+os.environ.setdefault("SSYM_TEST_HOOKS", "1")      # the library reads its measurement knobs only when asked to
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from soundsym_amd import Engine

@@ -2,6 +2,7 @@
 """tools/refcos_abl.py -- main_ms of the refcos search on the benchmark's shape under whatever library SSYM_LIB names
 (ablation builds: -DSSYM_RM_NOEPI, -DSSYM_RM_NOFETCH: wrong values, valid timing -- results are not checked here)."""
 import os, sys
+os.environ.setdefault("SSYM_TEST_HOOKS", "1")      # the library reads its measurement knobs only when asked to
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from soundsym_amd import Engine, synth

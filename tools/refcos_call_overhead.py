@@ -2,6 +2,7 @@
 """tools/refcos_call_overhead.py -- wall time of one refcos search call against its device time (ssym_get_timings), with
 the results coming back to host arrays and with the results left on the device: what the host side of a call costs."""
 import os, sys, time
+os.environ.setdefault("SSYM_TEST_HOOKS", "1")      # the library reads its measurement knobs only when asked to
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -3,6 +3,7 @@
 on ragged segments: the exact tile kernel of csrc/refcos.hip (refcos_sims8_kernel, eight lanes per pair).  Device time
 is the match's main_ms with the matrix pipe switched off, which runs the same kernel on every pair."""
 import os, sys
+os.environ.setdefault("SSYM_TEST_HOOKS", "1")      # the library reads its measurement knobs only when asked to
 os.environ["SSYM_REFCOS_MFMA"] = "0"
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -6,6 +6,7 @@ through the library's MFCC front-end (ssym_mfcc), is cut into 4096 dictionary se
 targets (other stretches of the same recording), and is searched through the integer filter and through the f64 filter:
 pairs keyed exactly per target, times, and that both return the same indices and values."""
 import os, sys, time
+os.environ.setdefault("SSYM_TEST_HOOKS", "1")      # the library reads its measurement knobs only when asked to
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from soundsym_amd import Engine

@@ -2,6 +2,7 @@
 """tools/refcos_profile_cmd.py -- the refcos search on the benchmark's shape, a few steps: the command the refcos profile
 in profiles/ is taken over (SSYM_PROFILE_PY=tools/refcos_profile_cmd.py tools/profile_bench.sh <tag> 5)."""
 import os, sys
+os.environ.setdefault("SSYM_TEST_HOOKS", "1")      # the library reads its measurement knobs only when asked to
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from soundsym_amd import Engine, synth

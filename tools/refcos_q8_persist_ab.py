@@ -2,6 +2,7 @@
 """refcos_q8_kernel: persistent workgroups with the next tile's chunks requested before the epilogue (default) against one
 workgroup per tile (SSYM_REFCOS_Q8_PERSIST=0 is read once per process: run this script twice)."""
 import os, sys
+os.environ.setdefault("SSYM_TEST_HOOKS", "1")      # the library reads its measurement knobs only when asked to
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from soundsym_amd import Engine, synth

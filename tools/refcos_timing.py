@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """tools/refcos_timing.py -- the reference's own metric (refcos_sims_kernel + fold) on the benchmark's shape and on ragged segments."""
 import os, sys
+os.environ.setdefault("SSYM_TEST_HOOKS", "1")      # the library reads its measurement knobs only when asked to
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from soundsym_amd import Engine, synth

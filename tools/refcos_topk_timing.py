@@ -3,6 +3,7 @@
 segments of 128 frames x 12 values), wall clock per call: through the f64 matrix pipe (default) or, with
 SSYM_REFCOS_MFMA=0 (read once per process), on the exact tile kernel over every pair."""
 import os, sys, time
+os.environ.setdefault("SSYM_TEST_HOOKS", "1")      # the library reads its measurement knobs only when asked to
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from soundsym_amd import Engine, synth

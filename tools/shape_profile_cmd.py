@@ -2,6 +2,7 @@
 """One dtw search on uniform or ragged lengths, repeated: a command for rocprofv3 (tools/kernel_pmc.sh, tools/profile_cmd.sh).
 usage: shape_profile_cmd.py n "slo-shi:tlo-thi" [reps]"""
 import os, sys
+os.environ.setdefault("SSYM_TEST_HOOKS", "1")      # the library reads its measurement knobs only when asked to
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from soundsym_amd import Engine, synth

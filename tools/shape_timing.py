@@ -2,6 +2,7 @@
 """Filter time over source / target length ranges: where short segments lose against long ones.
 usage: shape_timing.py n "slo-shi:tlo-thi" ...   (inclusive frame ranges)"""
 import os, sys
+os.environ.setdefault("SSYM_TEST_HOOKS", "1")      # the library reads its measurement knobs only when asked to
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from soundsym_amd import Engine, synth

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Phase timings when no target has a near-duplicate source (the per-rank view in a sharded run)."""
 import os, sys
+os.environ.setdefault("SSYM_TEST_HOOKS", "1")      # the library reads its measurement knobs only when asked to
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from soundsym_amd import Engine, synth

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Frames wider than the filter's 42 values: the lower-bound cascade against the exact kernel on every pair."""
 import os, sys
+os.environ.setdefault("SSYM_TEST_HOOKS", "1")      # the library reads its measurement knobs only when asked to
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from soundsym_amd import Engine, synth

@@ -2,6 +2,7 @@
 """tools/wideband_timing.py -- a Sakoe-Chiba band beyond the banded kernel (r = 64): the unbanded filter as a lower bound
 against the exact kernel on every pair."""
 import os, sys
+os.environ.setdefault("SSYM_TEST_HOOKS", "1")      # the library reads its measurement knobs only when asked to
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from soundsym_amd import Engine, synth
