@@ -300,9 +300,16 @@ static void launch_one(hipStream_t st, const SegmentSet &src, const SegmentSet &
 #endif
             constexpr int OCCSP = (NT == 1 && KU == 2) ? 3 : (NT == 2 && KU == 2) ? SSYM_SP_OCC_NT2 : 2;
             const int gridSp = std::min(gridBlocks / OCC * OCCSP, (blocksWanted + 7) / 8 * 8);
+            // source pairs per block of the task order: about 1 MB of their records (an XCD's L2 holds 4 MB: the block, the
+            // XCD's target groups, the cost rows being written); SSYM_SP_PAIRBLOCK overrides (0: one block, the old order)
+            static const char *pbKnob = ssym_knob("SSYM_SP_PAIRBLOCK");
+            int pairBlock = std::max(16, (1 << 20) / (2 * 16 * NT * kFilterRecHalfs * 2));
+            if (pbKnob)
+                pairBlock = atoi(pbKnob) > 0 ? atoi(pbKnob) : nSrcPairs;
             dtw_filter_sp_kernel<NT, SQ, OCCSP, KU, kSpRowBlock><<<dim3(gridSp), 64 * kFilterWavesPerBlock, 0, st>>>(
                 (const _Float16 *)src.rec, (const _Float16 *)tgt.rec, src.len, tgt.len, (int)src.frames_pad,
-                (int)tgt.frames_pad, (int)tgt.n_pad, nSrcPairs, nTasks, taskChunk, outScale, taskCtr, cmat, rowOrigin, spBase);
+                (int)tgt.frames_pad, (int)tgt.n_pad, nSrcPairs, nTasks, taskChunk, outScale, taskCtr, cmat, rowOrigin, spBase,
+                std::min(pairBlock, std::max(nSrcPairs, 1)));
             if (cellsOut)
                 *cellsOut += launch_cells(src, tgt, spBase, nSrcPairs, rowOrigin, 16 * NT, 1, kSpRowBlock, kSpRing);
             return;

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_sp_
     const _Float16 *__restrict__ srcRec, const _Float16 *__restrict__ tgtRec,
     const int *__restrict__ srcLen, const int *__restrict__ tgtLen, int srcRows, int tgtFramesPad, int mPad,
     int nSrcPairs, int nTasks, int taskChunk, float outScale, unsigned *__restrict__ taskCtr,
-    float *__restrict__ cmat, int rowOrigin, int spBase)
+    float *__restrict__ cmat, int rowOrigin, int spBase, int pairBlock)
 {
     constexpr int REC = kFilterRecHalfs;
     constexpr int BR = NT * 16;
@@ -176,16 +176,21 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_sp_
 
     // ---- task sequence: eight XCD-local counters (workgroups b, b + 8, ... share an XCD), handed out one task ahead.
     // XCD x owns the target groups x, x + 8, x + 16, ... -- groups are ordered by length, so every XCD gets the same mix
-    // of short and long targets (dtw_filter_kernel's contiguous ranges gave the last XCD eight times the first one's work
-    // on 5...40-frame targets) -- times all source pairs; a range is walked from its END (longest targets and sources
-    // first); a wave whose range is spent helps the next XCD's.  Inside a chunk the walk is a decrement: one division per
-    // grab, none per task.
+    // of short and long targets (contiguous ranges gave the last XCD eight times the first one's work on 5...40-frame
+    // targets) -- times all source pairs.  Its range is ordered [block of `pairBlock` source pairs][its groups][pairs of the
+    // block]: a block's source records (about 1 MB) and the XCD's target groups stay in its L2 while every (group, pair) of
+    // the block is worked off -- with all pairs under one group the sources did not fit the L2 and were fetched from the
+    // Infinity Cache once per target group (1.0 GB of fabric traffic per 4096 x 4096 search of 5...40-frame segments).  The
+    // short first block takes the remainder; a range is walked from its END (longest sources and targets first); a wave
+    // whose range is spent helps the next XCD's.  Inside a chunk the walk is a decrement: divisions per grab, none per task.
     const unsigned nGroups = (unsigned)mPad >> 5;
-    unsigned hop = 0, xcd = 0, rangeLen = 0, chunkLeft = 0;
-    int ctg = 0, csp = 0;                        // the next task of the chunk: target group, source pair of the launch
+    const unsigned PB = (unsigned)max(pairBlock, 1), firstBlock = (unsigned)nSrcPairs % PB;     // pairs [0, firstBlock) form block 0
+    unsigned hop = 0, xcd = 0, rangeLen = 0, chunkLeft = 0, nG = 0;
+    int ctg = 0, csp = 0, cLo = 0, cHi = 0;      // the next task of the chunk: target group, source pair; its block's pairs [cLo, cHi)
     auto set_range = [&]() {
         xcd = (blockIdx.x + hop) & 7u;
-        rangeLen = xcd < nGroups ? ((nGroups - xcd + 7u) >> 3) * (unsigned)nSrcPairs : 0u;
+        nG = xcd < nGroups ? (nGroups - xcd + 7u) >> 3 : 0u;
+        rangeLen = nG * (unsigned)nSrcPairs;
     };
     set_range();
     auto next_task = [&](int &tg, int &sp) -> bool {      // false when every range is spent
@@ -194,9 +199,15 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_sp_
                 tg = ctg;
                 sp = csp;
                 --chunkLeft;
-                if (--csp < 0) {
-                    csp = nSrcPairs - 1;
+                if (--csp < cLo) {                        // the block's pairs under the next (shorter) group ...
+                    csp = cHi - 1;
                     ctg -= 8;
+                    if (ctg < 0) {                        // ... or, all its groups done, the block before it
+                        cHi = cLo;
+                        cLo = max(cLo - (int)PB, 0);
+                        csp = cHi - 1;
+                        ctg = (int)(xcd + 8u * (nG - 1u));
+                    }
                 }
                 return true;
             }
@@ -210,9 +221,22 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_sp_
             SSYM_SP_T(tg1);
             SSYM_SP_ACC(4, tg1 - tg0);
             if (got < rangeLen) {
-                const unsigned i = rangeLen - 1u - got, gl = i / (unsigned)nSrcPairs;
+                const unsigned i = rangeLen - 1u - got, head = nG * firstBlock;      // position in the range; tasks of block 0
+                unsigned gl, within;
+                if (i < head) {
+                    cLo = 0;
+                    cHi = (int)firstBlock;
+                    gl = i / firstBlock;
+                    within = i - gl * firstBlock;
+                } else {
+                    const unsigned r = i - head, perBlock = nG * PB, b = r / perBlock, rb = r - b * perBlock;
+                    cLo = (int)(firstBlock + b * PB);
+                    cHi = cLo + (int)PB;
+                    gl = rb / PB;
+                    within = rb - gl * PB;
+                }
                 chunkLeft = min((unsigned)taskChunk, rangeLen - got);
-                csp = (int)(i - gl * (unsigned)nSrcPairs);
+                csp = cLo + (int)within;
                 ctg = (int)(xcd + 8u * gl);
             } else {
                 ++hop;
