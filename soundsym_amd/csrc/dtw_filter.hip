@@ -465,11 +465,12 @@ int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
     // (sized for the three-workgroups-per-CU launch of the one-tile kernel too)
     const size_t handBytes = (size_t)(gridBlocks / 2 * 3) * kFilterWavesPerBlock * ((tgt.frames_pad + 3) / 4) * 256 * sizeof(float);
     const size_t ctrBytes = 8 * kTaskCtrStride * sizeof(unsigned);
-    rc = ensure(ctx, ctx->handoff, handBytes + 4 * ctrBytes);
+    constexpr int kMaxClasses = 10;                 // counter sets: three single-pass classes + up to seven multi-pass ones
+    rc = ensure(ctx, ctx->handoff, handBytes + kMaxClasses * ctrBytes);
     if (rc != SSYM_OK)
         return rc;
     unsigned *taskCtr = (unsigned *)((char *)ctx->handoff.ptr + handBytes);
-    rc = zero_words(ctx, taskCtr, 4 * ctrBytes);
+    rc = zero_words(ctx, taskCtr, kMaxClasses * ctrBytes);
     if (rc != SSYM_OK)
         return rc;
     hipStream_t st = ctx->stream;
@@ -530,12 +531,58 @@ int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
         SSYM_LAUNCH(2, 1, rowsPad - 32, bound[1], bound[2], 1)
         SSYM_LAUNCH(3, 1, rowsPad - 48, bound[2], bound[3], 2)
         static const bool nt8 = ssym_knob("SSYM_FILTER_NT8") != nullptr;
+        static const bool oneLong = ssym_knob("SSYM_FILTER_LONG_CLASSES") && atoi(ssym_knob("SSYM_FILTER_LONG_CLASSES")) == 0;
         if (shape.nt == 2) {
             SSYM_LAUNCH(2, shape.rb, 0, bound[3], nPairs, 3)
         } else if (nt8 && shape.rb == 2 && !abandon) {
             SSYM_LAUNCH(8, 1, 0, bound[3], nPairs, 3)
-        } else {
+        } else if (abandon || oneLong || oneLaunch) {
             SSYM_LAUNCH(4, shape.rb, 0, bound[3], nPairs, 3)
+        } else {
+            // Sources beyond 48 frames, ragged: a pair pays whole row passes, so a 70-frame source swept in passes of 64
+            // rows pays 128 -- but 96 in passes of 48.  The pairs (ascending by length) are cut into classes by the shape
+            // that pads them least, passes of 64 rows (four tiles) or of 48 (three), the last rows of their end-aligned
+            // slots as for the short classes; a class of fewer than 128 pairs rides with the next one (any larger shape
+            // holds it), and so does everything beyond the counter sets there are.  Equal lengths: one class, the set's
+            // own shape, as before.
+            struct LongClass { int nt, passes, lo, hi; };
+            LongClass cls[kMaxClasses];
+            int nCls = 0;
+            auto best = [&](uint32_t len, int &nt, int &passes) {
+                const int p4 = (int)((std::max(len, 1u) + 63) / 64), p3 = (int)((std::max(len, 1u) + 47) / 48);
+                if (48 * p3 < 64 * p4) { nt = 3; passes = p3; } else { nt = 4; passes = p4; }
+            };
+            for (int sp = bound[3]; sp < nPairs;) {
+                int nt, passes;
+                best(sp < nRealPairs ? pairLen(sp) : 0u, nt, passes);
+                // the run of pairs this shape is the best for: up to the first pair longer than its rows
+                const int end = std::max(sp + 1, std::min(nPairs, sp < nRealPairs ? firstAbove((uint32_t)(16 * nt * passes)) : nPairs));
+                cls[nCls++] = LongClass{nt, passes, sp, end == nRealPairs ? nPairs : end};     // (padding pairs ride with the last real one)
+                sp = cls[nCls - 1].hi;
+                if (nCls == kMaxClasses - 3 && sp < nPairs) {                                   // no counter set left: the set's own shape takes the rest
+                    cls[nCls - 1] = LongClass{4, shape.rb, cls[nCls - 1].lo, nPairs};
+                    break;
+                }
+            }
+            // small classes join their successor (whose rows are at least theirs); the last one keeps its own
+            for (int c = 0; c + 1 < nCls;) {
+                if (cls[c].hi - cls[c].lo < 128) {
+                    cls[c + 1].lo = cls[c].lo;
+                    for (int k = c; k + 1 < nCls; ++k)
+                        cls[k] = cls[k + 1];
+                    --nCls;
+                } else {
+                    ++c;
+                }
+            }
+            for (int c = 0; c < nCls; ++c) {
+                const int origin = rowsPad - 16 * cls[c].nt * cls[c].passes;
+                if (cls[c].nt == 3) {
+                    SSYM_LAUNCH(3, cls[c].passes, origin, cls[c].lo, cls[c].hi, 3 + c)
+                } else {
+                    SSYM_LAUNCH(4, cls[c].passes, origin, cls[c].lo, cls[c].hi, 3 + c)
+                }
+            }
         }
     } else if (topTiles == 3) {
         SSYM_LAUNCH(1, 1, rowsPad - 16, bound[0], bound[1], 0)

@@ -267,3 +267,37 @@ def test_ragged_4096x4096_refcos(oracle):
     want_idx, want_val = oracle.refcos_match_all(sf, so, ts, tos, 12)
     assert np.array_equal(idx[pick], want_idx) and np.array_equal(val[pick], want_val)
     r.close()
+
+
+def test_ragged_long_sources_multi_pass_classes(dtw, oracle):
+    """Sources beyond 48 frames of ragged length run in classes by the row passes that pad them least (passes of 48 or 64
+    rows, dtw_filter.hip): 1024 sources of 49...200 frames against 256 targets of 20...150 frames -- several multi-pass
+    launches -- with 16 sampled targets held against the oracle over all sources, and the same search with every long pair
+    in the set's own shape (SSYM_FILTER_LONG_CLASSES semantics are a measurement knob; here the answers must simply be the
+    oracle's)."""
+    from soundsym_amd.engine import pack_segments
+    st = synth.Stream(0x5EED0A90)
+    sig = synth.sigma(13)
+    ls = 49 + st.integers(1024, 152)
+    lt = 20 + st.integers(256, 131)
+    src = [(st.normal(int(f) * 13).reshape(int(f), 13) * sig).astype(np.float32) for f in ls]
+    tgt = [(st.normal(int(f) * 13).reshape(int(f), 13) * sig).astype(np.float32) for f in lt]
+    for t in range(0, 256, 5):                                   # plant neighbours of another length for a fifth of the targets
+        a = src[(7 * t) % 1024]
+        rows = np.rint(np.linspace(0.0, a.shape[0] - 1.0, max(20, a.shape[0] - 3))).astype(np.int64)
+        tgt[t] = (a[rows] + 0.05 * sig * st.normal(rows.size * 13).reshape(rows.size, 13)).astype(np.float32)
+    sf, so = pack_segments(src, 13, np.float32)
+    tf, to = pack_segments(tgt, 13, np.float32)
+    d, q = dtw.dictionary(sf, so, 13), dtw.queries(tf, to, 13)
+    idx, cost = dtw.match(d, q)
+    tm = dtw.timings()
+    assert tm["used_filter"] == 1 and tm["main_launches"] >= 3, tm
+    true_cells = float(np.diff(so).astype(np.float64).sum()) * float(np.diff(to).astype(np.float64).sum())
+    assert true_cells <= tm["n_filter_cells"] <= 1.45 * true_cells, tm["n_filter_cells"] / true_cells
+    idx2, cost2 = dtw.match(d, q)
+    assert np.array_equal(idx, idx2) and np.array_equal(cost, cost2)
+    pick = np.arange(0, 256, 16)
+    ts, tos = pack_segments([tgt[i] for i in pick], 13, np.float32)
+    want_idx, want_cost = oracle.dtw_match_all(sf.astype(np.float64), so, ts.astype(np.float64), tos, 13, nthreads=16)
+    assert np.array_equal(idx[pick], want_idx)
+    assert np.allclose(cost[pick], want_cost, rtol=1e-12, atol=0)
