@@ -226,7 +226,7 @@ static int32_t ensure_records(ssym_ctx *ctx, const SegmentSet &set, double scale
 // dtw_filter_sp_kernel skips leading row blocks of `rowBlock` rows), per target group the columns of its longest member
 // (at least `minCols`).  Rows depend on the pair only and columns on the group only, so the sum is a product.
 static unsigned long long launch_cells(const SegmentSet &src, const SegmentSet &tgt, int spBase, int nSrcPairs,
-                                       int rowOrigin, int passRows, int nPasses, int rowBlock, int minCols)
+                                       int rowOrigin, int passRows, int nPasses, int rowBlock, int minCols, int pairsPerTask = 1)
 {
     auto len = [](const SegmentSet &set, uint32_t slot) -> uint32_t {
         if (slot >= set.n)
@@ -242,7 +242,12 @@ static unsigned long long launch_cells(const SegmentSet &src, const SegmentSet &
         cols += rowBlock ? std::max<uint32_t>(m, (uint32_t)minCols) : m;
     }
     for (int sp = spBase; sp < spBase + nSrcPairs; ++sp) {
-        const int longer = (int)std::max(len(src, 2u * sp), len(src, 2u * sp + 1u));
+        int longer = (int)std::max(len(src, 2u * sp), len(src, 2u * sp + 1u));
+        if (pairsPerTask > 1) {                  // multi-pair tasks: every pair of a task starts at the task's first row block
+            const int first = spBase + (sp - spBase) / pairsPerTask * pairsPerTask;
+            for (int k = first; k < std::min(first + pairsPerTask, spBase + nSrcPairs); ++k)
+                longer = std::max(longer, (int)std::max(len(src, 2u * k), len(src, 2u * k + 1u)));
+        }
         const int r0min = (int)src.frames_pad - longer;
         if (rowBlock) {
             const int sk = std::min(std::max(r0min - rowOrigin, 0), 15) / rowBlock;
@@ -293,6 +298,30 @@ static void launch_one(hipStream_t st, const SegmentSet &src, const SegmentSet &
     // (dtw_filter_sp_kernel.hpp; SSYM_FILTER_SP=0 keeps dtw_filter_kernel for A/B measurements, same bits either way)
     static const bool spOn = !(ssym_knob("SSYM_FILTER_SP") && atoi(ssym_knob("SSYM_FILTER_SP")) == 0);
     // (with three operand planes its LDS -- ring and staging block -- admits two workgroups per CU up to two tiles)
+    // sources of at most 16 frames: three source pairs per wave (two with three operand planes: LDS), dtw_filter_sp_kernel MP
+    static const bool mpOn = !(ssym_knob("SSYM_SP_MULTIPAIR") && atoi(ssym_knob("SSYM_SP_MULTIPAIR")) == 0);
+    if constexpr (NT == 1) {
+        if (!abandon && nPasses == 1 && spOn && mpOn) {
+            constexpr int MPN = KU == 2 ? 3 : 2;
+            const int taskPairs = (nSrcPairs + MPN - 1) / MPN;
+            const int mpTasks = taskPairs * nTgtGroups;
+            const int gridMp = std::min(gridBlocks / OCC * 2, ((mpTasks + kFilterWavesPerBlock - 1) / kFilterWavesPerBlock + 7) / 8 * 8);
+            const long cellsMp = (long)(16 * MPN) * std::max<long>(meanTgt, 1);
+            int chunkMp = (int)std::max(1L, std::min(8L, 8192 / std::max(1L, cellsMp)));
+            chunkMp = std::max(1, std::min(chunkMp, mpTasks / std::max(1, gridMp * kFilterWavesPerBlock * 16)));
+            static const char *pbKnob = ssym_knob("SSYM_SP_PAIRBLOCK");
+            int pairBlock = std::max(16, (1 << 20) / (MPN * 2 * 16 * kFilterRecHalfs * 2));
+            if (pbKnob)
+                pairBlock = atoi(pbKnob) > 0 ? atoi(pbKnob) : taskPairs;
+            dtw_filter_sp_kernel<MPN, SQ, 2, KU, kSpRowBlock, true><<<dim3(gridMp), 64 * kFilterWavesPerBlock, 0, st>>>(
+                (const _Float16 *)src.rec, (const _Float16 *)tgt.rec, src.len, tgt.len, (int)src.frames_pad,
+                (int)tgt.frames_pad, (int)tgt.n_pad, taskPairs, nSrcPairs, chunkMp, outScale, taskCtr, cmat, rowOrigin, spBase,
+                std::min(pairBlock, std::max(taskPairs, 1)));
+            if (cellsOut)
+                *cellsOut += launch_cells(src, tgt, spBase, nSrcPairs, rowOrigin, 16, 1, kSpRowBlock, kSpRing, MPN);
+            return;
+        }
+    }
     if constexpr (NT <= 3 && (KU == 2 || NT <= 2)) {
         if (!abandon && nPasses == 1 && spOn) {
 #ifndef SSYM_SP_OCC_NT2

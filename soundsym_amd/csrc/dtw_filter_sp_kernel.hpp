@@ -67,9 +67,15 @@ constexpr int sp_slot_bytes(int ku) { return ku * 1024; }      // 64 lanes x KU 
 // MFMA chain is in flight while a tile's cells run.  Lr = D(., j-1), Lw = D(., j).  Straight-line code.
 // FIRST: column 0, where D(i, 0) = c(i, 0) + (i == the source's first row ? 0 : D(i - 1, 0)) -- nothing is read from the
 // column before it, so neither column array needs initialising when a task starts (r0rel: the lane's first real row).
-template <int NT, bool SQ, int KU, int R0, bool FIRST>
-__device__ __forceinline__ float dp_column_sp(const half8 (&A)[NT][KU], const half8 (&Bc)[KU], const half8 (&Bn)[KU],
-                                              f32x16 &acc, int r0rel, const float (&Lr)[NT * 16], float (&Lw)[NT * 16])
+// MP ("multi-pair", one-tile sources): the NT tiles of a column are NT DIFFERENT source pairs of at most 16 frames each --
+// NT independent recurrences per lane against the same target column.  One-tile columns fetched 2 KB of target operands for
+// 8...16 cells per lane and ran into the DMA path's 36 bytes per clock and CU (the one-tile class lost 13-21 % to its own
+// staging, tools: -DSSYM_SP_NOSTAGE); three pairs per wave take a third of the bytes per cell, amortise the column's
+// overhead over three times the cells and give the wave three independent chains to issue from.
+template <int NT, bool SQ, int KU, int R0, bool FIRST, bool MP>
+__device__ __forceinline__ void dp_column_sp(const half8 (&A)[NT][KU], const half8 (&Bc)[KU], const half8 (&Bn)[KU],
+                                             f32x16 &acc, const int (&r0rel)[MP ? NT : 1], const float (&Lr)[NT * 16],
+                                             float (&Lw)[NT * 16], float (&bottom)[MP ? NT : 1])
 {
     float up = __builtin_inff(), diag = __builtin_inff();
 #pragma unroll
@@ -79,14 +85,18 @@ __device__ __forceinline__ float dp_column_sp(const half8 (&A)[NT][KU], const ha
             accn = mfma_tile<KU>(A[T + 1], Bc);
         else
             accn = mfma_tile<KU>(A[0], Bn);   // first tile of the next column
+        if (MP) {                             // another pair: its recurrence starts afresh
+            up = __builtin_inff();
+            diag = __builtin_inff();
+        }
 #pragma unroll
-        for (int r = (T == 0 ? R0 : 0); r < 16; ++r) {
+        for (int r = ((MP || T == 0) ? R0 : 0); r < 16; ++r) {
             const int idx = T * 16 + r;
             const float x = acc[r];
             const float c = SQ ? __builtin_fabsf(x) : __builtin_amdgcn_sqrtf(__builtin_fabsf(x));
             float m;
             if (FIRST) {
-                m = (idx == r0rel) ? 0.0f : up;
+                m = ((MP ? r : idx) == r0rel[MP ? T : 0]) ? 0.0f : up;
             } else {
                 m = __builtin_fminf(__builtin_fminf(up, diag), Lr[idx]);
                 diag = Lr[idx];
@@ -95,9 +105,12 @@ __device__ __forceinline__ float dp_column_sp(const half8 (&A)[NT][KU], const ha
             Lw[idx] = cur;
             up = cur;
         }
+        if (MP)
+            bottom[T] = up;                   // D(last row of this pair, j)
         acc = accn;
     }
-    return up;   // D(last row, j)
+    if (!MP)
+        bottom[0] = up;                       // D(last row, j)
 }
 
 // BYTES per lane: (scalar base + the lane's constant offset) -> LDS block l (+ OFF on both sides).  The base is made opaque
@@ -128,13 +141,15 @@ __device__ __forceinline__ int wave_max_lo32(int v)
 // LDS per wave: the ring, then the next task's source operands [NT][KU][64 lanes][16 B] and lengths [2][64 lanes][4 B]
 constexpr int sp_wave_lds(int nt, int ku) { return kSpRing * sp_slot_bytes(ku) + nt * ku * 1024 + 512; }
 
-template <int NT, bool SQ, int OCC, int KU, int G>
+// nSrcPairs: the launch's source pairs -- MP: its TASK pairs, NT source pairs each, of which the launch holds pairLimit
+template <int NT, bool SQ, int OCC, int KU, int G, bool MP = false>
 __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_sp_kernel(
     const _Float16 *__restrict__ srcRec, const _Float16 *__restrict__ tgtRec,
     const int *__restrict__ srcLen, const int *__restrict__ tgtLen, int srcRows, int tgtFramesPad, int mPad,
-    int nSrcPairs, int nTasks, int taskChunk, float outScale, unsigned *__restrict__ taskCtr,
+    int nSrcPairs, int pairLimit, int taskChunk, float outScale, unsigned *__restrict__ taskCtr,
     float *__restrict__ cmat, int rowOrigin, int spBase, int pairBlock)
 {
+    constexpr int NP = MP ? NT : 1;                              // source pairs per task
     constexpr int REC = kFilterRecHalfs;
     constexpr int BR = NT * 16;
     constexpr int SLOT = sp_slot_bytes(KU);
@@ -171,7 +186,7 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_sp_
         const int arow = lane & 31;
         laneA = (unsigned)((((arow >> 2) & 1) * srcRows + rowOrigin + (arow & 3) + 4 * (arow >> 3)) * (REC * 2) + half * 48);
     }
-    unsigned laneSrcLen = half * 4, laneTgtLen = col * 4;
+    unsigned laneSrcLen = (MP ? min(lane, 2 * NP - 1) : half) * 4, laneTgtLen = col * 4;     // (MP: the 2 NP lengths of the task's pairs)
     unsigned laneOut = ((unsigned)half * (unsigned)mPad + (unsigned)col) * 4u;               // (mPad < 2^29: n_pad is 32 bits)
 
     // ---- task sequence: eight XCD-local counters (workgroups b, b + 8, ... share an XCD), handed out one task ahead.
@@ -245,10 +260,10 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_sp_
             }
         }
     };
-    // frame slot c of target group tg -> ring slot of virtual column vcol
-    auto stage = [&](int tg, int c, unsigned vcol) {
-        const char *gb = reinterpret_cast<const char *>(tgtRec) + (unsigned long long)tg * groupBytes +
-                         (unsigned long long)min(c, lastSlot) * kColBytes;
+    // frame slot c of the target group at `base` -> ring slot of virtual column vcol (a group's slots span less than 2^32 bytes)
+    auto group_base = [&](int tg) { return reinterpret_cast<const char *>(tgtRec) + (unsigned long long)tg * groupBytes; };
+    auto stage = [&](const char *base, int c, unsigned vcol) {
+        const char *gb = base + (unsigned)min(c, lastSlot) * kColBytes;
         char *slot = myRing + (vcol & (kSpRing - 1)) * SLOT;
         SSYM_SP_DMA(gb, laneOff16, slot, 16, 0);
         SSYM_SP_DMA(gb, laneOff16, slot, 16, 1024);
@@ -262,15 +277,21 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_sp_
             B[m] = *reinterpret_cast<const half8 *>(slot + m * 1024 + lane * 16);
     };
     // a task's lengths and source operands -> the staging block (P DMAs)
+    // (MP: task pair sp holds the launch's source pairs NP sp ... NP sp + NP - 1; those beyond pairLimit belong to the next
+    //  class: their operands are read from the launch's last pair instead, their lengths count as 0, nothing is stored)
+    auto first_pair = [&](int sp) { return spBase + (MP ? NP * sp : sp); };
     auto prefetch = [&](int tg, int sp) {
-        SSYM_SP_DMA(reinterpret_cast<const char *>(srcLen + 2 * (spBase + sp)), laneSrcLen, myLen, 4, 0);
+        const int fp = first_pair(sp), lastPair = spBase + pairLimit - 1;
+        SSYM_SP_DMA(reinterpret_cast<const char *>(srcLen + 2 * fp), laneSrcLen, myLen, 4, 0);
         SSYM_SP_DMA(reinterpret_cast<const char *>(tgtLen + 32 * tg), laneTgtLen, myLen + 256, 4, 0);
-        const char *pb = reinterpret_cast<const char *>(srcRec) + (unsigned long long)(spBase + sp) * pairBytes;
 #pragma unroll
-        for (int T = 0; T < NT; ++T)
+        for (int T = 0; T < NT; ++T) {
+            const char *pb = reinterpret_cast<const char *>(srcRec) +
+                             (unsigned long long)(MP ? min(fp + T, lastPair) : fp) * pairBytes + (MP ? 0 : T * (kFilterRowsPerTile * REC * 2));
 #pragma unroll
             for (int m = 0; m < KU; ++m)
-                SSYM_SP_DMA(pb + T * (kFilterRowsPerTile * REC * 2) + m * 16, laneA, myA + (T * KU + m) * 1024, 16, 0);
+                SSYM_SP_DMA(pb + m * 16, laneA, myA + (T * KU + m) * 1024, 16, 0);
+        }
     };
 
     int tg, sp, ntg = 0, nsp = 0;
@@ -284,7 +305,7 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_sp_
     prefetch(tg, sp);                             // the first task: nothing to hide its operands behind
 #pragma unroll
     for (int c = 0; c < kSpRing; ++c)
-        stage(tg, c, (unsigned)c);
+        stage(group_base(tg), c, (unsigned)c);
     bool haveNext = next_task(ntg, nsp);
     {
         SSYM_SP_T(tf0);
@@ -304,7 +325,13 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_sp_
         prof[profMark ? 9 : 8] += tTask0 - (profMark ? profMark : tLife0);
 #endif
         asm volatile("" ::: "memory");
-        const int fa = *reinterpret_cast<const int *>(myLen + lane * 4);
+        int fa[NP];
+#pragma unroll
+        for (int T = 0; T < NP; ++T) {
+            fa[T] = *reinterpret_cast<const int *>(myLen + (MP ? 2 * T + half : lane) * 4);
+            if (MP && NP * sp + T >= pairLimit)               // (wave-uniform)
+                fa[T] = 0;
+        }
         const int fb = *reinterpret_cast<const int *>(myLen + 256 + lane * 4);
         half8 A[NT][KU];
 #pragma unroll
@@ -314,10 +341,15 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_sp_
                 A[T][m] = *reinterpret_cast<const half8 *>(myA + (T * KU + m) * 1024 + lane * 16);
 
         const int fb_m1 = fb - 1;
-        const int r0rel = srcRows - fa - rowOrigin;           // the lane's first real row: sources are END-ALIGNED in their slots
+        int r0rel[NP];                                        // the lane's first real row(s): sources are END-ALIGNED in their slots
+        int r0lo = 16 * NT;
+#pragma unroll
+        for (int T = 0; T < NP; ++T) {
+            r0rel[T] = srcRows - fa[T] - rowOrigin;
+            r0lo = min(r0lo, min(__builtin_amdgcn_readlane(r0rel[T], 0), __builtin_amdgcn_readlane(r0rel[T], 32)));
+        }
         // at least a ring's worth of columns: the ring stays in step (columns beyond a target's end read zero records)
         const int nCols = max(wave_max_lo32(fb), kSpRing);
-        const int r0lo = min(__builtin_amdgcn_readlane(r0rel, 0), __builtin_amdgcn_readlane(r0rel, 32));
         const int sk = min(max(r0lo, 0), 15) / G;             // first row block of the first tile with a frame
 
         // columns 0 and 1 have landed (S(-4), S(-3) of the previous task; younger: S(-2), S(-1), its result store)
@@ -332,7 +364,11 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_sp_
         prefetch(ntg, nsp);
         asm volatile("" ::: "memory");
 
-        float res = INF;
+        float res[NP];
+#pragma unroll
+        for (int T = 0; T < NP; ++T)
+            res[T] = INF;
+        const char *const ownBase = group_base(tg), *const nextBase = group_base(ntg);
         SSYM_SP_T(tCols0);
         SSYM_SP_ACC(3, tCols0 - tTask0);
         SSYM_SP_ACC(5, 1);
@@ -344,14 +380,21 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_sp_
             constexpr int R0 = decltype(r0tag)::value;
             float L0[BR], L1[BR];                             // D(., j) for odd / even j; column 0 needs no column before it
             auto stage_next = [&](int j) {
+#ifndef SSYM_SP_NOSTAGE      // (tools only: timing without the columns' DMAs -- the MFMAs then run on stale bytes)
                 const bool own = j + kSpRing < nCols;
-                stage(own ? tg : ntg, own ? j + kSpRing : j + kSpRing - nCols, vc + j);
+                stage(own ? ownBase : nextBase, own ? j + kSpRing : j + kSpRing - nCols, vc + j);
+#else
+                (void)j;
+#endif
             };
             {
                 fetch(vc + 1, B1);
                 stage_next(0);
-                const float bottom = dp_column_sp<NT, SQ, KU, R0, true>(A, B0, B1, acc, r0rel, L0, L1);
-                res = (0 == fb_m1) ? bottom : res;            // D(fa-1, fb-1)
+                float bottom[NP];
+                dp_column_sp<NT, SQ, KU, R0, true, MP>(A, B0, B1, acc, r0rel, L0, L1, bottom);
+#pragma unroll
+                for (int T = 0; T < NP; ++T)
+                    res[T] = (0 == fb_m1) ? bottom[T] : res[T];            // D(fa-1, fb-1)
             }
             for (int j = 1; j < nCols; j += 2) {
                 {   // odd column j: operands in B1, D(., j-1) in L1
@@ -362,8 +405,11 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_sp_
                     asm volatile("" ::: "memory");
                     fetch(vc + j + 1, B0);
                     stage_next(j);
-                    const float bottom = dp_column_sp<NT, SQ, KU, R0, false>(A, B1, B0, acc, 0, L1, L0);
-                    res = (j == fb_m1) ? bottom : res;
+                    float bottom[NP];
+                    dp_column_sp<NT, SQ, KU, R0, false, MP>(A, B1, B0, acc, r0rel, L1, L0, bottom);
+#pragma unroll
+                    for (int T = 0; T < NP; ++T)
+                        res[T] = (j == fb_m1) ? bottom[T] : res[T];
                 }
                 if (j + 1 < nCols) {                          // even column j + 1 (wave-uniform)
                     if (j == 1)
@@ -373,8 +419,11 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_sp_
                     asm volatile("" ::: "memory");
                     fetch(vc + j + 2, B1);
                     stage_next(j + 1);
-                    const float bottom = dp_column_sp<NT, SQ, KU, R0, false>(A, B0, B1, acc, 0, L0, L1);
-                    res = (j + 1 == fb_m1) ? bottom : res;
+                    float bottom[NP];
+                    dp_column_sp<NT, SQ, KU, R0, false, MP>(A, B0, B1, acc, r0rel, L0, L1, bottom);
+#pragma unroll
+                    for (int T = 0; T < NP; ++T)
+                        res[T] = (j + 1 == fb_m1) ? bottom[T] : res[T];
                 }
             }
         };
@@ -396,11 +445,14 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_sp_
             profMark = tCols1;
 #endif
         }
-        {   // the result: (scalar base of the task) + (the lane's constant offset)
-            char *ob = reinterpret_cast<char *>(cmat) + ((unsigned long long)(2 * (spBase + sp)) * (unsigned)mPad + 32u * (unsigned)tg) * 4ull;
+#pragma unroll
+        for (int T = 0; T < NP; ++T) {   // the result(s): (scalar base of the task's pair) + (the lane's constant offset)
+            if (MP && NP * sp + T >= pairLimit)
+                continue;
+            char *ob = reinterpret_cast<char *>(cmat) + ((unsigned long long)(2 * (first_pair(sp) + T)) * (unsigned)mPad + 32u * (unsigned)tg) * 4ull;
             asm volatile("" : "+s"(ob));
             asm volatile("" : "+v"(laneOut));
-            *reinterpret_cast<float *>(ob + laneOut) = res * outScale;
+            *reinterpret_cast<float *>(ob + laneOut) = res[T] * outScale;
         }
         if (!haveNext)
             break;
