@@ -325,7 +325,7 @@ static void launch_one(hipStream_t st, const SegmentSet &src, const SegmentSet &
     if constexpr (NT <= 3 && (KU == 2 || NT <= 2)) {
         if (!abandon && nPasses == 1 && spOn) {
 #ifndef SSYM_SP_OCC_NT2
-#define SSYM_SP_OCC_NT2 2        // tools: 3 = two-tile tasks at three waves per SIMD (168 registers: four spilled)
+#define SSYM_SP_OCC_NT2 3        // two-tile tasks at three waves per SIMD (162 registers since the loop copies own their operand registers); 2: tools
 #endif
             constexpr int OCCSP = (NT == 1 && KU == 2) ? 3 : (NT == 2 && KU == 2) ? SSYM_SP_OCC_NT2 : 2;
             const int gridSp = std::min(gridBlocks / OCC * OCCSP, (blocksWanted + 7) / 8 * 8);

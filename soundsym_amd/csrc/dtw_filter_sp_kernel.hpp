@@ -355,9 +355,6 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_sp_
         // columns 0 and 1 have landed (S(-4), S(-3) of the previous task; younger: S(-2), S(-1), its result store)
         __builtin_amdgcn_s_waitcnt(kWaitStrict);
         asm volatile("" ::: "memory");
-        half8 B0[KU], B1[KU];
-        fetch(vc, B0);
-        f32x16 acc = mfma_tile<KU>(A[0], B0);
         // every read of the staging block has returned before the next task's operands overwrite it
         __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0)
         asm volatile("" ::: "memory");
@@ -379,6 +376,11 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_sp_
         auto run_columns = [&](auto r0tag) {
             constexpr int R0 = decltype(r0tag)::value;
             float L0[BR], L1[BR];                             // D(., j) for odd / even j; column 0 needs no column before it
+            // (operand registers and the accumulator tile belong to the loop copy: defined in front of the switch they had
+            //  to sit in the same registers at every copy's entry, which cost ~30 registers)
+            half8 B0[KU], B1[KU];
+            fetch(vc, B0);
+            f32x16 acc = mfma_tile<KU>(A[0], B0);
             auto stage_next = [&](int j) {
 #ifndef SSYM_SP_NOSTAGE      // (tools only: timing without the columns' DMAs -- the MFMAs then run on stale bytes)
                 const bool own = j + kSpRing < nCols;
