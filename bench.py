@@ -16,7 +16,14 @@ Workloads (BASELINE.json `configs`), picked with --workload:
   c5            configs[4]: 4096 x 4096 segments, 256 frames x 40 dims, Sakoe-Chiba r = 32, source-sharded
   c2            configs[1]: 1024 x 1024 segments, 64 frames x 13 dims
 --src-per-gpu K switches to WEAK scaling (K sources per GPU, the round-1 mode), --targets / --frames /
---dim / --band override single fields for experiments.
+--dim / --band override single fields for experiments.  --replay-world G (one GPU) measures the step ONE rank of a G-GPU
+run would make: its shard through ssym_match_sharded with the full dictionary's bounds replayed into the bound exchange
+(DESIGN.md section 7); never a multi-GPU result.
+
+Beside the headline the line carries `early_abandon`, `cpu_baseline` and `secondary`: the reference's own metric (refcos),
+the chain, one query at a time, the MFCC front-end, host-resident targets, and `secondary.ragged` -- the reference's REAL
+segment shape (4096 x 4096 segments of 5...40 frames, src/sound.rs:330-343) in both metrics with rates on TRUE cells, and
+BASELINE's configs[0] on the reference's recordings.
 """
 import argparse
 import glob

@@ -18,8 +18,11 @@ true_cells = {1: float(ls[ls <= 16].sum()) * sum_t, 2: float(ls[(ls > 16) & (ls 
               3: float(ls[ls > 32].sum()) * sum_t}
 
 def cls(name):
-    m = re.search(r"dtw_filter_sp_kernelILi(\d)", name)
-    return int(m.group(1)) if m else None
+    # <NT, SQ, OCC, KU, G, MP>: the multi-pair instantiation (MP = true, three one-tile pairs per wave) is the one-tile class
+    m = re.search(r"dtw_filter_sp_kernelILi(\d)ELb[01]ELi\dELi\dELi\d+ELb([01])", name)
+    if not m:
+        return None
+    return 1 if m.group(2) == "1" else int(m.group(1))
 
 stats = []
 for f in glob.glob(os.path.join(src_dir, "trace", "**", "*kernel_stats.csv"), recursive=True):
