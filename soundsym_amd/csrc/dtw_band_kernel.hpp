@@ -49,7 +49,14 @@ constexpr int kBandImagePad = 8;       // halfs between the two sources' LDS ima
 // target's threshold on all 64 lanes.  Tasks then differ in length by an order of magnitude, so the
 // waves of a workgroup take target groups from an LDS counter instead of owning one group per block.
 // KU = operand planes a tile multiplies (2 for record layout 3, whose third plane is zero: dtw_filter_kernel.hpp).
-template <int NTB, int WB, int OCC, bool SQ, int LASTN, bool PRUNE = false, int KU = kFilterKM>
+// PC (pair columns, LASTN == 1 and no PRUNE only): the 16 source frames tile T reads for column j are the diagonals
+// 16T - 1 .. 16T + 14 of column j + 1, so one LDS read of the source operands serves both columns: the steps of a column
+// PAIR run (j, T), (j + 1, T), (j, T + 1), ... on the same in-place column registers (column j + 1 trails column j by
+// one diagonal, which is all the recurrence needs), with two `up` values.  Half of the source reads go; both columns'
+// target operands stay live for the whole pair while the next pair's are in flight (four operand sets instead of two).
+// Bit-identical and NOT faster (configs[4]'s shape: 39.78 ms either way; 13 values +0.6 %): the source reads were not
+// what the columns waited for.  Instantiated by tools builds only (-DSSYM_BAND_PAIRCOLS_BUILD); LAB.md R4.3.
+template <int NTB, int WB, int OCC, bool SQ, int LASTN, bool PRUNE = false, int KU = kFilterKM, bool PC = false>
 __global__ __launch_bounds__(64 * WB, OCC) void dtw_band_kernel(
     const _Float16 *__restrict__ srcRec, const _Float16 *__restrict__ tgtRec,
     const int *__restrict__ srcLen, const int *__restrict__ tgtLen, int srcSlots, int radius,
@@ -262,7 +269,124 @@ __global__ __launch_bounds__(64 * WB, OCC) void dtw_band_kernel(
                 }
             }
         };
-        if constexpr (kBandPhases && NTB >= 4 && !PRUNE) {     // (pruned tasks rarely reach their last columns; half the compile time)
+        // PC: one pass of the same phases, two columns per source read
+        auto run_pairs = [&](auto tlo_c, auto thi_c, const int jBegin, const int jEnd) {
+            constexpr int TLO = decltype(tlo_c)::value, THI = decltype(thi_c)::value;
+            if (jBegin >= jEnd)
+                return;
+            half8 Ac[KU];                                      // the source operands of the tile in hand
+            load_rec(aLane + (size_t)jBegin * REC + (size_t)TLO * 16 * REC, Ac);
+            acc = mfma_tile<KU>(Ac, B0);                       // (jBegin, TLO); B0 / B1 hold columns jBegin, jBegin + 1
+            half8 Bx[KU], By[KU];
+            // columns j (operands P0) and j + 1 (P1); the next pair's operands travel to N0 / N1 meanwhile
+            auto pair = [&](const int j, const half8 (&P0)[KU], const half8 (&P1)[KU], half8 (&N0)[KU], half8 (&N1)[KU]) {
+                load_tgt_rec(bbase, min(j + 2, nCols - 1), N0);
+                load_tgt_rec(bbase, min(j + 3, nCols - 1), N1);
+                const _Float16 *aCol = aLane + (size_t)j * REC;
+                float up0 = INF, up1 = INF;
+                const bool mine0 = j == fb_m1, mine1 = j + 1 == fb_m1;
+                const bool any0 = __any(mine0), any1 = __any(mine1);       // some lane's end cell lies in the column
+#pragma unroll
+                for (int T = TLO; T <= THI; ++T) {
+                    // the next tile's source operands (the first tile of the next pair after the last one)
+                    half8 An[KU];
+                    load_rec(T < THI ? aCol + (size_t)(T + 1) * 16 * REC : aCol + 2 * REC + (size_t)TLO * 16 * REC, An);
+                    // step (j, T): cells of column j, the chain of (j + 1, T) between them
+                    {
+                        f32x16 accn = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                        const int nCells = (T == NTB - 1) ? LASTN : 16;
+#pragma unroll
+                        for (int r = 0; r < nCells; ++r) {
+#pragma unroll
+                            for (int m = 0; m < KU; ++m)
+                                if (r == (nCells >= 11 ? 5 * m : 0))
+                                    accn = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ac[m], P1[m], accn, 0, 0, 0);
+                            const int k = T * 16 + r;
+                            const float x = acc[r];
+                            const float c = SQ ? __builtin_fabsf(x) : __builtin_amdgcn_sqrtf(__builtin_fabsf(x));
+                            const float m3 = __builtin_fminf(__builtin_fminf(up0, L[k]), L[k + 1]);
+                            const float cur = c + m3;
+                            L[k] = cur;
+                            up0 = cur;
+                        }
+                        if (any0) {                            // (before column j + 1 overwrites these diagonals)
+#pragma unroll
+                            for (int r = 0; r < nCells; ++r)
+                                res = (mine0 && T * 16 + r == kstar) ? L[T * 16 + r] : res;
+                        }
+                        acc = accn;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    // step (j + 1, T): the same frames are diagonals 16T - 1 .. 16T + 14 of column j + 1; the chain of
+                    // (j, T + 1) -- of (j + 2, TLO) after the last tile -- between them
+                    {
+                        f32x16 accn = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                        const int rLo = (T == 0) ? 1 : 0, rHi = (T == NTB - 1) ? LASTN + 1 : 16, nCells = rHi - rLo;
+#pragma unroll
+                        for (int r = rLo; r < rHi; ++r) {
+#pragma unroll
+                            for (int m = 0; m < KU; ++m)
+                                if (r - rLo == (nCells >= 11 ? 5 * m : 0))
+                                    accn = __builtin_amdgcn_mfma_f32_32x32x16_f16(An[m], T < THI ? P0[m] : N0[m], accn, 0, 0, 0);
+                            const int k = T * 16 + r - 1;
+                            const float x = acc[r];
+                            const float c = SQ ? __builtin_fabsf(x) : __builtin_amdgcn_sqrtf(__builtin_fabsf(x));
+                            const float m3 = __builtin_fminf(__builtin_fminf(up1, L[k]), L[k + 1]);
+                            const float cur = c + m3;
+                            L[k] = cur;
+                            up1 = cur;
+                        }
+                        // a phase without the last tile(s): the next diagonal of column j + 1 is the first frame of the
+                        // tile left out, beyond the longer source's end
+                        if constexpr (THI < NTB - 1) {
+                            if (T == THI)
+                                L[THI * 16 + 15] = INF;
+                        }
+                        if (any1) {
+#pragma unroll
+                            for (int r = rLo; r < rHi; ++r)
+                                res = (mine1 && T * 16 + r - 1 == kstar) ? L[T * 16 + r - 1] : res;
+                        }
+#pragma unroll
+                        for (int m = 0; m < KU; ++m)
+                            Ac[m] = An[m];
+                        acc = accn;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            };
+            for (int j0 = jBegin; j0 < jEnd; j0 += 4) {
+                pair(j0, B0, B1, Bx, By);
+                if (j0 + 2 < jEnd) {
+                    pair(j0 + 2, Bx, By, B0, B1);
+                } else {
+#pragma unroll
+                    for (int m = 0; m < KU; ++m) {
+                        B0[m] = Bx[m];
+                        B1[m] = By[m];
+                    }
+                }
+            }
+        };
+        if constexpr (PC) {
+            static_assert(!PC || (LASTN == 1 && !PRUNE && NTB >= 4 && kBandPhases), "pair columns: unpruned, 2r + 1 = 16 (NTB - 1) + 1");
+            if (nCols > 1)
+                load_tgt_rec(bbase, 1, B1);
+            else
+                for (int m = 0; m < KU; ++m)
+                    B1[m] = B0[m];
+            // an odd last column computes one column too many (in place, after every end cell has been read): it ends
+            // the task, because every phase boundary but nCols is even
+            const int faMax = max(__shfl(fa, 0), __shfl(fa, 32));
+            const int head = min(max(radius - 15, 0) & ~1, nCols & ~1);
+            const int out1 = faMax + radius - 16 * (NTB - 1), out2 = out1 + 16;
+            const int tail1 = min(max((max(out1, 0) + 2) & ~1, head), (nCols + 1) & ~1);
+            const int tail2 = min(max((max(out2, 0) + 2) & ~1, tail1), (nCols + 1) & ~1);
+            run_pairs(std::integral_constant<int, 1>{}, std::integral_constant<int, NTB - 1>{}, 0, min(head, nCols));
+            run_pairs(std::integral_constant<int, 0>{}, std::integral_constant<int, NTB - 1>{}, head, min(tail1, nCols));
+            run_pairs(std::integral_constant<int, 0>{}, std::integral_constant<int, NTB - 2>{}, tail1, min(tail2, nCols));
+            run_pairs(std::integral_constant<int, 0>{}, std::integral_constant<int, NTB - 3>{}, tail2, nCols);
+        } else if constexpr (kBandPhases && NTB >= 4 && !PRUNE) {     // (pruned tasks rarely reach their last columns; half the compile time)
             // (wave-uniform bounds; every phase boundary is even and inside [0, nCols])
             const int faMax = max(__shfl(fa, 0), __shfl(fa, 32));
             const int head = min(max(radius - 15, 0) & ~1, nCols & ~1);

@@ -376,6 +376,15 @@ static int32_t launch_band_cfg2(ssym_ctx *ctx, const SegmentSet &src, const Segm
     // operand planes the kernel multiplies: record layout 3 leaves the third one zero
     const bool two = filter_mfmas(filter_pieces(filter_dim_used((int)src.dim)), filter_dim_used((int)src.dim)) == 2;
     auto kern = two ? dtw_band_kernel<NTB, WB, OCC, SQ, LASTN, PRUNE, 2> : dtw_band_kernel<NTB, WB, OCC, SQ, LASTN, PRUNE, 3>;
+    // two columns per source read (dtw_band_kernel.hpp, PC): an experiment that measured nothing (LAB.md R4.3), kept out of
+    // the product library -- tools/band_paircols_ab.py builds its own with EXTRA=-DSSYM_BAND_PAIRCOLS_BUILD
+#ifdef SSYM_BAND_PAIRCOLS_BUILD
+    if constexpr (!PRUNE && LASTN == 1 && NTB >= 4 && OCC == 2) {
+        const char *pc = ssym_knob("SSYM_BAND_PAIRCOLS");
+        if (pc && atoi(pc) != 0)
+            kern = two ? dtw_band_kernel<NTB, WB, OCC, SQ, LASTN, PRUNE, 2, true> : dtw_band_kernel<NTB, WB, OCC, SQ, LASTN, PRUNE, 3, true>;
+    }
+#endif
     if (lds > 64 * 1024)
         SSYM_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     kern<<<dim3(grid), 64 * WB, lds, ctx->stream>>>(
