@@ -226,7 +226,8 @@ static int32_t ensure_records(ssym_ctx *ctx, const SegmentSet &set, double scale
 // dtw_filter_sp_kernel skips leading row blocks of `rowBlock` rows), per target group the columns of its longest member
 // (at least `minCols`).  Rows depend on the pair only and columns on the group only, so the sum is a product.
 static unsigned long long launch_cells(const SegmentSet &src, const SegmentSet &tgt, int spBase, int nSrcPairs,
-                                       int rowOrigin, int passRows, int nPasses, int rowBlock, int minCols, int pairsPerTask = 1)
+                                       int rowOrigin, int passRows, int nPasses, int rowBlock, int minCols, int pairsPerTask = 1,
+                                       bool skipTile = false)
 {
     auto len = [](const SegmentSet &set, uint32_t slot) -> uint32_t {
         if (slot >= set.n)
@@ -255,6 +256,8 @@ static unsigned long long launch_cells(const SegmentSet &src, const SegmentSet &
         } else {
             const int firstPass = std::min(std::max(r0min - rowOrigin, 0) / passRows, nPasses - 1);
             rows += (unsigned long long)(nPasses - firstPass) * passRows;
+            if (skipTile && r0min - (rowOrigin + firstPass * passRows) >= 17)      // SKIP0: the first pass's empty first tile
+                rows -= 16;
         }
     }
     return rows * cols;
@@ -264,7 +267,7 @@ template <int NT, bool SQ, int KU>
 static void launch_one(hipStream_t st, const SegmentSet &src, const SegmentSet &tgt, int nPasses,
                        int gridBlocks, float outScale, float *handoff, unsigned *taskCtr, float *cmat,
                        const float *abandon, unsigned long long *colCtr, const uint32_t *candSlot,
-                       int spBase, int nSrcPairs, int rowOrigin, unsigned long long *cellsOut)
+                       int spBase, int nSrcPairs, int rowOrigin, unsigned long long *cellsOut, bool skipTile = false)
 {
     // sources of at most 16 frames (one tile, one pass): three waves per SIMD, see filter_ring() -- 11 %
     // faster there; at 32 frames the gain was within 3 % and cost spills
@@ -341,6 +344,17 @@ static void launch_one(hipStream_t st, const SegmentSet &src, const SegmentSet &
                 std::min(pairBlock, std::max(nSrcPairs, 1)));
             if (cellsOut)
                 *cellsOut += launch_cells(src, tgt, spBase, nSrcPairs, rowOrigin, 16 * NT, 1, kSpRowBlock, kSpRing);
+            return;
+        }
+    }
+    if constexpr (NT == 3 || NT == 4) {
+        if (skipTile && !abandon) {       // a class whose shorter sources leave the first tile of their first pass empty
+            if (cellsOut)
+                *cellsOut += launch_cells(src, tgt, spBase, nSrcPairs, rowOrigin, 16 * NT, nPasses, 0, 0, 1, true);
+            dtw_filter_kernel<NT, SQ, OCC, false, KU, true><<<dim3(grid), 64 * kFilterWavesPerBlock, 0, st>>>(
+                (const _Float16 *)src.rec, (const _Float16 *)tgt.rec, src.len, tgt.len, (int)src.frames_pad, nPasses,
+                (int)tgt.frames_pad, (int)tgt.n_pad, nSrcPairs, nTasks, taskChunk, outScale, handoff, taskCtr, cmat,
+                nullptr, nullptr, nullptr, rowOrigin, spBase);
             return;
         }
     }
@@ -552,9 +566,10 @@ int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
         bound[c] = oneLaunch ? 0 : firstAbove(16u * c);
     // operand planes the kernel multiplies: record layout 3 leaves the third one zero
     const bool two = filter_mfmas(filter_pieces(filter_dim_used((int)src.dim)), filter_dim_used((int)src.dim)) == 2;
+    bool skipTile = false;                          // set for a multi-pass class below
 #define SSYM_LAUNCH1(NT_, SQ_, KU_, PASSES_, ORIGIN_, LO_, HI_, K_)                                               \
     launch_one<NT_, SQ_, KU_>(st, src, tgt, PASSES_, gridBlocks, outScale, hand, taskCtr + (K_) * 8 * kTaskCtrStride, \
-                              cmat, abandon, colCtr, candSlot, LO_, (HI_) - (LO_), ORIGIN_, &ctx->launched_cells)
+                              cmat, abandon, colCtr, candSlot, LO_, (HI_) - (LO_), ORIGIN_, &ctx->launched_cells, skipTile)
 #define SSYM_LAUNCH(NT_, PASSES_, ORIGIN_, LO_, HI_, K_)                                                          \
     if ((HI_) > (LO_)) {                                                                                          \
         ++ctx->filter_launches;                                                                                   \
@@ -613,14 +628,22 @@ int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
                     ++c;
                 }
             }
+            const char *skipKnob = ssym_knob("SSYM_FILTER_SKIP0");        // (read per launch: the tests compare both settings)
+            const bool skipOn = !(skipKnob && atoi(skipKnob) == 0);
             for (int c = 0; c < nCls; ++c) {
                 const int origin = rowsPad - 16 * cls[c].nt * cls[c].passes;
+                // the class's shortest pair leaves the first tile of its first pass empty: the variant that skips such
+                // tiles' cells (equal lengths and classes that fill their rows keep the plain kernel)
+                const int rowsCls = 16 * cls[c].nt * cls[c].passes;
+                const int shortest = cls[c].lo < nRealPairs ? (int)pairLen(cls[c].lo) : rowsCls;
+                skipTile = skipOn && (rowsCls - shortest) % (16 * cls[c].nt) >= 17;
                 if (cls[c].nt == 3) {
                     SSYM_LAUNCH(3, cls[c].passes, origin, cls[c].lo, cls[c].hi, 3 + c)
                 } else {
                     SSYM_LAUNCH(4, cls[c].passes, origin, cls[c].lo, cls[c].hi, 3 + c)
                 }
             }
+            skipTile = false;
         }
     } else if (topTiles == 3) {
         SSYM_LAUNCH(1, 1, rowsPad - 16, bound[0], bound[1], 0)

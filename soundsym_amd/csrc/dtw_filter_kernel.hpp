@@ -123,10 +123,13 @@ __device__ __forceinline__ void load_tgt_rec(const _Float16 *__restrict__ p, int
 
 // One column of one row block: NT tiles, software-pipelined (the next tile's MFMA chain is in
 // flight while this tile's 16 cells run on the VALU).  Lr = D(., j-1), Lw = D(., j).
-template <int NT, bool SQ, int KU>
+// SKIP0 (skip0, wave-uniform): the block's first tile holds nothing but padding rows of both sources and not the row above
+// a source's first either -- its 16 cells are +inf in every column (they are never written: both column arrays start at
+// +inf) and so are the `up` and `diag` values it hands to the second tile.  The tile's MFMAs are still issued.
+template <int NT, bool SQ, int KU, bool SKIP0 = false>
 __device__ __forceinline__ float dp_column(const half8 (&A)[NT][KU], const half8 (&Bc)[KU],
                                            const half8 (&Bn)[KU], f32x16 &acc, float up, float diag,
-                                           const float (&Lr)[NT * 16], float (&Lw)[NT * 16])
+                                           const float (&Lr)[NT * 16], float (&Lw)[NT * 16], const bool skip0 = false)
 {
 #pragma unroll
     for (int T = 0; T < NT; ++T) {
@@ -140,16 +143,21 @@ __device__ __forceinline__ float dp_column(const half8 (&A)[NT][KU], const half8
         up = acc[3];
         Lw[T * 16] = Lr[T * 16];
 #else
+        if (SKIP0 && T == 0 && skip0) {
+            up = __builtin_inff();
+            diag = __builtin_inff();
+        } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int idx = T * 16 + r;
-            const float x = acc[r];
-            const float c = SQ ? __builtin_fabsf(x) : __builtin_amdgcn_sqrtf(__builtin_fabsf(x));
-            const float m = __builtin_fminf(__builtin_fminf(up, diag), Lr[idx]);
-            diag = Lr[idx];
-            const float cur = c + m;
-            Lw[idx] = cur;
-            up = cur;
+            for (int r = 0; r < 16; ++r) {
+                const int idx = T * 16 + r;
+                const float x = acc[r];
+                const float c = SQ ? __builtin_fabsf(x) : __builtin_amdgcn_sqrtf(__builtin_fabsf(x));
+                const float m = __builtin_fminf(__builtin_fminf(up, diag), Lr[idx]);
+                diag = Lr[idx];
+                const float cur = c + m;
+                Lw[idx] = cur;
+                up = cur;
+            }
         }
 #endif
         acc = accn;
@@ -201,7 +209,9 @@ constexpr int wait_vmcnt(int n) { return 0x0F70 | (n & 15) | ((n >> 4) << 14); }
 //
 // KU = the operand planes (K = 16 each) a tile multiplies: 3, or 2 for record layout 3 of ssym_internal.hpp, whose
 // third plane is zero -- neither loaded nor staged nor issued (the record strides stay those of three planes).
-template <int NT, bool SQ, int OCC = 2, bool PRUNE = false, int KU = kFilterKM>
+// SKIP0 (launches of ragged multi-pass classes whose shorter sources leave the first tile of their first pass empty, no
+// PRUNE): that tile's cells are skipped, see dp_column -- a 70-frame source in two passes of 48 rows pays 80 rows of cells.
+template <int NT, bool SQ, int OCC = 2, bool PRUNE = false, int KU = kFilterKM, bool SKIP0 = false>
 __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_kernel(
     const _Float16 *__restrict__ srcRec, const _Float16 *__restrict__ tgtRec,
     const int *__restrict__ srcLen, const int *__restrict__ tgtLen, int srcRows, int nPasses,
@@ -210,6 +220,7 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_ker
     const float *__restrict__ abandon = nullptr, unsigned long long *__restrict__ colCtr = nullptr,
     const uint32_t *__restrict__ candSlot = nullptr, int rowOrigin = 0, int spBase = 0)
 {
+    static_assert(!SKIP0 || (!PRUNE && NT >= 2), "SKIP0: unpruned launches of at least two tiles");
     constexpr int REC = kFilterRecHalfs;
     constexpr int BR = NT * 16;            // rows per pass
     const float INF = __builtin_inff();
@@ -309,6 +320,9 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_ker
             const bool haveTop = pass > firstPass;      // wave-uniform
 #endif
             const bool lastPass = pass == nPasses - 1;
+            // SKIP0: the pass's first tile lies above both sources and above the row that starts them (wave-uniform; true in
+            // a task's first pass at most)
+            const bool skip0 = SKIP0 && r0min - rowBase >= 17;
             const bool started = r0 < rowBase + BR;     // PRUNE: the lane's source has rows in this pass or above
 
             // Target records (and the hand-off row above this row block) travel global -> LDS by
@@ -415,9 +429,9 @@ __global__ __launch_bounds__(64 * kFilterWavesPerBlock, OCC) void dtw_filter_ker
                             stageTop((j >> 2) + 1);                 // the next group's top values
                         float bottom;
                         if ((q & 1) == 0)
-                            bottom = dp_column<NT, SQ, KU>(A, B0, B1, acc, up, diag, L0, L1);
+                            bottom = dp_column<NT, SQ, KU, SKIP0>(A, B0, B1, acc, up, diag, L0, L1, skip0);
                         else
-                            bottom = dp_column<NT, SQ, KU>(A, B1, B0, acc, up, diag, L1, L0);
+                            bottom = dp_column<NT, SQ, KU, SKIP0>(A, B1, B0, acc, up, diag, L1, L0, skip0);
                         bq[q] = bottom;
                         if (!lastPass) {
 #ifndef SSYM_ABL_NOHAND

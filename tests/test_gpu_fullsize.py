@@ -301,3 +301,17 @@ def test_ragged_long_sources_multi_pass_classes(dtw, oracle):
     want_idx, want_cost = oracle.dtw_match_all(sf.astype(np.float64), so, ts.astype(np.float64), tos, 13, nthreads=16)
     assert np.array_equal(idx[pick], want_idx)
     assert np.allclose(cost[pick], want_cost, rtol=1e-12, atol=0)
+    # a task's first pass skips the cells of a first tile that holds only padding (dtw_filter_kernel SKIP0): the filter's
+    # values are the same bits with the skip compiled out of the launch, and fewer cells are evaluated with it
+    import os
+    filt = dtw.pair_matrix(d, q, exact=False)
+    os.environ["SSYM_FILTER_SKIP0"] = "0"
+    try:
+        filt0 = dtw.pair_matrix(d, q, exact=False)
+        idx0, cost0 = dtw.match(d, q)
+        cells0 = dtw.timings()["n_filter_cells"]
+    finally:
+        del os.environ["SSYM_FILTER_SKIP0"]
+    assert np.array_equal(filt, filt0) and np.isfinite(filt).all()
+    assert np.array_equal(idx, idx0) and np.array_equal(cost, cost0)
+    assert tm["n_filter_cells"] < 0.97 * cells0, (tm["n_filter_cells"], cells0)
