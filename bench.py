@@ -218,13 +218,13 @@ def ragged_metrics(device: int) -> dict:
     valu_peak_cells = 1024 * 64 / 16.0 * 2.4e9
     e = Engine(metric="dtw", dtype="f32", device=device)
 
-    def dtw_leg(src, tgt, planted=None):
+    def dtw_leg(src, tgt, planted=None, steps=20):
         sf, so = pack_segments(src, 13, np.float32)
         tf, to = pack_segments(tgt, 13, np.float32)
         d, q = e.dictionary(sf, so, 13), e.queries(tf, to, 13)
         for _ in range(5):
             idx, _ = e.match(d, q)
-        steps, kms, tot = 20, [], []
+        kms, tot = [], []
         t0 = time.perf_counter()
         for _ in range(steps):
             idx, _ = e.match(d, q)
@@ -234,7 +234,7 @@ def ragged_metrics(device: int) -> dict:
         dt = (time.perf_counter() - t0) / steps
         true_cells = float(np.diff(so).astype(np.float64).sum()) * float(np.diff(to).astype(np.float64).sum())
         k_s = float(np.mean(kms)) * 1e-3
-        leg = {"value": n * n / dt, "unit": "segment-pairs/s", "ms_per_step": dt * 1e3,
+        leg = {"value": len(src) * len(tgt) / dt, "unit": "segment-pairs/s", "ms_per_step": dt * 1e3,
                "phase_ms": {k: round(float(v), 3) for k, v in tmx.items() if k.endswith("_ms")},
                "filter_ms": k_s * 1e3, "filter_launches": int(tmx["main_launches"]),
                "true_cells_per_s": true_cells / k_s, "true_cells": true_cells,
@@ -258,6 +258,13 @@ def ragged_metrics(device: int) -> dict:
     out["dtw_planted"] = dtw_leg(srcp, tgtp, pi)
     out["dtw_planted"]["workload"] = ("the same shape, every target a source resampled to another length plus noise "
                                       "(synth.make_ragged planted=True)")
+    # the same shape at a dictionary's size: the three class launches' ramp and drain are a tenth of the 1.3 ms search
+    # above and nothing of this one
+    nl = 16384
+    srcl, tgtl = synth.make_ragged(nl, nl, lo, hi, 13, RAGGED_SEED + 3)
+    out["dtw_16384"] = dtw_leg(srcl, tgtl, steps=8)
+    out["dtw_16384"]["workload"] = f"{nl}x{nl} segments of {lo}...{hi} frames x 13 dims, f32, dtw, unrelated targets"
+    del srcl, tgtl
     e.close()
 
     r = Engine(metric="refcos", dtype="f64", device=device)

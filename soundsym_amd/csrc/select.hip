@@ -57,6 +57,14 @@ constexpr unsigned long long kInfBitsSel = 0x7ff0000000000000ull;      // +inf a
 //      err (m = 0) and keeps list 1; certify.hip computes m for list 1; stage 2 applies it again
 //      inside list 1 with the per-pair err and keeps list 2, which is re-scored exactly.
 // ---------------------------------------------------------------------------------------------
+// SSYM_SELECT_PRETEST=0 (tests, measurements): every pair forms its interval in dtw_colmin_kernel / dtw_mark_kernel, as
+// before round 4; the lists are the same either way
+static int select_pretest()
+{
+    const char *k = ssym_knob("SSYM_SELECT_PRETEST");
+    return !(k && atoi(k) == 0);
+}
+
 __global__ void fill_u64_kernel(unsigned long long *p, unsigned long long v, uint32_t n)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -90,7 +98,7 @@ __global__ __launch_bounds__(kSelTgt * kSelSub) void dtw_colmin_kernel(
     uint32_t mPad, const double *__restrict__ dist, const int *__restrict__ srcLen,
     const float *__restrict__ srcMaxSq, const int *__restrict__ tgtLen, const float *__restrict__ tgtMaxSq,
     MarginParams mp, const uint32_t *__restrict__ permT, const unsigned long long *__restrict__ prev,
-    unsigned long long *__restrict__ ub)
+    unsigned long long *__restrict__ ub, int pretest)
 {
     // s, t are record SLOTS (the filter's coordinates); the caller's per-target distance is looked up
     // through the slot's segment
@@ -108,11 +116,29 @@ __global__ __launch_bounds__(kSelTgt * kSelSub) void dtw_colmin_kernel(
         const uint32_t s1 = min(s0 + kSelChunk / kSelSub, nSrc);
         // top-k rounds (prev != NULL): the smallest bound strictly above the previous round's
         const double floorv = prev ? __longlong_as_double((long long)prev[t]) : -1.0;
-        double best = __builtin_inf();
-        for (uint32_t s = s0; s < s1; ++s) {
-            const size_t o = (size_t)s * mPad + t;
+        // ... starting from what the workgroups before this one have already found for the target (any bound in ub[t] is a
+        // key_hi of the same minimum -- or the caller's seed, which takes part in it --, however stale the read)
+        double best = pretest ? __longlong_as_double((long long)ub[t]) : __builtin_inf();
+        // the thread's costs first, all loads in flight together (one dependent load per loop trip left a 16384 x 16384
+        // matrix at 1 TB/s)
+        float cv[kSelChunk / kSelSub];
+#pragma unroll
+        for (uint32_t i = 0; i < kSelChunk / kSelSub; ++i)
+            cv[i] = s0 + i < s1 ? cmat[(size_t)(s0 + i) * mPad + t] : __builtin_inff();
+#pragma unroll
+        for (uint32_t i = 0; i < kSelChunk / kSelSub; ++i) {
+            const uint32_t s = s0 + i;
+            if (s >= s1)
+                break;
+            // key_hi is the larger distance of delta from the ends of an interval that holds the filter cost, so it is at
+            // least |cost - delta|: a pair that far out cannot lower the minimum, and its interval (some 150 f64
+            // instructions, three square roots) is not formed -- all but a few pairs per thread (NaN: skipped as well;
+            // its interval is +inf)
+            const double c = (double)cv[i];
+            if (pretest && !(fabs(c - delta) < best))
+                continue;
             double klo, khi;
-            dtw_key_interval(mp, (double)cmat[o], 0.0, (double)srcMaxSq[s], nb, srcLen[s], fb, delta, klo, khi,
+            dtw_key_interval(mp, c, 0.0, (double)srcMaxSq[s], nb, srcLen[s], fb, delta, klo, khi,
                              (double)srcMaxSq[mp.src_resid_off + s], rb);
             if (khi < best && khi > floorv)
                 best = khi;
@@ -136,7 +162,7 @@ __global__ __launch_bounds__(kSelTgt * kSelSub) void dtw_mark_kernel(
     uint32_t mPad, const double *__restrict__ dist, const int *__restrict__ srcLen,
     const float *__restrict__ srcMaxSq, const int *__restrict__ tgtLen, const float *__restrict__ tgtMaxSq,
     MarginParams mp, const uint32_t *__restrict__ permT, const unsigned long long *__restrict__ ub,
-    unsigned long long *__restrict__ mask, uint32_t *__restrict__ cnt)
+    unsigned long long *__restrict__ mask, uint32_t *__restrict__ cnt, double srcMaxSqAll, int srcMaxFrames, int pretest)
 {
     __shared__ unsigned long long sHits[kSelTgt];
     const uint32_t tx = threadIdx.x % kSelTgt, ty = threadIdx.x / kSelTgt;
@@ -154,10 +180,32 @@ __global__ __launch_bounds__(kSelTgt * kSelSub) void dtw_mark_kernel(
             const uint32_t c0 = blockIdx.y * kSelChunk;
             const uint32_t s0 = c0 + ty * (kSelChunk / kSelSub);
             const uint32_t s1 = min(s0 + kSelChunk / kSelSub, nSrc);
-            for (uint32_t s = s0; s < s1; ++s) {
-                const size_t o = (size_t)s * mPad + t;
+            // A cheap NECESSARY condition first, per target: key_lo <= thr needs lo <= delta + thr and hi >= delta - thr
+            // with lo >= cost - err, hi <= cost + err, and err is at most errMax = A + rel * cost for the longest source
+            // with the largest frame (dtw_cell_error grows with na and with the residual; no certificate, xmin = 0) --
+            // so cost must lie in [loCut, hiCut].  Only pairs that pass form their own interval (the exact test, same
+            // list as before): on unrelated data a few per target instead of all of them.
+            const double u = 5.9604644775390625e-8;
+            const double Lmax = (double)(srcMaxFrames + fb - 1);
+            const double A = 1.02 * Lmax * dtw_cell_error(mp, 0.0, srcMaxSqAll, nb, -1.0, rb) * (1.0 + 1e-9) + 1e-300;
+            const double rel = (Lmax + 6.0) * u * (1.0 + 1e-9);
+            const double hiCut = rel < 0.5 ? (delta + thr + A) / (1.0 - rel) * (1.0 + 1e-9) + 1e-290 : __builtin_inf();
+            const double loRaw = (delta - thr - A) / (1.0 + rel);
+            const double loCut = mp.lower_only ? -__builtin_inf() : (loRaw > 0.0 ? loRaw * (1.0 - 1e-9) - 1e-290 : -__builtin_inf());
+            float cv[kSelChunk / kSelSub];                           // all of the thread's loads in flight together
+#pragma unroll
+            for (uint32_t i = 0; i < kSelChunk / kSelSub; ++i)
+                cv[i] = s0 + i < s1 ? cmat[(size_t)(s0 + i) * mPad + t] : __builtin_inff();
+#pragma unroll
+            for (uint32_t i = 0; i < kSelChunk / kSelSub; ++i) {
+                const uint32_t s = s0 + i;
+                if (s >= s1)
+                    break;
+                const double c = (double)cv[i];
+                if (pretest && !(c <= hiCut && c >= loCut))        // (NaN fails both: its interval is +inf, never a hit)
+                    continue;
                 double klo, khi;
-                dtw_key_interval(mp, (double)cmat[o], 0.0, (double)srcMaxSq[s], nb, srcLen[s], fb, delta, klo, khi,
+                dtw_key_interval(mp, c, 0.0, (double)srcMaxSq[s], nb, srcLen[s], fb, delta, klo, khi,
                                  (double)srcMaxSq[mp.src_resid_off + s], rb);
                 if (klo <= thr)
                     hits |= 1ull << (s - c0);
@@ -648,9 +696,10 @@ int32_t launch_dtw_bounds(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
     else
         fill_u64_kernel<<<(tgt.n + 255) / 256, 256, 0, st>>>(ub, kInfBits, tgt.n);
     dim3 grid((tgt.n + kSelTgt - 1) / kSelTgt, nChunks);
+    const int pretest = select_pretest();
     if (k_top <= 1) {
         dtw_colmin_kernel<<<grid, kSelTgt * kSelSub, 0, st>>>(cmat, src.n, tgt.n, tgt.n_pad, dist_dev, src.len,
-                                                src.max_sqnorm, tgt.len, tgt.max_sqnorm, mp, tgt.perm, nullptr, ub);
+                                                src.max_sqnorm, tgt.len, tgt.max_sqnorm, mp, tgt.perm, nullptr, ub, pretest);
     } else {
         unsigned long long *prev;
         uint32_t *prevIdx;
@@ -659,7 +708,7 @@ int32_t launch_dtw_bounds(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
             return rc;
         for (uint32_t r = 0; r < k_top; ++r) {
             dtw_colmin_kernel<<<grid, kSelTgt * kSelSub, 0, st>>>(cmat, src.n, tgt.n, tgt.n_pad, dist_dev, src.len, src.max_sqnorm,
-                                                    tgt.len, tgt.max_sqnorm, mp, tgt.perm, r ? prev : nullptr, ub);
+                                                    tgt.len, tgt.max_sqnorm, mp, tgt.perm, r ? prev : nullptr, ub, pretest);
             topk_advance_kernel<<<(tgt.n + 255) / 256, 256, 0, st>>>(ub, prev, tgt.n, (int)r, r + 1 == k_top);
         }
     }
@@ -877,7 +926,8 @@ int32_t launch_dtw_select(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
     dim3 grid((tgt.n + 255) / 256, nChunks);
     dim3 markGrid((tgt.n + kSelTgt - 1) / kSelTgt, nChunks);
     dtw_mark_kernel<<<markGrid, kSelTgt * kSelSub, 0, st>>>(cmat, src.n, tgt.n, tgt.n_pad, dist_dev, src.len,
-                                          src.max_sqnorm, tgt.len, tgt.max_sqnorm, mp, tgt.perm, ub, mask, cnt);
+                                          src.max_sqnorm, tgt.len, tgt.max_sqnorm, mp, tgt.perm, ub, mask, cnt,
+                                          src.max_sqnorm_all, (int)src.max_frames, select_pretest());
     dtw_scan_kernel<<<1, 1024, 0, st>>>(cnt, tgt.n, cap, hdr);
     dtw_scatter_kernel<<<grid, 256, 0, st>>>(mask, tgt.n, cnt, fill, hdr, pairs);
     SSYM_HIP_CHECK(ctx, hipGetLastError());

@@ -730,3 +730,52 @@ def test_dtw_few_queries_single_launch_equals_the_batched_path(oracle, dtype, di
     ri, rv = e.match(d, e.queries(tf, to, dim), distance=dist, force_exact=True)
     assert np.array_equal(bi, ri) and np.array_equal(bv, rv)
     e.close()
+
+
+@pytest.mark.parametrize("band,squared,dim,with_dist,k", [(-1, False, 13, False, 1), (-1, False, 13, True, 1),
+                                                          (-1, True, 13, False, 1), (8, False, 13, True, 1),
+                                                          (-1, False, 50, False, 1), (-1, False, 13, True, 4),
+                                                          (-1, False, 20, False, 3)])
+def test_selection_pretests_keep_the_lists(oracle, band, squared, dim, with_dist, k):
+    # dtw_colmin_kernel / dtw_mark_kernel form a pair's key interval only when a cheap necessary condition on its filter
+    # cost holds (select.hip): bounds, candidate lists, indices and costs are those of the run that forms every interval
+    # (SSYM_SELECT_PRETEST=0), and the oracle's -- unrelated and planted ragged segments, per-target distances on both
+    # sides of the costs (the interval test then has a lower AND an upper cut), bands, squared costs, frames wider than the
+    # filter takes in (its cost is a lower bound only: no lower cut), top-k rounds
+    import os
+    src, tgt = synth.make_ragged(300, 200, 3, 70, dim, 0x5EED0C00 + dim + (band & 0xff) + 7 * k)
+    for t in range(0, 200, 3):
+        tgt[t] = (src[(11 * t) % 300] * np.float32(1.0 + 0.002 * (t % 5))).astype(np.float32)
+    sf, so = pack_segments(src, dim, np.float32)
+    tf, to = pack_segments(tgt, dim, np.float32)
+    e = Engine(metric="dtw", dtype="f32", band=band, squared=squared)
+    d, q = e.dictionary(sf, so, dim), e.queries(tf, to, dim)
+    dist = None
+    if with_dist:
+        base = e.match(d, q)[1]
+        fin = np.where(np.isfinite(base), base, 0.0)
+        dist = fin * np.tile([0.0, 0.5, 1.0, 1.5, 3.0], 40) + np.tile([0.0, 0.1, 0.0, 7.0, 0.0], 40)
+
+    def run():
+        if k > 1:
+            r = e.match_topk(d, q, k, distance=dist)
+        else:
+            r = e.match(d, q, distance=dist)
+        return r[0].copy(), r[1].copy(), int(e.timings()["n_refined"])
+
+    on = run()
+    os.environ["SSYM_SELECT_PRETEST"] = "0"
+    try:
+        off = run()
+    finally:
+        del os.environ["SSYM_SELECT_PRETEST"]
+    assert np.array_equal(on[0], off[0]) and np.array_equal(on[1], off[1], equal_nan=True) and on[2] == off[2]
+    if k == 1:
+        _, _, mat = oracle.dtw_match_all(sf.astype(np.float64), so, tf.astype(np.float64), to, dim, band=band,
+                                         squared=squared, nthreads=8, want_matrix=True)
+        key = np.where(np.isfinite(mat), np.abs(mat - (dist[None, :] if dist is not None else 0.0)), np.inf)
+        have = np.isfinite(key).any(axis=0)
+        want = np.where(have, key.argmin(axis=0), 0)
+        assert np.array_equal(on[0], want)
+        assert np.allclose(on[1][have], mat[want, np.arange(len(tgt))][have], rtol=EXACT_RTOL, atol=0)
+    e.close()
