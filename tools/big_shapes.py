@@ -22,8 +22,9 @@ t0 = time.perf_counter()
 idx, cost = e.match(dd, q)
 dt = time.perf_counter() - t0
 tm = e.timings()
-print("dtw %d x %d (%.3g pairs): %.2f s, filter %.1f ms, planted ok %s, refined %d" % (
-    n, m, float(n) * m, dt, tm["main_ms"], bool(np.array_equal(idx, perm)), tm["n_refined"]), flush=True)
+print("dtw %d x %d (%.3g pairs): %.3f s, filter %.1f ms, selection %.1f ms, re-scoring %.1f ms, planted ok %s, refined %d" % (
+    n, m, float(n) * m, dt, tm["main_ms"], tm["select_ms"], tm["refine_ms"], bool(np.array_equal(idx, perm)), tm["n_refined"]),
+    flush=True)
 assert np.array_equal(idx, perm)
 e.close()
 r = Engine(metric="refcos", dtype="f64")
