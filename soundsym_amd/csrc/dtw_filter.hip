@@ -302,10 +302,15 @@ static void launch_one(hipStream_t st, const SegmentSet &src, const SegmentSet &
     static const bool spOn = !(ssym_knob("SSYM_FILTER_SP") && atoi(ssym_knob("SSYM_FILTER_SP")) == 0);
     // (with three operand planes its LDS -- ring and staging block -- admits two workgroups per CU up to two tiles)
     // sources of at most 16 frames: three source pairs per wave (two with three operand planes: LDS), dtw_filter_sp_kernel MP
-    static const bool mpOn = !(ssym_knob("SSYM_SP_MULTIPAIR") && atoi(ssym_knob("SSYM_SP_MULTIPAIR")) == 0);
+    // (SSYM_SP_MULTIPAIR, read per launch: 0 = never, 2 = whatever the size -- the tests' way to small multi-pair launches)
+    const char *mpKnob = ssym_knob("SSYM_SP_MULTIPAIR");
+    const bool mpOn = !(mpKnob && atoi(mpKnob) == 0), mpAlways = mpKnob && atoi(mpKnob) == 2;
     if constexpr (NT == 1) {
-        if (!abandon && nPasses == 1 && spOn && mpOn) {
-            constexpr int MPN = KU == 2 ? 3 : 2;
+        // (... when the multi-pair tasks still give every wave slot of the chip one: a 284 x 55 search is 96 of them, each
+        //  sweeping its group's longest target three pairs wide while nine tenths of the SIMDs idle -- one pair per wave there)
+        constexpr int MPN = KU == 2 ? 3 : 2;
+        const long mpTasksWanted = (long)((nSrcPairs + MPN - 1) / MPN) * nTgtGroups;
+        if (!abandon && nPasses == 1 && spOn && mpOn && (mpAlways || mpTasksWanted >= (long)gridBlocks / OCC * 2 * kFilterWavesPerBlock)) {
             const int taskPairs = (nSrcPairs + MPN - 1) / MPN;
             const int mpTasks = taskPairs * nTgtGroups;
             const int gridMp = std::min(gridBlocks / OCC * 2, ((mpTasks + kFilterWavesPerBlock - 1) / kFilterWavesPerBlock + 7) / 8 * 8);

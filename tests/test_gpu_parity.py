@@ -779,3 +779,36 @@ def test_selection_pretests_keep_the_lists(oracle, band, squared, dim, with_dist
         assert np.array_equal(on[0], want)
         assert np.allclose(on[1][have], mat[want, np.arange(len(tgt))][have], rtol=EXACT_RTOL, atol=0)
     e.close()
+
+
+def test_multi_pair_tasks_small_and_forced(oracle):
+    # sources of at most 16 frames run three pairs per wave only when such tasks fill the chip (dtw_filter.hip); a small
+    # search takes one pair per wave.  SSYM_SP_MULTIPAIR=2 forces the multi-pair kernel onto the small search: the filter's
+    # matrix is the same bits either way -- ragged lengths 0...16, pair counts that do not divide by three, an empty source
+    import os
+    st = synth.Stream(0x5EED0C77)
+    sig = synth.sigma(13)
+    for n, m in ((37, 70), (128, 33), (5, 5)):
+        ls = st.integers(n, 17)
+        lt = 1 + st.integers(m, 60)
+        src = [(st.normal(int(f) * 13).reshape(int(f), 13) * sig).astype(np.float32) for f in ls]
+        tgt = [(st.normal(int(f) * 13).reshape(int(f), 13) * sig).astype(np.float32) for f in lt]
+        sf, so = pack_segments(src, 13, np.float32)
+        tf, to = pack_segments(tgt, 13, np.float32)
+        e = Engine(metric="dtw", dtype="f32")
+        d, q = e.dictionary(sf, so, 13), e.queries(tf, to, 13)
+        plain = e.pair_matrix(d, q, exact=False)
+        idx, cost = e.match(d, q)
+        os.environ["SSYM_SP_MULTIPAIR"] = "2"
+        try:
+            forced = e.pair_matrix(d, q, exact=False)
+            idx2, cost2 = e.match(d, q)
+        finally:
+            del os.environ["SSYM_SP_MULTIPAIR"]
+        assert np.array_equal(plain, forced)
+        assert np.array_equal(idx, idx2) and np.array_equal(cost, cost2, equal_nan=True)
+        want_idx, want_cost = oracle.dtw_match_all(sf.astype(np.float64), so, tf.astype(np.float64), to, 13, nthreads=8)
+        assert np.array_equal(idx, want_idx)
+        fin = np.isfinite(want_cost)
+        assert np.array_equal(np.isfinite(cost), fin) and np.allclose(cost[fin], want_cost[fin], rtol=EXACT_RTOL, atol=0)
+        e.close()
