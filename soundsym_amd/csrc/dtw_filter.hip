@@ -637,11 +637,13 @@ int32_t launch_dtw_filter(ssym_ctx *ctx, const SegmentSet &src, const SegmentSet
             const bool skipOn = !(skipKnob && atoi(skipKnob) == 0);
             for (int c = 0; c < nCls; ++c) {
                 const int origin = rowsPad - 16 * cls[c].nt * cls[c].passes;
-                // the class's shortest pair leaves the first tile of its first pass empty: the variant that skips such
-                // tiles' cells (equal lengths and classes that fill their rows keep the plain kernel)
+                // at least an eighth of the class's pairs leave the first tile of their first pass empty: the variant that
+                // skips such tiles' cells (equal lengths and classes that fill their rows keep the plain kernel)
                 const int rowsCls = 16 * cls[c].nt * cls[c].passes;
-                const int shortest = cls[c].lo < nRealPairs ? (int)pairLen(cls[c].lo) : rowsCls;
-                skipTile = skipOn && (rowsCls - shortest) % (16 * cls[c].nt) >= 17;
+                int skipping = 0;
+                for (int sp = cls[c].lo; sp < std::min(cls[c].hi, nRealPairs); ++sp)
+                    skipping += (rowsCls - (int)pairLen(sp)) % (16 * cls[c].nt) >= 17;
+                skipTile = skipOn && 8 * skipping >= cls[c].hi - cls[c].lo && skipping > 0;
                 if (cls[c].nt == 3) {
                     SSYM_LAUNCH(3, cls[c].passes, origin, cls[c].lo, cls[c].hi, 3 + c)
                 } else {
