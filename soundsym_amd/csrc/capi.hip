@@ -706,17 +706,44 @@ static int32_t match_impl(ssym_ctx *ctx, const ssym_dict *dict, const ssym_queri
                     ctx->timings = tm;
                     return SSYM_OK;
                 }
-                uint32_t h1[2] = {0, 0}, h2[2] = {0, 0};
-                unsigned gave[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                SSYM_HIP_CHECK(ctx, hipMemcpyAsync(h1, hdr1, sizeof(h1), hipMemcpyDeviceToHost, st));
-                SSYM_HIP_CHECK(ctx, hipMemcpyAsync(h2, hdr2, sizeof(h2), hipMemcpyDeviceToHost, st));
+                // ONE synchronisation per attempt: the lists' header words land in the pinned window (a copy into
+                // pageable memory is a host round trip of its own: three of them and a second synchronisation for the
+                // results were 60-80 us of a call), and the host results are requested in front of it -- an
+                // overflowing list 1 (rare) drops them and asks again after the repeat
+                uint32_t h1s[2] = {0, 0}, h2s[2] = {0, 0};
+                unsigned gaves[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                uint32_t *hw = ctx->api_depth > 0 ? (uint32_t *)stage_take(ctx, 12 * sizeof(uint32_t)) : nullptr;
+                uint32_t *h1 = hw ? hw : h1s, *h2 = hw ? hw + 2 : h2s;
+                unsigned *gave = hw ? hw + 4 : gaves;
+                if (hw)
+                    memset(hw, 0, 12 * sizeof(uint32_t));
+                SSYM_HIP_CHECK(ctx, hipMemcpyAsync(h1, hdr1, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                SSYM_HIP_CHECK(ctx, hipMemcpyAsync(h2, hdr2, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
                 if (ctx->pipe_mask)
-                    SSYM_HIP_CHECK(ctx, hipMemcpyAsync(gave, ctx->pipe_flag.ptr, sizeof(gave), hipMemcpyDeviceToHost, st));
+                    SSYM_HIP_CHECK(ctx, hipMemcpyAsync(gave, ctx->pipe_flag.ptr, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+                const size_t pendingBefore = ctx->pending_d2h.size();
+                bool stagedHere = false;
+                if (!outDev && ctx->api_depth > 0) {
+                    rc = stage_d2h(ctx, out_idx, idxDev, sizeof(uint32_t) * (size_t)M * k_top);
+                    if (rc == SSYM_OK && out_cost)
+                        rc = stage_d2h(ctx, out_cost, costDev, sizeof(double) * (size_t)M * k_top);
+                    if (rc != SSYM_OK)
+                        return rc;
+                    // (a result too large for the window went straight to the caller's memory: still behind this
+                    //  synchronisation, and harmlessly overwritten by a repeat)
+                    stagedHere = true;
+                }
                 SSYM_HIP_CHECK(ctx, hipStreamSynchronize(st));
                 for (int i = 0; i < 8; ++i)
                     if ((ctx->pipe_mask >> i & 1u) && gave[i])
                         ++tm.exact_redone;
                 ctx->pipe_mask = 0;
+                if (stagedHere) {
+                    if (h1[1] && !(attempt == 1 || cap == (uint64_t)N * M))
+                        ctx->pending_d2h.resize(pendingBefore);      // the repeat's results are the ones to hand over
+                    else
+                        outputsStaged = true;
+                }
                 if (attempt == 0 && phase != 2)
                     sel_ms += ev_ms(ev[1], ev[2]);      // the per-target threshold (bounds) belongs to selection
                 sel_ms += ev_ms(ev[2], ev[3]);
